@@ -1,0 +1,174 @@
+/*
+ * lanczos_hip.h - C ABI of liblanczos_hip.so (MI355X / gfx950 Lanczos hot path).
+ *
+ * The reference (jgslunde/Lanczos) has no FFI layer: its only interface is the
+ * Python class surface of Python/Regular/Lanczos.py:11-337 and
+ * Python/Irregular/IrrLanczos.py:12-554, whose "GPU backend" is a run of CuPy
+ * library calls.  Each entry point below therefore cites the CuPy/NumPy call
+ * sites of the reference that it replaces (paths relative to /root/reference).
+ * The Python host mirror of the class surface lives in lanczos_amd/ and reaches
+ * this library through ctypes only (no torch types cross this boundary).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = LZ_OK, negative = error;
+ *     lz_last_error(h) returns a human-readable message for the last failure.
+ *   - the caller owns all host buffers (pointer + explicit sizes); the library
+ *     owns all device memory behind the opaque handle.
+ *   - fp64 values, int32 CSR indices, row-major everywhere.
+ *   - one handle = one GPU = one rank.  A handle is not thread-safe.
+ *   - distributed runs: the basis, r and the matrix are row-block partitioned;
+ *     "local" sizes refer to this rank's rows.
+ */
+#ifndef LANCZOS_HIP_H
+#define LANCZOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lz_context* lz_handle;
+
+enum lz_status {
+  LZ_OK = 0,
+  LZ_ERR_ARG = -1,       /* bad argument / shape */
+  LZ_ERR_HIP = -2,       /* HIP runtime error */
+  LZ_ERR_COMM = -3,      /* RCCL / host-collective error */
+  LZ_ERR_STATE = -4,     /* call order violated (e.g. run before set_csr) */
+  LZ_ERR_NOMEM = -5,     /* device allocation failed */
+  LZ_ERR_NODEVICE = -6   /* no usable GPU */
+};
+
+/* flags for lz_run / lz_set_options */
+enum lz_flags {
+  LZ_FLAG_NONE = 0,
+  LZ_FLAG_PROFILE = 1,        /* bracket every hot kernel with hipEvents (lz_get_timings) */
+  LZ_FLAG_QTW_MFMA = 2,       /* use the MFMA (v_mfma_f64_16x16x4_f64) Q^T w kernel        */
+  LZ_FLAG_QTW_VALU = 4,       /* force the VALU/shuffle Q^T w kernel                      */
+  LZ_FLAG_SPMV_SCALAR = 8,    /* force the plain one-thread-per-row CSR kernel            */
+  LZ_FLAG_FUSED_NORM = 16     /* multi-rank only: fold ||r||^2 into the Q^T r all-reduce   */
+};
+
+/* kernel classes reported by lz_get_timings */
+enum lz_kernel_class {
+  LZ_K_SPMV = 0,     /* r = A v_j with fused alpha partials             */
+  LZ_K_QTW = 1,      /* v_j = r/beta; c = Q^T v_j (reorth pass 1)        */
+  LZ_K_UPDATE = 2,   /* v_j = 2 v_j - Q c        (reorth pass 2)        */
+  LZ_K_THREE = 3,    /* r = r - alpha v_j - beta v_{j-1}; ||r||^2        */
+  LZ_K_FINAL = 4,    /* tiny second-stage reductions                    */
+  LZ_K_COMM = 5,     /* all-reduce / halo exchange / all-gather         */
+  LZ_K_RITZ = 6,     /* Y = V^T-layout GEMM (FP64 MFMA)                 */
+  LZ_K_COUNT = 7
+};
+
+typedef struct lz_timings {
+  double ms[LZ_K_COUNT];        /* summed device time per class (hipEvent)        */
+  double bytes[LZ_K_COUNT];     /* summed ALGORITHMIC bytes per class */
+  double flops[LZ_K_COUNT];     /* summed algorithmic flops per class             */
+  int64_t launches[LZ_K_COUNT]; /* number of launches per class                   */
+  double total_ms;              /* device time of the whole lz_run (events)       */
+} lz_timings;
+
+/* ---- library / device ------------------------------------------------- */
+int lz_version(void);
+int lz_device_count(int* count);
+/* Replaces: `import cupy as np` backend switch, Lanczos.py:85-88. */
+int lz_create(lz_handle* out, int device_id);
+int lz_destroy(lz_handle h);
+const char* lz_last_error(lz_handle h); /* h may be NULL: last error of lz_create */
+int lz_set_options(lz_handle h, int flags);
+int lz_device_synchronize(lz_handle h);
+int lz_device_name(lz_handle h, char* buf, size_t buflen);
+/* vectors are padded to 256-byte multiples on the device; in halo mode the ghost
+ * entries of the extended local vector start at index lz_padded_rows(rows_local). */
+int64_t lz_padded_rows(int64_t rows);
+
+/* ---- distributed setup (optional; default is a single rank) ------------
+ * The reference has no communication layer; the
+ * partition below is this build's own design: rows are split in contiguous
+ * blocks, alpha/beta/c are summed with an all-reduce, and the SpMV input is
+ * exchanged either as neighbour halos (send/recv lists) or as an all-gather. */
+int lz_comm_unique_id(void* id, size_t id_bytes); /* >= 128 bytes; rank 0 calls, host broadcasts */
+int lz_comm_init_rccl(lz_handle h, int world, int rank, const void* id, size_t id_bytes);
+/* host-staged collectives (tests / fallback): the library copies device data to
+ * the given host buffer, calls back, and copies the result to the device. */
+typedef int (*lz_host_allreduce_fn)(void* user, double* buf, int64_t count);
+/* peers/send_counts/recv_counts have npeers entries; sendbuf/recvbuf are the
+ * concatenated per-peer segments in peer order. */
+typedef int (*lz_host_exchange_fn)(void* user, int npeers, const int32_t* peers, const double* sendbuf,
+                                   const int64_t* send_counts, double* recvbuf, const int64_t* recv_counts);
+/* allgather: sendbuf (count doubles) -> recvbuf (world*count doubles) */
+typedef int (*lz_host_allgather_fn)(void* user, const double* sendbuf, double* recvbuf, int64_t count);
+int lz_comm_init_host(lz_handle h, int world, int rank, lz_host_allreduce_fn ar, lz_host_exchange_fn ex,
+                      lz_host_allgather_fn ag, void* user);
+
+/* ---- matrix ----------------------------------------------------------- *
+ * Replaces: cupyx.scipy.sparse.csr_matrix(H, dtype=float64), Lanczos.py:88
+ * (csc_matrix in IrrLanczos.py:205; a symmetric CSC is the same arrays).
+ * Single rank: rows_local == M_global, ncols_ext == M_global.
+ * Multi rank : this rank's row block; colidx index the EXTENDED local vector
+ *   [ owned rows (rows_local) | ghost entries ... ] of length ncols_ext
+ *   (halo mode, see lz_set_halo) or the padded global vector (all-gather mode,
+ *   see lz_set_allgather). */
+int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext, int64_t nnz,
+               const int32_t* rowptr, const int32_t* colidx, const double* vals);
+/* Dense row-major A (M x M), single rank only.  Replaces the dense->CSR
+ * conversion the reference's GPU path performs for ndarray input
+ * (1Dbox.py:27 -> Lanczos.py:88) with a real dense GEMV. */
+int lz_set_dense(lz_handle h, int64_t M, const double* A);
+/* halo plan: for peer p (npeers of them) send x[send_idx[..]] (local row
+ * indices, send_counts[p] of them, concatenated) and receive recv_counts[p]
+ * doubles into the ghost region, in peer order. */
+int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* send_counts, const int32_t* send_idx,
+                const int64_t* recv_counts);
+/* all-gather plan: every rank owns `chunk` padded rows; x_full has world*chunk entries. */
+int lz_set_allgather(lz_handle h, int64_t chunk);
+
+/* ---- the Lanczos run --------------------------------------------------- *
+ * Replaces Lanczos.py:104-119 (== IrrLanczos.py:222-238): basis allocation,
+ * warm-up step and the Krylov loop with full re-orthogonalisation, with the
+ * reference CPU branch's arithmetic (reorthogonalize, Lanczos.py:247-249).
+ * v0_local: this rank's rows of the NORMALISED start vector (Lanczos.py:93-100
+ * is done by the host mirror with NumPy's legacy RNG).  alpha_out[n],
+ * beta_out[n-1] (n >= 2) receive the recurrence coefficients (replicated on all
+ * ranks); beta follows the reference's indexing (beta[j-1] set at step j). */
+int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double* beta_out);
+/* Krylov basis, row-major (n, rows_local): basis vector j is row j
+ * (replaces cp.asnumpy(V.T), Lanczos.py:136; the mirror exposes the transposed view). */
+int lz_get_basis(lz_handle h, double* V_out, int64_t ld);
+/* Ritz back-transform Y = V_cols * S  (Lanczos.py:153-156: n GEMVs np.dot(V, S[:, i])):
+ * S is (n, n) row-major (columns = eigenvectors of H_eff), Y_out is (rows_local, n) row-major. */
+int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out);
+/* Device-side versions of the two checks get_H_eigs runs on Y (Lanczos.py:157-158,
+ * 288-323): column norms (n) and the (n, n) Gram matrix Y^T Y, computed on the
+ * device-resident Y of the last lz_ritz_vectors call (summed over ranks). */
+int lz_ritz_gram(lz_handle h, double* gram_out);
+/* y_i = A * Y[:, i] residual check used by print_good_eigs (Lanczos.py:166-185):
+ * out[i] = (A y_i . y_i)^2 / (||A y_i||^2), for all n columns. */
+int lz_ritz_quality(lz_handle h, double* out);
+int lz_get_timings(lz_handle h, lz_timings* out);
+
+/* ---- single steps (unit parity tests drive the kernels one by one) ------ */
+/* allocate a zeroed basis of n rows + r (what lz_run does first, Lanczos.py:104-107) */
+int lz_basis_alloc(lz_handle h, int n);
+int lz_basis_set_row(lz_handle h, int j, const double* row_local); /* host -> V[j] */
+int lz_basis_get_row(lz_handle h, int j, double* row_local);       /* V[j] -> host */
+int lz_r_set(lz_handle h, const double* r_local);
+int lz_r_get(lz_handle h, double* r_local);
+/* r = A V[j]; *dot_out = V[j] . r   (Lanczos.py:116-118) */
+int lz_step_spmv(lz_handle h, int j, double* dot_out);
+/* V[j] = r / ||r|| (if scale != 0; *beta_out = ||r||) then the reference's
+ * reorthogonalize(V, j) over rows [0, nrows): c = V V[j]; V[j] = 2 V[j] - c^T V
+ * (Lanczos.py:112-115, 247-249).  c_out[nrows] receives the coefficients. */
+int lz_step_reorth(lz_handle h, int j, int nrows, int scale, double* beta_out, double* c_out);
+/* r = r - alpha V[j] - beta V[jm1] (jm1 < 0: term skipped); *norm2_out = ||r||^2 (Lanczos.py:119,112) */
+int lz_step_three_term(lz_handle h, int j, int jm1, double alpha, double beta, double* norm2_out);
+/* y = A x on host vectors (length rows_local / ncols_ext handled internally; single rank) */
+int lz_spmv_host(lz_handle h, const double* x, double* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANCZOS_HIP_H */

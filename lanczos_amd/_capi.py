@@ -1,0 +1,354 @@
+"""ctypes binding of liblanczos_hip.so (include/lanczos_hip.h).
+
+The library is the only compute backend of this package: if it cannot be
+loaded, or no GPU is present, every compute call raises - there is no CPU
+fallback (the NumPy path is the reference's own and lives, as a checker, under
+oracle/ for the tests only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblanczos_hip.so")
+
+LZ_OK = 0
+STATUS_NAMES = {0: "LZ_OK", -1: "LZ_ERR_ARG", -2: "LZ_ERR_HIP", -3: "LZ_ERR_COMM", -4: "LZ_ERR_STATE", -5: "LZ_ERR_NOMEM", -6: "LZ_ERR_NODEVICE"}
+
+FLAG_PROFILE = 1
+FLAG_QTW_MFMA = 2
+FLAG_QTW_VALU = 4
+FLAG_SPMV_SCALAR = 8
+FLAG_FUSED_NORM = 16
+
+KERNEL_CLASSES = ("spmv", "qtw", "update", "three_term", "final", "comm", "ritz")
+K_COUNT = len(KERNEL_CLASSES)
+
+
+class LzTimings(C.Structure):
+    _fields_ = [
+        ("ms", C.c_double * K_COUNT),
+        ("bytes", C.c_double * K_COUNT),
+        ("flops", C.c_double * K_COUNT),
+        ("launches", C.c_int64 * K_COUNT),
+        ("total_ms", C.c_double),
+    ]
+
+
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+HOST_EXCHANGE_FN = C.CFUNCTYPE(
+    C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+)
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_I32 = C.POINTER(C.c_int32)
+_I64 = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes): every symbol include/lanczos_hip.h declares
+SIGNATURES = {
+    "lz_version": (C.c_int, []),
+    "lz_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "lz_create": (C.c_int, [C.POINTER(_P), C.c_int]),
+    "lz_destroy": (C.c_int, [_P]),
+    "lz_last_error": (C.c_char_p, [_P]),
+    "lz_set_options": (C.c_int, [_P, C.c_int]),
+    "lz_device_synchronize": (C.c_int, [_P]),
+    "lz_device_name": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
+    "lz_padded_rows": (C.c_int64, [C.c_int64]),
+    "lz_comm_unique_id": (C.c_int, [_P, C.c_size_t]),
+    "lz_comm_init_rccl": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
+    "lz_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, HOST_ALLGATHER_FN, _P]),
+    "lz_set_csr": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _I32, _I32, _D]),
+    "lz_set_dense": (C.c_int, [_P, C.c_int64, _D]),
+    "lz_set_halo": (C.c_int, [_P, C.c_int, _I32, _I64, _I32, _I64]),
+    "lz_set_allgather": (C.c_int, [_P, C.c_int64]),
+    "lz_run": (C.c_int, [_P, C.c_int, _D, _D, _D]),
+    "lz_get_basis": (C.c_int, [_P, _D, C.c_int64]),
+    "lz_ritz_vectors": (C.c_int, [_P, _D, _D]),
+    "lz_ritz_gram": (C.c_int, [_P, _D]),
+    "lz_ritz_quality": (C.c_int, [_P, _D]),
+    "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
+    "lz_basis_alloc": (C.c_int, [_P, C.c_int]),
+    "lz_basis_set_row": (C.c_int, [_P, C.c_int, _D]),
+    "lz_basis_get_row": (C.c_int, [_P, C.c_int, _D]),
+    "lz_r_set": (C.c_int, [_P, _D]),
+    "lz_r_get": (C.c_int, [_P, _D]),
+    "lz_step_spmv": (C.c_int, [_P, C.c_int, _D]),
+    "lz_step_reorth": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D, _D]),
+    "lz_step_three_term": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, _D]),
+    "lz_spmv_host": (C.c_int, [_P, _D, _D]),
+}
+
+
+class LanczosHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP extension and bind every declared symbol.  Raises
+    ``LanczosHipError`` (never falls back) when the library is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.isfile(p):
+        raise LanczosHipError(-6, f"HIP extension not built: {p} is missing (run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C lanczos_amd/csrc`)")
+    try:
+        lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise LanczosHipError(-6, f"cannot load {p}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(_D)
+
+
+def i32ptr(a):
+    return a.ctypes.data_as(_I32)
+
+
+def i64ptr(a):
+    return a.ctypes.data_as(_I64)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Handle:
+    """Thin RAII wrapper over ``lz_handle``: raises on every non-zero status."""
+
+    def __init__(self, device_id=0):
+        self.lib = load_library()
+        self._h = _P()
+        st = self.lib.lz_create(C.byref(self._h), int(device_id))
+        if st != LZ_OK:
+            msg = self.lib.lz_last_error(None).decode()
+            self._h = None
+            raise LanczosHipError(st, msg)
+        self._keep = []  # keeps ctypes callbacks alive
+
+    def check(self, st):
+        if st != LZ_OK:
+            raise LanczosHipError(st, self.lib.lz_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.lz_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- info / options
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self.check(self.lib.lz_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def set_options(self, flags):
+        self.check(self.lib.lz_set_options(self._h, int(flags)))
+
+    def synchronize(self):
+        self.check(self.lib.lz_device_synchronize(self._h))
+
+    def padded_rows(self, rows):
+        return int(self.lib.lz_padded_rows(int(rows)))
+
+    # -- communication
+    def unique_id(self):
+        buf = C.create_string_buffer(128)
+        st = self.lib.lz_comm_unique_id(buf, 128)
+        if st != LZ_OK:
+            raise LanczosHipError(st, self.lib.lz_last_error(None).decode())
+        return buf.raw
+
+    def comm_init_rccl(self, world, rank, uid):
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self.check(self.lib.lz_comm_init_rccl(self._h, int(world), int(rank), buf, 128))
+
+    def comm_init_host(self, world, rank, allreduce, exchange=None, allgather=None):
+        """``allreduce(np.ndarray)`` sums in place over ranks; ``exchange(peers, send_segments) -> recv_segments``;
+        ``allgather(np.ndarray) -> np.ndarray (world*count)``."""
+
+        def _ar(user, buf, count):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(count,))
+                allreduce(a)
+                return 0
+            except Exception:  # pragma: no cover - surfaced as LZ_ERR_COMM
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def _ex(user, npeers, peers, sendbuf, scount, recvbuf, rcount):
+            try:
+                pr = [int(peers[i]) for i in range(npeers)]
+                sc = [int(scount[i]) for i in range(npeers)]
+                rc = [int(rcount[i]) for i in range(npeers)]
+                s = np.ctypeslib.as_array(sendbuf, shape=(max(sum(sc), 1),))
+                r = np.ctypeslib.as_array(recvbuf, shape=(max(sum(rc), 1),))
+                so = np.concatenate([[0], np.cumsum(sc)]).astype(int)
+                ro = np.concatenate([[0], np.cumsum(rc)]).astype(int)
+                out = exchange(pr, [s[so[i] : so[i + 1]].copy() for i in range(npeers)], rc)
+                for i in range(npeers):
+                    r[ro[i] : ro[i + 1]] = out[i]
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        def _ag(user, sendbuf, recvbuf, count):
+            try:
+                s = np.ctypeslib.as_array(sendbuf, shape=(count,))
+                r = np.ctypeslib.as_array(recvbuf, shape=(count * world,))
+                r[:] = allgather(s.copy())
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        cbs = (HOST_ALLREDUCE_FN(_ar), HOST_EXCHANGE_FN(_ex), HOST_ALLGATHER_FN(_ag))
+        self._keep.append(cbs)
+        self.check(self.lib.lz_comm_init_host(self._h, int(world), int(rank), cbs[0], cbs[1], cbs[2], None))
+
+    # -- matrix
+    def set_csr(self, M_global, row0, rowptr, colidx, vals, ncols_ext=None):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+        vals = f64(vals)
+        rows = len(rowptr) - 1
+        nnz = int(rowptr[-1])
+        if ncols_ext is None:
+            ncols_ext = M_global
+        self.check(self.lib.lz_set_csr(self._h, int(M_global), int(row0), rows, int(ncols_ext), nnz, i32ptr(rowptr), i32ptr(colidx), dptr(vals)))
+        self.rows = rows
+
+    def set_dense(self, A):
+        A = f64(A)
+        if A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise ValueError("dense H must be square")
+        self.check(self.lib.lz_set_dense(self._h, A.shape[0], dptr(A)))
+        self.rows = A.shape[0]
+
+    def set_halo(self, peers, send_counts, send_idx, recv_counts):
+        peers = np.ascontiguousarray(peers, dtype=np.int32)
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        si = np.ascontiguousarray(send_idx, dtype=np.int32)
+        self.check(self.lib.lz_set_halo(self._h, len(peers), i32ptr(peers), i64ptr(sc), i32ptr(si), i64ptr(rc)))
+
+    def set_allgather(self, chunk):
+        self.check(self.lib.lz_set_allgather(self._h, int(chunk)))
+
+    # -- run
+    def run(self, n, v0_local):
+        v0 = f64(v0_local)
+        if v0.shape != (self.rows,):
+            raise ValueError("v0 has the wrong length")
+        alpha = np.zeros(n)
+        beta = np.zeros(max(n - 1, 1))
+        self.check(self.lib.lz_run(self._h, int(n), dptr(v0), dptr(alpha), dptr(beta)))
+        self.n = n
+        return alpha, beta[: n - 1]
+
+    def get_basis(self):
+        V = np.empty((self.n, self.rows))
+        self.check(self.lib.lz_get_basis(self._h, dptr(V), self.rows))
+        return V
+
+    def ritz_vectors(self, S, fetch=True):
+        S = f64(S)
+        Y = np.empty((self.rows, self.n)) if fetch else None
+        self.check(self.lib.lz_ritz_vectors(self._h, dptr(S), dptr(Y) if fetch else None))
+        return Y
+
+    def ritz_gram(self):
+        G = np.empty((self.n, self.n))
+        self.check(self.lib.lz_ritz_gram(self._h, dptr(G)))
+        return G
+
+    def ritz_quality(self):
+        q = np.empty(self.n)
+        self.check(self.lib.lz_ritz_quality(self._h, dptr(q)))
+        return q
+
+    def timings(self):
+        t = LzTimings()
+        self.check(self.lib.lz_get_timings(self._h, C.byref(t)))
+        out = {"total_ms": t.total_ms}
+        for i, k in enumerate(KERNEL_CLASSES):
+            out[k] = {"ms": t.ms[i], "bytes": t.bytes[i], "flops": t.flops[i], "launches": int(t.launches[i])}
+        return out
+
+    # -- single steps
+    def basis_alloc(self, n):
+        self.check(self.lib.lz_basis_alloc(self._h, int(n)))
+        self.n = n
+
+    def basis_set_row(self, j, row):
+        row = f64(row)
+        assert row.shape == (self.rows,)
+        self.check(self.lib.lz_basis_set_row(self._h, int(j), dptr(row)))
+
+    def basis_get_row(self, j):
+        out = np.empty(self.rows)
+        self.check(self.lib.lz_basis_get_row(self._h, int(j), dptr(out)))
+        return out
+
+    def r_set(self, r):
+        r = f64(r)
+        assert r.shape == (self.rows,)
+        self.check(self.lib.lz_r_set(self._h, dptr(r)))
+
+    def r_get(self):
+        out = np.empty(self.rows)
+        self.check(self.lib.lz_r_get(self._h, dptr(out)))
+        return out
+
+    def step_spmv(self, j):
+        d = C.c_double()
+        self.check(self.lib.lz_step_spmv(self._h, int(j), C.byref(d)))
+        return d.value
+
+    def step_reorth(self, j, nrows, scale=False):
+        beta = C.c_double()
+        c = np.empty(nrows)
+        self.check(self.lib.lz_step_reorth(self._h, int(j), int(nrows), int(bool(scale)), C.byref(beta), dptr(c)))
+        return (beta.value if scale else None), c
+
+    def step_three_term(self, j, jm1, alpha, beta):
+        d = C.c_double()
+        self.check(self.lib.lz_step_three_term(self._h, int(j), int(jm1), float(alpha), float(beta), C.byref(d)))
+        return d.value
+
+    def spmv_host(self, x, ncols=None):
+        x = f64(x)
+        y = np.empty(self.rows)
+        self.check(self.lib.lz_spmv_host(self._h, dptr(x), dptr(y)))
+        return y

@@ -1,0 +1,304 @@
+"""Host-side mirror of the reference's Lanczos class surface over the HIP library.
+
+Mirrors Python/Regular/Lanczos.py:11-337 and the symmetric ("Old") half of
+Python/Irregular/IrrLanczos.py:12-554 (paths relative to /root/reference):
+same constructor, method names, keyword arguments, attributes, error types and
+messages.  Everything numerical inside ``execute_Lanczos`` / ``get_H_eigs`` runs
+in liblanczos_hip.so; this file only prepares inputs (start vector with NumPy's
+legacy RNG exactly like the reference's CPU branch, CSR packing), assembles the
+small tridiagonal ``H_eff``, calls ``numpy.linalg.eigh`` on it (as the reference
+does, also in its GPU mode, Lanczos.py:151) and formats the diagnostics.
+
+There is deliberately NO CPU implementation of the recurrence here:
+``use_cuda=False`` raises ``NotImplementedError`` (that path is the reference's
+own NumPy code), and a missing HIP extension or GPU raises ``LanczosHipError``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse
+import scipy.sparse.linalg
+
+from . import _capi
+
+_NOT_EXECUTED = "Lanczos Algorithm has not been called."
+_CPU_MSG = (
+    "lanczos_amd implements the device path only (use_cuda=True runs on the MI355X through liblanczos_hip.so); "
+    "use_cuda=False is the reference's own NumPy path and is not re-implemented here"
+)
+
+
+def _pack_matrix(H):
+    """-> ("csr", rowptr, colidx, vals) or ("dense", A).  Keeps the stored entry
+    order of a CSR input (the per-row summation order then equals SciPy's)."""
+    if scipy.sparse.issparse(H):
+        A = H if H.format == "csr" else H.tocsr()
+        if A.dtype != np.float64:
+            A = A.astype(np.float64)
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("H must be square")
+        if A.nnz >= 2**31 or A.shape[0] >= 2**31:
+            raise ValueError("matrix too large for int32 CSR indices")
+        return ("csr", A.indptr.astype(np.int32, copy=False), A.indices.astype(np.int32, copy=False), A.data)
+    if hasattr(H, "rowptr") and hasattr(H, "colidx"):  # lanczos_amd.synthetic.CSR
+        return ("csr", H.rowptr, H.colidx, H.vals)
+    A = np.asarray(H, dtype=np.float64)
+    if A.ndim != 2 or A.shape[0] != A.shape[1]:
+        raise ValueError("H must be a square matrix")
+    return ("dense", np.ascontiguousarray(A))
+
+
+class LanczosBase:
+    """State, lazy properties and diagnostics shared by ``Lanczos`` and ``IrrLanczos``."""
+
+    verbose = True  # the reference prints "+++ ..." progress lines; set False to silence
+    device_id = 0
+    options = 0     # lz_flags forwarded to lz_set_options (see include/lanczos_hip.h)
+    _check_eigs = ("normalized", "orthogonal")  # which asserts get_H_eigs runs (Lanczos.py:157-158)
+
+    def __init__(self, H):
+        self.H = H
+        self.M = np.shape(H)[0]
+        self.Lanczos_has_been_executed = False
+        self.H_eigs_have_been_found = False
+        self.H_exact_eigs_have_been_found = False
+        self._handle = None
+        self._V = None
+        self._timings = None
+
+    def _say(self, msg):
+        if self.verbose:
+            print(msg)
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def H_eff(self):
+        if not self.Lanczos_has_been_executed:
+            raise ValueError(_NOT_EXECUTED)
+        return self._H_eff
+
+    @property
+    def V(self):
+        """(M, n) Krylov basis, columns = Lanczos vectors; like the reference this is
+        the transposed view of an (n, M) array.  Copied off the device on first use."""
+        if not self.Lanczos_has_been_executed:
+            raise ValueError(_NOT_EXECUTED)
+        if self._V is None:
+            self._V = self._handle.get_basis().T
+        return self._V
+
+    @property
+    def H_eigvecs(self):
+        if not self.H_eigs_have_been_found:
+            self.get_H_eigs()
+        return self._H_eigvecs
+
+    @property
+    def H_eigvals(self):
+        if not self.H_eigs_have_been_found:
+            self.get_H_eigs()
+        return self._H_eigvals
+
+    @property
+    def H_eigvals_actual(self):
+        if not self.H_exact_eigs_have_been_found:
+            self.find_exact_eigs()
+            self.H_exact_eigs_have_been_found = True
+        return self._H_eigvals_actual
+
+    @property
+    def H_eigvecs_actual(self):
+        if not self.H_exact_eigs_have_been_found:
+            self.find_exact_eigs()
+            self.H_exact_eigs_have_been_found = True
+        return self._H_eigvecs_actual
+
+    @property
+    def timings(self):
+        """Per-kernel-class device timings of the last run (only with ``options |= FLAG_PROFILE``)."""
+        return self._timings
+
+    def find_exact_eigs(self, nr_vecs=20):
+        self._say("+++ Calculating exact eigs using scipy.sparse.linalg.eigsh.")
+        self._H_eigvals_actual, self._H_eigvecs_actual = scipy.sparse.linalg.eigsh(self.H, k=nr_vecs, which="SM")
+        self._say("+++ Finished calculating exact eigs.")
+
+    # ------------------------------------------------------------------ the hot path
+    def _execute(self, n, seed, use_cuda, v0):
+        if n > self.M:
+            raise ValueError("n cannot be larger than M!")
+        self._say("+++ Executing Lanczos algorithm")
+        self.n = n
+        if not use_cuda:
+            raise NotImplementedError(_CPU_MSG)
+        M = self.M
+
+        # start vector: the reference's CPU-branch stream (global legacy RNG), Lanczos.py:93-100
+        np.random.seed(seed)
+        if v0 is None:
+            v0 = np.random.uniform(-1, 1, size=(M))
+        else:
+            v0 = np.array(v0)
+        v0 = v0 / np.linalg.norm(v0)
+        if n < 2:
+            # the reference allocates beta = zeros(n-1) and writes beta[-1] at j = 0 (Lanczos.py:107,112)
+            raise IndexError("index -1 is out of bounds for axis 0 with size 0")
+
+        packed = _pack_matrix(self.H)
+        if self._handle is None:
+            self._handle = _capi.Handle(self.device_id)
+        h = self._handle
+        h.set_options(self.options)
+        if packed[0] == "csr":
+            h.set_csr(M, 0, packed[1], packed[2], packed[3])
+        else:
+            h.set_dense(packed[1])
+        alpha, beta = h.run(n, v0)
+        self._timings = h.timings()
+
+        # H_eff (Lanczos.py:121-130): symmetric tridiagonal, assembled on the host from 2n-1 doubles
+        H_eff = np.zeros((n, n))
+        idx = np.arange(n)
+        H_eff[idx, idx] = alpha
+        H_eff[idx[:-1], idx[1:]] = beta
+        H_eff[idx[1:], idx[:-1]] = beta
+        self._alpha, self._beta = alpha, beta
+        self._H_eff = H_eff
+        self._V = None
+        # the reference's GPU branch leaves a SciPy CSR in self.H (Lanczos.py:137)
+        self.H = scipy.sparse.csr_matrix(self.H, dtype=np.float64)
+        self.H_eigs_have_been_found = False
+        self._say("+++ Lanczos executed successfully.")
+        self.Lanczos_has_been_executed = True
+
+    def _ritz(self, checks):
+        if not self.Lanczos_has_been_executed:
+            raise ValueError(_NOT_EXECUTED)
+        self._say("+++ Converting eigenvectors from H_eff to H basis.")
+        H_eff_eigvals, H_eff_eigvecs = np.linalg.eigh(self.H_eff)
+        # Y = V S on the device (FP64 MFMA GEMM), Lanczos.py:153-156
+        H_eigvecs_lanczos = self._handle.ritz_vectors(H_eff_eigvecs)
+        if "normalized" in checks:
+            self.test_is_normalized(H_eigvecs_lanczos, tol=0.001)
+        if "orthogonal" in checks:
+            self.test_is_orthogonal(H_eigvecs_lanczos, tol=0.01)
+        self._H_eigvals = H_eff_eigvals
+        self._H_eigvecs = H_eigvecs_lanczos
+        self._say("+++ Finished Converting.")
+        self.H_eigs_have_been_found = True
+
+    def get_H_eigs(self):
+        self._ritz(self._check_eigs)
+
+    # ------------------------------------------------------------------ diagnostics (host, NumPy)
+    def _eigvec_quality(self):
+        """cos^2 between H x / |H x| and x for every Ritz vector (Lanczos.py:169-175)."""
+        H, X = self.H, self.H_eigvecs
+        HX = H @ X if scipy.sparse.issparse(H) else np.asarray(H) @ X
+        HX = HX / np.linalg.norm(HX, axis=0)
+        return np.einsum("ij,ij->j", HX, X) ** 2
+
+    def print_good_eigs(self, tol=0.01, print_nr=20, print_bad=True):
+        """Print the first ``print_nr`` Ritz values with the eigenvector quality
+        ``((Hx/|Hx|) . x)^2``; lines failing ``|1 - q| < tol`` are tagged BAD."""
+        eigvals, q = self.H_eigvals, self._eigvec_quality()
+        print("__________EIGENVALUE AND EIGVENVECTOR COMPARISON__________")
+        print("%12s %12s" % ("Eigval", "Eigvec InnerProd"))
+        for i in range(print_nr):
+            tag = "" if abs(1 - q[i]) < tol else " --- BAD"
+            print("%12.4f %20.14f%s" % (eigvals[i], q[i], tag))
+
+    def _match_to_exact(self):
+        va, la = self.H_eigvecs_actual, self.H_eigvals_actual
+        ve, le = self.H_eigvecs, self.H_eigvals
+        nr = len(la)
+        overlap = (ve.T @ va) ** 2  # (n, nr)
+        est = np.full(nr, np.nan)
+        best = np.full(nr, np.nan)
+        who = np.full(nr, np.nan)
+        for i in range(self.n):
+            k = int(overlap[i].argmax())
+            if np.isnan(best[k]) or overlap[i, k] > best[k]:
+                est[k], best[k], who[k] = le[i], overlap[i, k], i
+        return la, est, best, who
+
+    def compare_eigs(self):
+        """Table of exact (``eigsh``) vs Lanczos eigenpairs matched by largest eigenvector overlap."""
+        if not self.Lanczos_has_been_executed:
+            raise ValueError(_NOT_EXECUTED)
+        print("+++ Comparing to exact eigs.")
+        la, est, best, who = self._match_to_exact()
+        pct = np.abs((la - est) / est) * 100
+        print("__________EIGENVALUE AND EIGVENVECTOR COMPARISON__________")
+        print("%6s %6s %20s %20s %14s %14s" % ("Idx1", "Idx2", "Actual", "Lanczos", "% Diff", "Eigvec Prod"))
+        for i in range(len(la)):
+            print("%6.0d %6.0f %20.10f %20.10f %14.4f %14.4f" % (i, who[i], la[i], est[i], pct[i], best[i]))
+
+    @staticmethod
+    def reorthogonalize(V, j, use_cuda=True):
+        """In-place single-pass Gram-Schmidt of row ``j`` of the (n, M) array ``V`` against
+        all rows, with the reference's arithmetic ``V[j] = 2 V[j] - (V V[j])^T V``
+        (Lanczos.py:247-249), executed by the HIP kernels."""
+        if not use_cuda:
+            raise NotImplementedError(_CPU_MSG)
+        V = np.asarray(V)
+        n, M = V.shape
+        h = _capi.Handle(LanczosBase.device_id)
+        try:
+            eye_ptr = np.arange(M + 1, dtype=np.int32)
+            h.set_csr(M, 0, eye_ptr, eye_ptr[:-1], np.ones(M))  # length carrier only; no matvec is run
+            h.basis_alloc(n)
+            for i in range(n):
+                h.basis_set_row(i, V[i])
+            h.step_reorth(j, n, scale=False)
+            V[j] = h.basis_get_row(j)
+        finally:
+            h.close()
+
+    @staticmethod
+    def get_matched_eigs(v, vL, l, lL):
+        """Order estimated eigenpairs (vL, lL) by their best overlap with exact ones (v, l);
+        returns ``(v_sorted, vL_sorted, l_sorted, lL_sorted)``, best match first."""
+        overlap = (vL.T @ v) ** 2
+        partner = overlap.argmax(axis=1)
+        quality = overlap[np.arange(len(lL)), partner]
+        order = quality.argsort()[::-1]
+        return v[:, partner[order]], vL[:, order], l[partner[order]], lL[order]
+
+    @staticmethod
+    def test_is_Hermitian(A):
+        """Assert A equals its transpose."""
+        At = A.T
+        same = (A != At).nnz == 0 if scipy.sparse.issparse(A) else bool((np.asarray(A) == np.asarray(At)).all())
+        assert same, "A IS NOT HERMITIAN!"
+
+    @staticmethod
+    def test_is_normalized(V, tol=0.001, no_assert=False):
+        """Column norms of the (M, m) matrix V; like the reference (Lanczos.py:288-305) only the
+        column whose norm is CLOSEST to 1 is reported/asserted."""
+        norms = np.linalg.norm(V, axis=0)
+        pick = norms[np.argmin(np.abs(norms - 1))]
+        if no_assert:
+            return pick
+        assert np.abs(pick - 1) < tol, "VECTOR HAS NORM %.4f. IS NOT NORMALIZED." % pick
+
+    @staticmethod
+    def test_is_orthogonal(V, tol=0.01, no_assert=False):
+        """sqrt of the largest off-diagonal |V^T V| entry (Lanczos.py:307-323)."""
+        G = V.T @ V
+        G[np.diag_indices_from(G)] -= np.linalg.norm(V, axis=0) ** 2
+        G = np.abs(G)
+        a, b = np.unravel_index(np.argmax(G), G.shape)
+        worst = np.sqrt(G[a, b])
+        if no_assert:
+            return worst
+        assert worst < tol, "VECTORS %d AND %d NOT ORTHOGONAL! INNER PRODUCT %.4f" % (a, b, worst)
+
+    @staticmethod
+    def test_is_eigvecs(A, V, tol=0.01, no_assert=False):
+        """Spread of (A v)/v per column; the reference asserts ``max > tol`` (sic, Lanczos.py:326-337)."""
+        R = (np.asarray(A @ V)) / V
+        worst = np.max(R.max(axis=0) - R.min(axis=0))
+        if no_assert:
+            return worst
+        assert worst > tol, "VECTOR NOT EIGENVECTOR."

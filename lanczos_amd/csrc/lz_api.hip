@@ -1,0 +1,913 @@
+// C ABI of liblanczos_hip.so: context, device memory, the Lanczos run loop and
+// the (optional) multi-rank collectives.  See include/lanczos_hip.h for the
+// contract and the reference call sites each entry point replaces.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "lz_internal.h"
+
+using namespace lz;
+
+namespace {
+
+std::string g_create_error;
+
+struct EventRec {
+  int cls;
+  hipEvent_t a, b;
+};
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+const char* load_rccl() {
+  if (g_rccl.lib) return nullptr;
+  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return "cannot dlopen librccl.so.1";
+#define LZ_SYM(field, name)                                          \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name)); \
+  if (!g_rccl.field) return "missing RCCL symbol " name;
+  LZ_SYM(GetUniqueId, "ncclGetUniqueId")
+  LZ_SYM(CommInitRank, "ncclCommInitRank")
+  LZ_SYM(CommDestroy, "ncclCommDestroy")
+  LZ_SYM(AllReduce, "ncclAllReduce")
+  LZ_SYM(AllGather, "ncclAllGather")
+  LZ_SYM(Send, "ncclSend")
+  LZ_SYM(Recv, "ncclRecv")
+  LZ_SYM(GroupStart, "ncclGroupStart")
+  LZ_SYM(GroupEnd, "ncclGroupEnd")
+  LZ_SYM(GetErrorString, "ncclGetErrorString")
+#undef LZ_SYM
+  g_rccl.lib = lib;
+  return nullptr;
+}
+
+}  // namespace
+
+struct lz_context {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::string name;
+  int flags = 0;
+
+  // partition
+  int64_t Mg = 0, row0 = 0, rows = 0, ncols_ext = 0;
+  int64_t rows_pad = 0;  // owned rows padded to 32 doubles
+  int64_t ldv = 0;       // stride between basis rows (>= rows_pad, + ghost tail in halo mode)
+
+  // matrix
+  int kind = 0;  // 0 none, 1 csr, 2 dense
+  CsrDev csr;
+  double* d_dense = nullptr;
+
+  // basis and work vectors
+  int n = 0;
+  double* d_V = nullptr;
+  double* d_r = nullptr;
+  double* d_alpha = nullptr;  // n
+  double* d_beta = nullptr;   // n
+  double* d_c = nullptr;      // n + 1
+  double* d_nrm2 = nullptr;   // 2 : [0] = ||r||^2
+  double* d_part = nullptr;   // partials
+  size_t part_cap = 0;
+  double* d_xtmp = nullptr;   // lz_spmv_host scratch
+  QtwPlan qplan;
+
+  // Ritz vectors
+  double* d_Y = nullptr;
+  int64_t y_rows = 0;
+  int y_n = 0;
+
+  // communication
+  int world = 1, rank = 0;
+  int comm_kind = 0;  // 0 none, 1 rccl, 2 host callbacks
+  ncclComm_t comm = nullptr;
+  lz_host_allreduce_fn h_ar = nullptr;
+  lz_host_exchange_fn h_ex = nullptr;
+  lz_host_allgather_fn h_ag = nullptr;
+  void* h_user = nullptr;
+  std::vector<double> hbuf_a, hbuf_b;
+  int xmode = 0;  // 0 none, 1 halo, 2 allgather
+  std::vector<int32_t> peers;
+  std::vector<int64_t> scount, rcount, soff, roff;
+  int64_t total_send = 0, total_recv = 0;
+  int32_t* d_send_idx = nullptr;
+  double* d_sendbuf = nullptr;
+  int64_t ag_chunk = 0;
+  double* d_xfull = nullptr;
+
+  // timing
+  std::vector<EventRec> events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+  hipEvent_t run_a = nullptr, run_b = nullptr;
+  bool run_timed = false;
+  lz_timings acc;
+};
+
+namespace {
+
+int fail(lz_handle h, int code, const std::string& msg) {
+  if (h)
+    h->err = msg;
+  else
+    g_create_error = msg;
+  return code;
+}
+
+#define LZ_HIP(h, call)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (call);                                                                               \
+    if (e_ != hipSuccess)                                                                                 \
+      return fail(h, e_ == hipErrorOutOfMemory ? LZ_ERR_NOMEM : LZ_ERR_HIP,                               \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                                     \
+  } while (0)
+
+#define LZ_NCCL(h, call)                                                                                  \
+  do {                                                                                                    \
+    ncclResult_t r_ = (call);                                                                             \
+    if (r_ != ncclSuccess) return fail(h, LZ_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+#define LZ_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != LZ_OK) return rc_; \
+  } while (0)
+
+int check_launch(lz_handle h, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  return LZ_OK;
+}
+
+template <class T>
+int dev_free(lz_handle h, T*& p) {
+  if (p) {
+    LZ_HIP(h, hipFree(p));
+    p = nullptr;
+  }
+  return LZ_OK;
+}
+
+template <class T>
+int dev_alloc(lz_handle h, T*& p, size_t count) {
+  LZ_TRY(dev_free(h, p));
+  void* q = nullptr;
+  LZ_HIP(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  p = static_cast<T*>(q);
+  return LZ_OK;
+}
+
+// ---- profiling events ---------------------------------------------------
+struct Scope {
+  lz_handle h;
+  int cls;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  Scope(lz_handle h_, int cls_, double bytes, double flops) : h(h_), cls(cls_) {
+    h->acc.bytes[cls] += bytes;
+    h->acc.flops[cls] += flops;
+    h->acc.launches[cls] += 1;
+    on = (h->flags & LZ_FLAG_PROFILE) != 0;
+    if (on) {
+      if (!h->free_events.empty()) {
+        a = h->free_events.back().first;
+        b = h->free_events.back().second;
+        h->free_events.pop_back();
+      } else {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+          on = false;
+          return;
+        }
+      }
+      hipEventRecord(a, h->stream);
+    }
+  }
+  ~Scope() {
+    if (on) {
+      hipEventRecord(b, h->stream);
+      h->events.push_back({cls, a, b});
+    }
+  }
+};
+
+int drain_events(lz_handle h) {
+  if (h->events.empty() && !h->run_timed) return LZ_OK;
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  for (auto& e : h->events) {
+    float ms = 0.f;
+    LZ_HIP(h, hipEventElapsedTime(&ms, e.a, e.b));
+    h->acc.ms[e.cls] += ms;
+    h->free_events.push_back({e.a, e.b});
+  }
+  h->events.clear();
+  if (h->run_timed) {
+    float ms = 0.f;
+    LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
+    h->acc.total_ms += ms;
+    h->run_timed = false;
+  }
+  return LZ_OK;
+}
+
+// ---- collectives --------------------------------------------------------
+int comm_allreduce(lz_handle h, double* dbuf, int64_t count) {
+  if (h->world <= 1 || count <= 0) return LZ_OK;
+  Scope sc(h, LZ_K_COMM, 8.0 * count, 0);
+  if (h->comm_kind == 1) {
+    LZ_NCCL(h, g_rccl.AllReduce(dbuf, dbuf, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream));
+    return LZ_OK;
+  }
+  if (h->comm_kind == 2) {
+    h->hbuf_a.resize((size_t)count);
+    LZ_HIP(h, hipMemcpyAsync(h->hbuf_a.data(), dbuf, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->h_ar(h->h_user, h->hbuf_a.data(), count) != 0) return fail(h, LZ_ERR_COMM, "host all-reduce callback failed");
+    LZ_HIP(h, hipMemcpyAsync(dbuf, h->hbuf_a.data(), count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    return LZ_OK;
+  }
+  return fail(h, LZ_ERR_STATE, "world > 1 but no communicator initialised");
+}
+
+// make the SpMV input of basis row j complete on this rank; returns the x pointer to use
+int comm_exchange_x(lz_handle h, int j, const double** x_out) {
+  double* vj = h->d_V + (int64_t)j * h->ldv;
+  *x_out = vj;
+  if (h->world <= 1) return LZ_OK;
+  if (h->xmode == 1) {
+    if (h->peers.empty()) return LZ_OK;
+    Scope sc(h, LZ_K_COMM, 8.0 * (h->total_send + h->total_recv), 0);
+    launch_gather(vj, h->d_send_idx, h->total_send, h->d_sendbuf, h->stream);
+    LZ_TRY(check_launch(h, "gather"));
+    double* ghost = vj + h->rows_pad;
+    if (h->comm_kind == 1) {
+      LZ_NCCL(h, g_rccl.GroupStart());
+      for (size_t p = 0; p < h->peers.size(); ++p) {
+        if (h->scount[p] > 0)
+          LZ_NCCL(h, g_rccl.Send(h->d_sendbuf + h->soff[p], (size_t)h->scount[p], ncclDouble, h->peers[p], h->comm, h->stream));
+        if (h->rcount[p] > 0)
+          LZ_NCCL(h, g_rccl.Recv(ghost + h->roff[p], (size_t)h->rcount[p], ncclDouble, h->peers[p], h->comm, h->stream));
+      }
+      LZ_NCCL(h, g_rccl.GroupEnd());
+    } else {
+      h->hbuf_a.resize((size_t)std::max<int64_t>(h->total_send, 1));
+      h->hbuf_b.resize((size_t)std::max<int64_t>(h->total_recv, 1));
+      LZ_HIP(h, hipMemcpyAsync(h->hbuf_a.data(), h->d_sendbuf, h->total_send * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      LZ_HIP(h, hipStreamSynchronize(h->stream));
+      if (h->h_ex(h->h_user, (int)h->peers.size(), h->peers.data(), h->hbuf_a.data(), h->scount.data(), h->hbuf_b.data(),
+                  h->rcount.data()) != 0)
+        return fail(h, LZ_ERR_COMM, "host halo-exchange callback failed");
+      LZ_HIP(h, hipMemcpyAsync(ghost, h->hbuf_b.data(), h->total_recv * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      LZ_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return LZ_OK;
+  }
+  if (h->xmode == 2) {
+    Scope sc(h, LZ_K_COMM, 8.0 * h->ag_chunk * h->world, 0);
+    if (h->comm_kind == 1) {
+      LZ_NCCL(h, g_rccl.AllGather(vj, h->d_xfull, (size_t)h->ag_chunk, ncclDouble, h->comm, h->stream));
+    } else {
+      h->hbuf_a.resize((size_t)h->ag_chunk);
+      h->hbuf_b.resize((size_t)(h->ag_chunk * h->world));
+      LZ_HIP(h, hipMemcpyAsync(h->hbuf_a.data(), vj, h->ag_chunk * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      LZ_HIP(h, hipStreamSynchronize(h->stream));
+      if (h->h_ag(h->h_user, h->hbuf_a.data(), h->hbuf_b.data(), h->ag_chunk) != 0)
+        return fail(h, LZ_ERR_COMM, "host all-gather callback failed");
+      LZ_HIP(h, hipMemcpyAsync(h->d_xfull, h->hbuf_b.data(), h->ag_chunk * h->world * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      LZ_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    *x_out = h->d_xfull;
+    return LZ_OK;
+  }
+  return fail(h, LZ_ERR_STATE, "world > 1 but neither lz_set_halo nor lz_set_allgather was called");
+}
+
+// ---- the individual steps (device-resident scalars, no host sync) --------
+int ensure_part(lz_handle h, size_t need) {
+  if (need <= h->part_cap) return LZ_OK;
+  LZ_TRY(dev_alloc(h, h->d_part, need));
+  h->part_cap = need;
+  return LZ_OK;
+}
+
+double spmv_bytes(lz_handle h) {
+  if (h->kind == 1) return 12.0 * h->csr.nnz + 4.0 * (h->rows + 1) + 16.0 * h->rows;
+  return 8.0 * (double)h->rows * h->rows + 16.0 * h->rows;
+}
+double spmv_flops(lz_handle h) { return h->kind == 1 ? 2.0 * h->csr.nnz : 2.0 * (double)h->rows * h->rows; }
+
+// r = A V[j]; d_alpha[j] = sum over ranks of V[j] . r
+int step_spmv(lz_handle h, int j) {
+  const double* x = nullptr;
+  LZ_TRY(comm_exchange_x(h, j, &x));
+  const double* xown = h->d_V + (int64_t)j * h->ldv;
+  int np = 0;
+  {
+    Scope sc(h, LZ_K_SPMV, spmv_bytes(h), spmv_flops(h));
+    if (h->kind == 1)
+      np = launch_spmv_csr(h->csr, x, h->d_r, xown, h->d_part, h->flags, h->stream);
+    else
+      np = launch_gemv_dense(h->d_dense, h->rows, x, h->d_r, h->d_part, h->stream);
+    LZ_TRY(check_launch(h, "spmv"));
+  }
+  {
+    Scope sc(h, LZ_K_FINAL, 0, 0);
+    launch_final_sum(h->d_part, np, h->d_alpha + j, h->stream);
+    LZ_TRY(check_launch(h, "final_sum(alpha)"));
+  }
+  return comm_allreduce(h, h->d_alpha + j, 1);
+}
+
+// V[j] = r / sqrt(nrm2) (if scale), then c = V[0:nrows] . V[j]; V[j] = 2 V[j] - c^T V[0:nrows]
+int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx) {
+  const double M = (double)h->rows;
+  {
+    Scope sc(h, LZ_K_QTW, 8.0 * (nrows - 1) * M + (scale ? 16.0 : 8.0) * M, 2.0 * nrows * M);
+    launch_qtw(h->d_V, h->ldv, h->rows_pad, nrows, j, scale ? h->d_r : nullptr, h->d_nrm2, h->d_beta + beta_idx, h->qplan,
+               h->d_part, h->flags, h->stream);
+    LZ_TRY(check_launch(h, "qtw"));
+  }
+  {
+    Scope sc(h, LZ_K_FINAL, 0, 0);
+    launch_final_rows(h->d_part, nrows, h->qplan.G, h->d_c, h->stream);
+    LZ_TRY(check_launch(h, "final_rows"));
+  }
+  LZ_TRY(comm_allreduce(h, h->d_c, nrows));
+  {
+    Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + 16.0 * M, 2.0 * nrows * M);
+    launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, h->stream);
+    LZ_TRY(check_launch(h, "update"));
+  }
+  return LZ_OK;
+}
+
+// r = r - alpha V[j] - beta V[jm1]; d_nrm2[0] = sum over ranks of ||r||^2
+int step_three_term(lz_handle h, int j, int jm1, const double* d_alpha, const double* d_beta) {
+  const double M = (double)h->rows;
+  int np = 0;
+  {
+    Scope sc(h, LZ_K_THREE, (jm1 >= 0 ? 32.0 : 24.0) * M, (jm1 >= 0 ? 6.0 : 4.0) * M);
+    np = launch_three_term(h->d_r, h->d_V + (int64_t)j * h->ldv, jm1 >= 0 ? h->d_V + (int64_t)jm1 * h->ldv : nullptr, d_alpha,
+                           d_beta, h->rows_pad, h->d_part, h->stream);
+    LZ_TRY(check_launch(h, "three_term"));
+  }
+  {
+    Scope sc(h, LZ_K_FINAL, 0, 0);
+    launch_final_sum(h->d_part, np, h->d_nrm2, h->stream);
+    LZ_TRY(check_launch(h, "final_sum(nrm2)"));
+  }
+  return comm_allreduce(h, h->d_nrm2, 1);
+}
+
+int require_basis(lz_handle h, int j) {
+  if (!h->d_V) return fail(h, LZ_ERR_STATE, "no basis allocated (call lz_run or lz_basis_alloc first)");
+  if (j < 0 || j >= h->n) return fail(h, LZ_ERR_ARG, "basis row index out of range");
+  return LZ_OK;
+}
+
+void build_rowblocks(const int32_t* rowptr, int64_t rows, std::vector<int32_t>& blk) {
+  blk.clear();
+  blk.push_back(0);
+  int64_t r = 0;
+  while (r < rows) {
+    int64_t e = r;
+    const int64_t k0 = rowptr[r];
+    while (e < rows && e - r < 512 && (int64_t)rowptr[e + 1] - k0 <= 4096) ++e;
+    if (e == r) e = r + 1;  // a single row longer than the LDS tile: block of its own
+    blk.push_back((int32_t)e);
+    r = e;
+  }
+}
+
+}  // namespace
+
+// ======================================================================= C ABI
+extern "C" {
+
+int lz_version(void) { return 100; }
+
+int lz_device_count(int* count) {
+  if (!count) return LZ_ERR_ARG;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *count = 0;
+    g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+    return LZ_ERR_NODEVICE;
+  }
+  *count = c;
+  return LZ_OK;
+}
+
+int lz_create(lz_handle* out, int device_id) {
+  if (!out) return fail(nullptr, LZ_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess || c <= 0)
+    return fail(nullptr, LZ_ERR_NODEVICE,
+                std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+  if (device_id < 0 || device_id >= c) return fail(nullptr, LZ_ERR_ARG, "device_id out of range");
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail(nullptr, LZ_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  lz_context* h = new lz_context();
+  h->dev = device_id;
+  memset(&h->acc, 0, sizeof(h->acc));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+  e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete h;
+    return fail(nullptr, LZ_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  }
+  hipEventCreate(&h->run_a);
+  hipEventCreate(&h->run_b);
+  *out = h;
+  return LZ_OK;
+}
+
+int lz_destroy(lz_handle h) {
+  if (!h) return LZ_OK;
+  hipSetDevice(h->dev);
+  hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  hipFree(h->csr.rowptr);
+  hipFree(h->csr.colidx);
+  hipFree(h->csr.vals);
+  hipFree(h->csr.rowblk);
+  hipFree(h->d_dense);
+  hipFree(h->d_V);
+  hipFree(h->d_r);
+  hipFree(h->d_alpha);
+  hipFree(h->d_beta);
+  hipFree(h->d_c);
+  hipFree(h->d_nrm2);
+  hipFree(h->d_part);
+  hipFree(h->d_xtmp);
+  hipFree(h->d_Y);
+  hipFree(h->d_send_idx);
+  hipFree(h->d_sendbuf);
+  hipFree(h->d_xfull);
+  for (auto& e : h->events) {
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  for (auto& e : h->free_events) {
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  if (h->run_a) hipEventDestroy(h->run_a);
+  if (h->run_b) hipEventDestroy(h->run_b);
+  hipStreamDestroy(h->stream);
+  delete h;
+  return LZ_OK;
+}
+
+const char* lz_last_error(lz_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int lz_set_options(lz_handle h, int flags) {
+  if (!h) return LZ_ERR_ARG;
+  h->flags = flags;
+  return LZ_OK;
+}
+
+int lz_device_synchronize(lz_handle h) {
+  if (!h) return LZ_ERR_ARG;
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipDeviceSynchronize());
+  return LZ_OK;
+}
+
+int lz_device_name(lz_handle h, char* buf, size_t buflen) {
+  if (!h || !buf || buflen == 0) return LZ_ERR_ARG;
+  snprintf(buf, buflen, "%s", h->name.c_str());
+  return LZ_OK;
+}
+
+int64_t lz_padded_rows(int64_t rows) { return round_up(rows, kPadDoubles); }
+
+// ---- communication -------------------------------------------------------
+int lz_comm_unique_id(void* id, size_t id_bytes) {
+  if (!id || id_bytes < sizeof(ncclUniqueId)) return fail(nullptr, LZ_ERR_ARG, "id buffer must hold at least 128 bytes");
+  const char* e = load_rccl();
+  if (e) return fail(nullptr, LZ_ERR_COMM, e);
+  ncclUniqueId uid;
+  ncclResult_t r = g_rccl.GetUniqueId(&uid);
+  if (r != ncclSuccess) return fail(nullptr, LZ_ERR_COMM, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+  memset(id, 0, id_bytes);
+  memcpy(id, &uid, sizeof(uid));
+  return LZ_OK;
+}
+
+int lz_comm_init_rccl(lz_handle h, int world, int rank, const void* id, size_t id_bytes) {
+  if (!h) return LZ_ERR_ARG;
+  if (world < 1 || rank < 0 || rank >= world || !id || id_bytes < sizeof(ncclUniqueId))
+    return fail(h, LZ_ERR_ARG, "bad world/rank/id");
+  const char* e = load_rccl();
+  if (e) return fail(h, LZ_ERR_COMM, e);
+  LZ_HIP(h, hipSetDevice(h->dev));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  LZ_NCCL(h, g_rccl.CommInitRank(&h->comm, world, uid, rank));
+  h->world = world;
+  h->rank = rank;
+  h->comm_kind = 1;
+  return LZ_OK;
+}
+
+int lz_comm_init_host(lz_handle h, int world, int rank, lz_host_allreduce_fn ar, lz_host_exchange_fn ex,
+                      lz_host_allgather_fn ag, void* user) {
+  if (!h) return LZ_ERR_ARG;
+  if (world < 1 || rank < 0 || rank >= world || !ar) return fail(h, LZ_ERR_ARG, "bad world/rank/callbacks");
+  h->world = world;
+  h->rank = rank;
+  h->comm_kind = 2;
+  h->h_ar = ar;
+  h->h_ex = ex;
+  h->h_ag = ag;
+  h->h_user = user;
+  return LZ_OK;
+}
+
+// ---- matrix ----------------------------------------------------------------
+int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext, int64_t nnz,
+               const int32_t* rowptr, const int32_t* colidx, const double* vals) {
+  if (!h) return LZ_ERR_ARG;
+  if (M_global <= 0 || rows_local <= 0 || row0 < 0 || row0 + rows_local > M_global || nnz < 0 || !rowptr ||
+      (nnz > 0 && (!colidx || !vals)))
+    return fail(h, LZ_ERR_ARG, "lz_set_csr: bad sizes or NULL arrays");
+  if (rows_local >= (int64_t)1 << 31 || nnz >= (int64_t)1 << 31 || ncols_ext >= (int64_t)1 << 31)
+    return fail(h, LZ_ERR_ARG, "lz_set_csr: sizes exceed int32 CSR indexing");
+  if (ncols_ext < rows_local) return fail(h, LZ_ERR_ARG, "lz_set_csr: ncols_ext < rows_local");
+  if (rowptr[0] != 0 || rowptr[rows_local] != nnz) return fail(h, LZ_ERR_ARG, "lz_set_csr: rowptr[0] != 0 or rowptr[rows] != nnz");
+  int max_nnz = 0;
+  int fixed_k = (int)(rows_local > 0 ? rowptr[1] - rowptr[0] : 0);
+  for (int64_t i = 0; i < rows_local; ++i) {
+    const int64_t d = (int64_t)rowptr[i + 1] - rowptr[i];
+    if (d < 0) return fail(h, LZ_ERR_ARG, "lz_set_csr: rowptr not monotone");
+    if (d > max_nnz) max_nnz = (int)d;
+    if (d != fixed_k) fixed_k = 0;
+  }
+  for (int64_t k = 0; k < nnz; ++k)
+    if (colidx[k] < 0 || colidx[k] >= ncols_ext) return fail(h, LZ_ERR_ARG, "lz_set_csr: column index out of range");
+  if (fixed_k > 64) fixed_k = 0;
+
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  h->kind = 0;
+  LZ_TRY(dev_free(h, h->d_dense));
+  LZ_TRY(dev_free(h, h->d_V));  // a new matrix invalidates the basis
+  h->n = 0;
+  CsrDev& A = h->csr;
+  LZ_TRY(dev_alloc(h, A.rowptr, (size_t)rows_local + 1));
+  LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
+  LZ_TRY(dev_alloc(h, A.vals, (size_t)nnz + 2));
+  LZ_HIP(h, hipMemset(A.colidx, 0, ((size_t)nnz + 2) * sizeof(int32_t)));
+  LZ_HIP(h, hipMemset(A.vals, 0, ((size_t)nnz + 2) * sizeof(double)));
+  LZ_HIP(h, hipMemcpy(A.rowptr, rowptr, ((size_t)rows_local + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    LZ_HIP(h, hipMemcpy(A.colidx, colidx, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    LZ_HIP(h, hipMemcpy(A.vals, vals, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+  }
+  std::vector<int32_t> blk;
+  build_rowblocks(rowptr, rows_local, blk);
+  LZ_TRY(dev_alloc(h, A.rowblk, blk.size()));
+  LZ_HIP(h, hipMemcpy(A.rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  A.n_rowblk = (int)blk.size() - 1;
+  A.rows = rows_local;
+  A.ncols = ncols_ext;
+  A.nnz = nnz;
+  A.fixed_k = fixed_k;
+  A.max_row_nnz = max_nnz;
+  A.avg_row_nnz = (double)nnz / (double)rows_local;
+  h->Mg = M_global;
+  h->row0 = row0;
+  h->rows = rows_local;
+  h->ncols_ext = ncols_ext;
+  h->rows_pad = round_up(rows_local, kPadDoubles);
+  h->ldv = h->rows_pad;
+  h->xmode = 0;
+  h->kind = 1;
+  return LZ_OK;
+}
+
+int lz_set_dense(lz_handle h, int64_t M, const double* A) {
+  if (!h) return LZ_ERR_ARG;
+  if (M <= 0 || !A) return fail(h, LZ_ERR_ARG, "lz_set_dense: bad size or NULL matrix");
+  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_set_dense: dense matrices are single-rank only");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  h->kind = 0;
+  LZ_TRY(dev_free(h, h->d_V));
+  h->n = 0;
+  LZ_TRY(dev_alloc(h, h->d_dense, (size_t)M * M));
+  LZ_HIP(h, hipMemcpy(h->d_dense, A, (size_t)M * M * sizeof(double), hipMemcpyHostToDevice));
+  h->Mg = M;
+  h->row0 = 0;
+  h->rows = M;
+  h->ncols_ext = M;
+  h->rows_pad = round_up(M, kPadDoubles);
+  h->ldv = h->rows_pad;
+  h->xmode = 0;
+  h->kind = 2;
+  return LZ_OK;
+}
+
+int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* send_counts, const int32_t* send_idx,
+                const int64_t* recv_counts) {
+  if (!h) return LZ_ERR_ARG;
+  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_set_halo: call lz_set_csr first");
+  if (npeers < 0 || (npeers > 0 && (!peers || !send_counts || !recv_counts))) return fail(h, LZ_ERR_ARG, "lz_set_halo: NULL arrays");
+  h->peers.assign(peers, peers + npeers);
+  h->scount.assign(send_counts, send_counts + npeers);
+  h->rcount.assign(recv_counts, recv_counts + npeers);
+  h->soff.assign(npeers, 0);
+  h->roff.assign(npeers, 0);
+  int64_t ts = 0, tr = 0;
+  for (int p = 0; p < npeers; ++p) {
+    if (peers[p] < 0 || peers[p] >= h->world || peers[p] == h->rank || send_counts[p] < 0 || recv_counts[p] < 0)
+      return fail(h, LZ_ERR_ARG, "lz_set_halo: bad peer or count");
+    h->soff[p] = ts;
+    h->roff[p] = tr;
+    ts += send_counts[p];
+    tr += recv_counts[p];
+  }
+  if (h->rows_pad + tr != h->ncols_ext)
+    return fail(h, LZ_ERR_ARG, "lz_set_halo: ncols_ext must equal lz_padded_rows(rows_local) + total receive count");
+  for (int64_t k = 0; k < ts; ++k)
+    if (!send_idx || send_idx[k] < 0 || send_idx[k] >= h->rows) return fail(h, LZ_ERR_ARG, "lz_set_halo: send index out of range");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_TRY(dev_alloc(h, h->d_send_idx, (size_t)ts));
+  LZ_TRY(dev_alloc(h, h->d_sendbuf, (size_t)ts));
+  if (ts > 0) LZ_HIP(h, hipMemcpy(h->d_send_idx, send_idx, (size_t)ts * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->total_send = ts;
+  h->total_recv = tr;
+  h->ldv = h->rows_pad + round_up(tr, kPadDoubles);
+  h->xmode = 1;
+  LZ_TRY(dev_free(h, h->d_V));
+  h->n = 0;
+  return LZ_OK;
+}
+
+int lz_set_allgather(lz_handle h, int64_t chunk) {
+  if (!h) return LZ_ERR_ARG;
+  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_set_allgather: call lz_set_csr first");
+  if (chunk < h->rows_pad || chunk % kPadDoubles != 0 || chunk * h->world != h->ncols_ext)
+    return fail(h, LZ_ERR_ARG, "lz_set_allgather: chunk must be a multiple of 32, >= padded rows, and world*chunk == ncols_ext");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_TRY(dev_alloc(h, h->d_xfull, (size_t)(chunk * h->world)));
+  LZ_HIP(h, hipMemset(h->d_xfull, 0, (size_t)(chunk * h->world) * sizeof(double)));
+  h->ag_chunk = chunk;
+  h->ldv = chunk;
+  h->xmode = 2;
+  LZ_TRY(dev_free(h, h->d_V));
+  h->n = 0;
+  return LZ_OK;
+}
+
+// ---- basis -------------------------------------------------------------------
+int lz_basis_alloc(lz_handle h, int n) {
+  if (!h) return LZ_ERR_ARG;
+  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "no matrix set (lz_set_csr / lz_set_dense)");
+  if (n < 1) return fail(h, LZ_ERR_ARG, "n must be >= 1");
+  if (h->world > 1 && h->xmode == 0) return fail(h, LZ_ERR_STATE, "multi-rank run needs lz_set_halo or lz_set_allgather");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  const size_t vsz = (size_t)n * (size_t)h->ldv;
+  if (!h->d_V || h->n != n) {
+    LZ_TRY(dev_alloc(h, h->d_V, vsz));
+    LZ_TRY(dev_alloc(h, h->d_r, (size_t)h->ldv));
+    LZ_TRY(dev_alloc(h, h->d_alpha, (size_t)n + 1));
+    LZ_TRY(dev_alloc(h, h->d_beta, (size_t)n + 1));
+    LZ_TRY(dev_alloc(h, h->d_c, (size_t)n + 1));
+    LZ_TRY(dev_alloc(h, h->d_nrm2, 2));
+  }
+  h->n = n;
+  h->qplan = plan_qtw(h->rows_pad);
+  size_t need = (size_t)(n + 4) * (size_t)h->qplan.G;
+  need = std::max<size_t>(need, 4096);
+  need = std::max<size_t>(need, (size_t)(h->rows / 4 + 64));                     // dense gemv / scalar spmv partials
+  need = std::max<size_t>(need, (size_t)h->csr.n_rowblk + 64);
+  LZ_TRY(ensure_part(h, need));
+  LZ_HIP(h, hipMemsetAsync(h->d_V, 0, vsz * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_r, 0, (size_t)h->ldv * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_alpha, 0, ((size_t)n + 1) * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_beta, 0, ((size_t)n + 1) * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_c, 0, ((size_t)n + 1) * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_nrm2, 0, 2 * sizeof(double), h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_basis_set_row(lz_handle h, int j, const double* row_local) {
+  if (!h || !row_local) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, j));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpyAsync(h->d_V + (int64_t)j * h->ldv, row_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_basis_get_row(lz_handle h, int j, double* row_local) {
+  if (!h || !row_local) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, j));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpyAsync(row_local, h->d_V + (int64_t)j * h->ldv, (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_r_set(lz_handle h, const double* r_local) {
+  if (!h || !r_local) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, 0));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpyAsync(h->d_r, r_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_r_get(lz_handle h, double* r_local) {
+  if (!h || !r_local) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, 0));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpyAsync(r_local, h->d_r, (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+// ---- single steps ---------------------------------------------------------------
+int lz_step_spmv(lz_handle h, int j, double* dot_out) {
+  if (!h) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, j));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_TRY(step_spmv(h, j));
+  if (dot_out) LZ_HIP(h, hipMemcpyAsync(dot_out, h->d_alpha + j, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_step_reorth(lz_handle h, int j, int nrows, int scale, double* beta_out, double* c_out) {
+  if (!h) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, j));
+  if (nrows < 1 || nrows > h->n || j >= nrows) return fail(h, LZ_ERR_ARG, "lz_step_reorth: need 1 <= nrows <= n and j < nrows");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  if (scale) {
+    // ||r||^2 of the current r: r = r - 0 * V[j] leaves r unchanged bit for bit and refreshes d_nrm2
+    LZ_HIP(h, hipMemsetAsync(h->d_c + h->n, 0, sizeof(double), h->stream));
+    LZ_TRY(step_three_term(h, j, -1, h->d_c + h->n, nullptr));
+  }
+  LZ_TRY(step_reorth(h, j, nrows, scale != 0, h->n));  // beta lands in d_beta[n] (scratch slot)
+  if (beta_out && scale) LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta + h->n, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (c_out) LZ_HIP(h, hipMemcpyAsync(c_out, h->d_c, (size_t)nrows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_step_three_term(lz_handle h, int j, int jm1, double alpha, double beta, double* norm2_out) {
+  if (!h) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, j));
+  if (jm1 >= h->n) return fail(h, LZ_ERR_ARG, "lz_step_three_term: jm1 out of range");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  double ab[2] = {alpha, beta};
+  // scratch scalars: d_c[n] is never used by the recurrence, d_beta[n] likewise
+  LZ_HIP(h, hipMemcpyAsync(h->d_c + h->n, &ab[0], sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(h->d_beta + h->n, &ab[1], sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_TRY(step_three_term(h, j, jm1, h->d_c + h->n, h->d_beta + h->n));
+  if (norm2_out) LZ_HIP(h, hipMemcpyAsync(norm2_out, h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_spmv_host(lz_handle h, const double* x, double* y) {
+  if (!h || !x || !y) return LZ_ERR_ARG;
+  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "no matrix set");
+  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_spmv_host is single-rank only");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  const size_t nx = (size_t)round_up(h->ncols_ext, kPadDoubles) + 2 * (size_t)h->rows_pad;
+  LZ_TRY(dev_alloc(h, h->d_xtmp, nx));
+  double* dx = h->d_xtmp;
+  double* dy = h->d_xtmp + round_up(h->ncols_ext, kPadDoubles);
+  LZ_TRY(ensure_part(h, std::max<size_t>((size_t)h->csr.n_rowblk + 64, (size_t)(h->rows / 4 + 64))));
+  LZ_HIP(h, hipMemcpyAsync(dx, x, (size_t)h->ncols_ext * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->kind == 1)
+    launch_spmv_csr(h->csr, dx, dy, dx, h->d_part, h->flags, h->stream);
+  else
+    launch_gemv_dense(h->d_dense, h->rows, dx, dy, h->d_part, h->stream);
+  LZ_TRY(check_launch(h, "spmv"));
+  LZ_HIP(h, hipMemcpyAsync(y, dy, (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+// ---- the run -----------------------------------------------------------------------
+int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double* beta_out) {
+  if (!h) return LZ_ERR_ARG;
+  if (!v0_local || !alpha_out || !beta_out) return fail(h, LZ_ERR_ARG, "lz_run: NULL buffer");
+  if (n < 2) return fail(h, LZ_ERR_ARG, "lz_run: n must be >= 2 (the reference's beta array has n-1 entries)");
+  if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run: n cannot be larger than M");
+  LZ_TRY(lz_basis_alloc(h, n));
+  LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+  // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
+  LZ_TRY(step_spmv(h, 0));
+  LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr));
+  for (int j = 0; j < n; ++j) {
+    const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
+    LZ_TRY(step_reorth(h, j, j + 1, true, bidx));
+    LZ_TRY(step_spmv(h, j));
+    // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
+    LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx));
+  }
+  LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
+  h->run_timed = true;
+  LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_get_basis(lz_handle h, double* V_out, int64_t ld) {
+  if (!h || !V_out) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, 0));
+  if (ld < h->rows) return fail(h, LZ_ERR_ARG, "lz_get_basis: ld < rows_local");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpy2DAsync(V_out, (size_t)ld * sizeof(double), h->d_V, (size_t)h->ldv * sizeof(double),
+                             (size_t)h->rows * sizeof(double), (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
+  if (!h || !S) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, 0));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  const int n = h->n;
+  const int npad = (int)round_up(n, 16);
+  std::vector<double> Sp((size_t)npad * npad, 0.0);
+  for (int k = 0; k < n; ++k) memcpy(&Sp[(size_t)k * npad], S + (size_t)k * n, (size_t)n * sizeof(double));
+  double* dS = nullptr;
+  LZ_TRY(dev_alloc(h, dS, Sp.size()));
+  hipError_t e = hipMemcpyAsync(dS, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && (!h->d_Y || h->y_rows != h->rows || h->y_n != n)) {
+    int rc = dev_alloc(h, h->d_Y, (size_t)h->rows * n);
+    if (rc != LZ_OK) {
+      hipFree(dS);
+      return rc;
+    }
+    h->y_rows = h->rows;
+    h->y_n = n;
+  }
+  if (e == hipSuccess) {
+    Scope sc(h, LZ_K_RITZ, 16.0 * n * (double)h->rows + 8.0 * n * n, 2.0 * (double)h->rows * n * n);
+    launch_ritz_gemm(h->d_V, h->ldv, h->rows, n, dS, npad, h->d_Y, n, h->stream);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && Y_out)
+    e = hipMemcpyAsync(Y_out, h->d_Y, (size_t)h->rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(dS);
+  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_vectors: ") + hipGetErrorString(e));
+  return LZ_OK;
+}
+
+int lz_ritz_gram(lz_handle h, double* gram_out) {
+  if (!h || !gram_out) return LZ_ERR_ARG;
+  return fail(h, LZ_ERR_STATE, "lz_ritz_gram: not implemented in this round");
+}
+
+int lz_ritz_quality(lz_handle h, double* out) {
+  if (!h || !out) return LZ_ERR_ARG;
+  return fail(h, LZ_ERR_STATE, "lz_ritz_quality: not implemented in this round");
+}
+
+int lz_get_timings(lz_handle h, lz_timings* out) {
+  if (!h || !out) return LZ_ERR_ARG;
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_TRY(drain_events(h));
+  *out = h->acc;
+  memset(&h->acc, 0, sizeof(h->acc));
+  return LZ_OK;
+}
+
+}  // extern "C"

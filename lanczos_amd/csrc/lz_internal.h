@@ -1,0 +1,70 @@
+// Internal declarations shared by the kernel translation units and the C ABI.
+// gfx950 (MI355X / CDNA4) only: wave = 64 lanes, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "lanczos_hip.h"
+
+namespace lz {
+
+constexpr int kWave = 64;
+constexpr int kTPB = 256;          // threads per block for all streaming kernels
+constexpr int kPadDoubles = 32;    // vectors are padded to 256-byte multiples
+constexpr int kNumCU = 256;
+constexpr int kNumXCD = 8;
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---- CSR SpMV ----------------------------------------------------------
+struct CsrDev {
+  int64_t rows = 0, ncols = 0, nnz = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* colidx = nullptr;
+  double* vals = nullptr;
+  int fixed_k = 0;            // > 0: every row has exactly fixed_k entries
+  int32_t* rowblk = nullptr;  // CSR-stream row blocks: rows [rowblk[b], rowblk[b+1])
+  int n_rowblk = 0;
+  int max_row_nnz = 0;
+  double avg_row_nnz = 0;
+};
+
+// launch wrappers (all asynchronous on `s`)
+// y = A x (rows), part[b] = sum_{rows of block b} x_own[i] * y[i]; returns number of partials written
+int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
+                    hipStream_t s);
+int launch_gemv_dense(const double* A, int64_t M, const double* x, double* y, double* part, hipStream_t s);
+
+// out[0] = sum(part[0..n)) (fixed order)
+void launch_final_sum(const double* part, int n, double* out, hipStream_t s);
+// c[i] = sum_b part[i*G + b]
+void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s);
+
+struct QtwPlan {
+  int64_t L = 0;   // elements of w owned by one block (multiple of 512)
+  int G = 0;       // number of blocks
+};
+QtwPlan plan_qtw(int64_t len);
+// pass 1 of the re-orthogonalisation (+ optional v_j = r / sqrt(nrm2)):
+//   part[i*G + b] = sum_{m in block b} V[i][m] * V[j][m],  i in [0, nrows)
+void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
+                double* beta_slot, const QtwPlan& plan, double* part, int flags, hipStream_t s);
+// pass 2: V[j] = 2 V[j] - sum_{i<nrows} c[i] V[i] (sequential, unfused: bitwise NumPy order)
+void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, hipStream_t s);
+// r = (r - alpha v_j) - beta v_jm1 ; part[b] = partial ||r||^2 ; returns number of partials
+int launch_three_term(double* r, const double* vj, const double* vjm1, const double* alpha, const double* beta,
+                      int64_t len, double* part, hipStream_t s);
+// gather x[idx[k]] -> buf[k]
+void launch_gather(const double* x, const int32_t* idx, int64_t n, double* buf, hipStream_t s);
+
+// Y(rows x n, row-major, ldy) = sum_k V[k][m] * S[k][i]   (FP64 MFMA)
+void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
+                      int64_t ldy, hipStream_t s);
+// G(npad x npad) partials of Y^T Y over row chunks
+int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part, hipStream_t s);
+
+}  // namespace lz

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE's CPU path here.
+
+Run only in the build container (needs /root/reference):
+
+    cd /tmp && MPLBACKEND=Agg python /root/repo/oracle/gen_golden.py
+
+The reference imports ``cupy`` at module top level (Python/Regular/Lanczos.py:4-5)
+but never touches it on the ``use_cuda=False`` path, so empty stub modules are
+registered first.  For every case the script
+
+  1. builds the input (own generator, or the reference's Hamiltonian builder),
+  2. runs the reference ``Lanczos`` / ``IrrLanczos.execute_LanczosOld`` on CPU,
+  3. runs oracle/lanczos_ref.py on the same input and records the max abs
+     difference (expected: exactly 0.0),
+  4. stores inputs + reference outputs as a compressed .npz (data only - no
+     reference source travels).
+
+Fixture shapes follow SURVEY.md section 8c (i)-(v).
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/Python"
+OUT = os.path.join(REPO, "tests", "golden")
+
+for _m in ("cupy", "cupyx", "cupyx.scipy", "cupyx.scipy.sparse"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.path.insert(0, os.path.join(REF, "Regular"))
+sys.path.insert(0, os.path.join(REF, "Irregular"))
+sys.path.insert(0, REPO)
+
+import Lanczos as ref_regular  # noqa: E402  (reference, read-only)
+import IrrLanczos as ref_irregular  # noqa: E402
+import Hamiltonian as ref_hamiltonian  # noqa: E402
+
+from oracle import lanczos_ref as oracle  # noqa: E402
+from lanczos_amd import synthetic  # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        return fn(*a, **k)
+
+
+def run_reference(H, n, seed, v0, irregular=False):
+    if irregular:
+        obj = ref_irregular.IrrLanczos(H)
+        quiet(obj.execute_LanczosOld, n, seed=seed, use_cuda=False, v0=v0)
+    else:
+        obj = ref_regular.Lanczos(H)
+        quiet(obj.execute_Lanczos, n, seed=seed, use_cuda=False, v0=v0)
+    quiet(obj.get_H_eigs)
+    return obj
+
+
+def case(name, H, n, seed=99, v0=None, store_matrix=True, gen=None, keep_V=None):
+    H = scipy.sparse.csr_matrix(H)
+    H.sort_indices()
+    M = H.shape[0]
+    reg = run_reference(H, n, seed, v0)
+    irr = run_reference(H, n, seed, v0, irregular=True)
+    assert np.array_equal(reg.H_eff, irr.H_eff) and np.array_equal(reg.V, irr.V), "Regular != Irregular-Old"
+    alpha = np.diag(reg.H_eff).copy()
+    beta = np.diag(reg.H_eff, 1).copy()
+    a, b, V = oracle.execute_lanczos(H, n, seed=seed, v0=v0)
+    a2, b2, V2 = oracle.execute_lanczos(H, n, seed=seed, v0=v0, economy=True)
+    assert np.array_equal(a, a2) and np.array_equal(b, b2) and np.array_equal(V, V2), "economy sweep changed bits"
+    theta, S, Y = oracle.ritz_pairs(oracle.build_h_eff(a, b), V)
+    diff = max(
+        np.abs(a - alpha).max(),
+        np.abs(b - beta).max(),
+        np.abs(V.T - reg.V).max(),
+        np.abs(theta - reg.H_eigvals).max(),
+        np.abs(Y - reg.H_eigvecs).max(),
+        np.abs(oracle.build_h_eff(a, b) - reg.H_eff).max(),
+    )
+    if keep_V is None:
+        keep_V = M * n <= 200_000
+    data = dict(
+        name=name, M=M, n=n, seed=seed,
+        alpha=alpha, beta=beta, H_eigvals=reg.H_eigvals,
+        norm_closest_to_1=oracle.is_normalized(reg.H_eigvecs),
+        max_offdiag_gram=oracle.is_orthogonal(reg.H_eigvecs),
+        ref_vs_oracle_maxabs=diff,
+        numpy_version=np.__version__, scipy_version=scipy.__version__,
+    )
+    if v0 is not None:
+        data["v0"] = np.asarray(v0)
+    if store_matrix:
+        data.update(rowptr=H.indptr.astype(np.int32), colidx=H.indices.astype(np.int32), vals=H.data)
+    if gen is not None:
+        data["generator"] = gen
+    if keep_V:
+        data["V"] = np.ascontiguousarray(reg.V.T)  # (n, M): basis vector j is row j
+        data["H_eigvecs_first3"] = reg.H_eigvecs[:, :3].copy()
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
+    print(f"{name:28s} M={M:6d} n={n:5d} ref-vs-oracle max|diff|={diff:.3e} eig[:3]={reg.H_eigvals[:3]}")
+
+
+def deuteron_potential(x, y, z):
+    # same functional form/constants the reference's driver uses (3Ddeuteron.py:51-61); data, not code of the path
+    r = np.sqrt(x**2 + y**2 + z**2)
+    eWell = 54.531
+    return 40.0 * eWell * np.exp(-((r / 0.25) ** 4.0)) - 65.4823128982115 * np.exp(-((r / 1.7) ** 4.0))
+
+
+def main():
+    os.chdir(os.environ.get("TMPDIR", "/tmp"))  # the reference's Hamiltonian creates ./T_matrices
+
+    # (i) C1: dense 512 x 512 random symmetric, n = 20, explicit v0
+    A = synthetic.dense_symmetric(512, seed=0)
+    v0 = np.random.default_rng(0).uniform(-1, 1, 512)
+    case("c1_dense512_n20", A, 20, v0=v0, store_matrix=False, gen="dense_symmetric(512, seed=0); v0=default_rng(0).uniform(-1,1,512)")
+
+    # (ii) 2-D periodic 5-point 32 x 32, n = 30, default start vector (legacy RNG, seed 99)
+    case("lap2d_32x32_n30", synthetic.laplacian_2d_5pt(32, 32).to_scipy(), 30, store_matrix=False, gen="laplacian_2d_5pt(32, 32)")
+
+    # (iii) mini 3Ddeuteron: the reference's own builder, N = 12, 27-point, seed 78 (3Ddeuteron.py:63-95 scaled down)
+    N, L = 12, 25
+    dx = float(L) / N
+    T_factor = 197.327**2 / (2 * 469.4592) / dx**2
+    ham = ref_hamiltonian.Hamiltonian(N, L, deuteron_potential, T_factor)
+    quiet(ham.create_sparse_T)
+    quiet(ham.create_sparse_V)
+    H = -ham.T_sparse + ham.V_sparse
+    H.sort_indices()
+    case("deuteron3d_N12_27pt_n100", H, 100, seed=78, keep_V=True)
+
+    # (iv) 1Dbox.py:5-22 matrix, N = 500, n = 50 (dense there; wrapped as CSR for the CPU path)
+    Nb = 500
+    pot = np.zeros(Nb)
+    pot[Nb // 4 : (3 * Nb) // 4] = -10
+    Hb = np.diag(2 + pot) - np.diag(np.ones(Nb - 1), 1) - np.diag(np.ones(Nb - 1), -1)
+    case("box1d_N500_n50", Hb, 50)
+
+    # (v) 1Ddeuteron.py:6-54, N = n = 1001: the n == M edge
+    Nd = 1001
+    dxd = 25.0 / Nd
+    rr = np.linspace(0, 25, Nd)
+    Vd = 40.0 * 54.531 * np.exp(-((rr / 0.25) ** 4.0)) - 65.4823128982115 * np.exp(-((rr / 1.7) ** 4.0))
+    Vd[Nd - 1] = 0.0  # the script's loop stops at N-2
+    Tf = 197.327**2 / (2 * 469.4592) / dxd**2
+    T = scipy.sparse.diags([np.full(Nd - 1, Tf), np.r_[-Tf, np.full(Nd - 2, -2 * Tf), -Tf], np.full(Nd - 1, Tf)], [-1, 0, 1], format="csr")
+    case("deuteron1d_N1001_n1001", -T + scipy.sparse.diags(Vd, format="csr"), 1001, keep_V=False)
+
+    # extra structure coverage for the hot path: 3-D 7-point, random irregular graph, ragged rows
+    case("lap3d_8x8x8_n40", synthetic.laplacian_3d_7pt(8, 8, 8).to_scipy(), 40, store_matrix=False, gen="laplacian_3d_7pt(8, 8, 8)")
+    case("graph_M2000_E7000_n40", synthetic.random_graph_laplacian(2000, 7000, seed=1234).to_scipy(), 40, store_matrix=False, gen="random_graph_laplacian(2000, 7000, seed=1234)")
+    rng = np.random.default_rng(7)
+    R = scipy.sparse.random(700, 700, density=0.02, random_state=rng, format="csr")
+    R = R + R.T + scipy.sparse.diags(np.linspace(-3, 3, 700))
+    R = R.tolil()
+    R[5, :] = 0.01  # one dense row/column and a few empty-off-diagonal rows: ragged CSR
+    R[:, 5] = 0.01
+    case("ragged_M700_n25", R.tocsr(), 25, seed=3)
+    # n = 2: smallest n the reference survives (beta has one entry)
+    case("lap2d_8x8_n2", synthetic.laplacian_2d_5pt(8, 8).to_scipy(), 2, store_matrix=False, gen="laplacian_2d_5pt(8, 8)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    """Returns (fixture dict, scipy CSR matrix H)."""
+    import scipy.sparse
+
+    from lanczos_amd import synthetic
+
+    d = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+    M = int(d["M"])
+    if "rowptr" in d:
+        H = scipy.sparse.csr_matrix((d["vals"], d["colidx"], d["rowptr"]), shape=(M, M))
+    else:
+        gen = str(d["generator"]).split(";")[0].strip()
+        obj = eval(gen, {"__builtins__": {}}, {k: getattr(synthetic, k) for k in synthetic.__all__})
+        H = obj.to_scipy() if hasattr(obj, "to_scipy") else scipy.sparse.csr_matrix(obj)
+    return d, H
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The ctypes layer with a live GPU; GPU tests fail (not skip) if the extension is missing."""
+    from lanczos_amd import _capi
+
+    _capi.load_library()
+    return _capi

@@ -1,0 +1,169 @@
+"""Kernel-level parity on the GPU, through the C ABI (lz_step_* entry points).
+
+Element-wise kernels (SpMV row sums, re-orthogonalisation update, three-term
+recurrence, r/beta scaling) are compared BIT-EXACT against NumPy/SciPy - they
+follow the reference's expression order with no FMA.  Reductions (alpha, c,
+||r||^2) are compared to 1e-13 relative to the sum of magnitudes.
+"""
+import numpy as np
+import pytest
+import scipy.sparse
+
+from lanczos_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _matrices():
+    rng = np.random.default_rng(5)
+    R = scipy.sparse.random(3000, 3000, density=0.004, random_state=rng, format="csr")
+    R = (R + R.T + scipy.sparse.diags(rng.standard_normal(3000))).tocsr()
+    R.sort_indices()
+    L = R.tolil()
+    L[17, :] = rng.standard_normal(3000)  # a 3000-entry row: exercises the short-row tile limit
+    L[:, 17] = L[17, :].T
+    wide = scipy.sparse.random(9000, 9000, density=0.0012, random_state=rng, format="csr")
+    wide = (wide + wide.T).tolil()
+    wide[100, :] = 1.0  # > 4096 entries: long-row path
+    wide[:, 100] = 1.0
+    return {
+        "lap2d_37x29": synthetic.laplacian_2d_5pt(37, 29).to_scipy(),
+        "lap3d_9x8x7": synthetic.laplacian_3d_7pt(9, 8, 7).to_scipy(),
+        "graph_5000": synthetic.random_graph_laplacian(5000, 17000, seed=3).to_scipy(),
+        "ragged_3000": L.tocsr(),
+        "longrow_9000": wide.tocsr(),
+        "empty_rows": scipy.sparse.csr_matrix(([1.0, 2.0, 2.0, 5.0], ([0, 1, 3, 3], [0, 3, 1, 3])), shape=(6, 6)),
+        "lap2d_400x300": synthetic.laplacian_2d_5pt(400, 300).to_scipy(),
+    }
+
+
+MATS = _matrices()
+
+
+@pytest.mark.parametrize("name", list(MATS))
+@pytest.mark.parametrize("flags", [0, 8])
+def test_spmv_bit_exact(hip, name, flags):
+    H = MATS[name]
+    M = H.shape[0]
+    h = hip.Handle(0)
+    h.set_options(flags)
+    h.set_csr(M, 0, H.indptr, H.indices, H.data)
+    x = np.random.default_rng(1).uniform(-1, 1, M)
+    y = h.spmv_host(x)
+    ref = H * x
+    if name == "longrow_9000" and flags == 0:
+        long_rows = np.diff(H.indptr) > 4096
+        assert long_rows.sum() == 1
+        assert np.array_equal(y[~long_rows], ref[~long_rows])
+        np.testing.assert_allclose(y[long_rows], ref[long_rows], rtol=0, atol=1e-13 * np.abs(H[100]).dot(np.abs(x)).max())
+    else:
+        assert np.array_equal(y, ref), f"max diff {np.abs(y - ref).max()}"
+    h.close()
+
+
+def test_spmv_step_and_alpha(hip):
+    H = MATS["graph_5000"]
+    M = H.shape[0]
+    h = hip.Handle(0)
+    h.set_csr(M, 0, H.indptr, H.indices, H.data)
+    h.basis_alloc(4)
+    v = np.random.default_rng(2).standard_normal(M)
+    h.basis_set_row(2, v)
+    a = h.step_spmv(2)
+    r = h.r_get()
+    assert np.array_equal(r, H * v)
+    assert abs(a - np.dot(v, r)) <= 1e-13 * np.dot(np.abs(v), np.abs(r))
+    h.close()
+
+
+def test_dense_gemv(hip):
+    A = synthetic.dense_symmetric(517, seed=4)
+    h = hip.Handle(0)
+    h.set_dense(A)
+    x = np.random.default_rng(3).standard_normal(517)
+    y = h.spmv_host(x)
+    np.testing.assert_allclose(y, A @ x, rtol=0, atol=1e-13 * (np.abs(A) @ np.abs(x)).max())
+    h.close()
+
+
+@pytest.mark.parametrize("M,n,j", [(1000, 6, 3), (70000, 9, 8), (5121, 5, 0), (33, 4, 2)])
+def test_three_term_bit_exact(hip, M, n, j):
+    rng = np.random.default_rng(M + j)
+    h = hip.Handle(0)
+    ptr = np.arange(M + 1, dtype=np.int32)
+    h.set_csr(M, 0, ptr, ptr[:-1], np.ones(M))
+    h.basis_alloc(n)
+    r, vj, vm = rng.standard_normal((3, M))
+    alpha, beta = rng.standard_normal(2)
+    h.r_set(r)
+    h.basis_set_row(j, vj)
+    jm1 = j - 1
+    if jm1 >= 0:
+        h.basis_set_row(jm1, vm)
+    nrm2 = h.step_three_term(j, jm1, alpha, beta)
+    out = h.r_get()
+    ref = r - vj * alpha - vm * beta if jm1 >= 0 else r - vj * alpha
+    assert np.array_equal(out, ref)
+    assert abs(nrm2 - ref.dot(ref)) <= 1e-13 * ref.dot(ref)
+    h.close()
+
+
+@pytest.mark.parametrize("M,n,j,nrows", [(1000, 6, 3, 4), (70000, 12, 11, 12), (5121, 7, 2, 7), (33, 4, 0, 1), (20000, 40, 39, 40)])
+def test_reorth_matches_numpy(hip, M, n, j, nrows):
+    """reference reorthogonalize(V, j): c = sum(V[j]*V, axis=1); V[j] = 2 V[j] - sum(c[:,None]*V, axis=0)."""
+    rng = np.random.default_rng(M + 7 * j)
+    V = np.zeros((n, M))
+    V[:nrows] = rng.standard_normal((nrows, M)) / np.sqrt(M)
+    h = hip.Handle(0)
+    ptr = np.arange(M + 1, dtype=np.int32)
+    h.set_csr(M, 0, ptr, ptr[:-1], np.ones(M))
+    h.basis_alloc(n)
+    for i in range(nrows):
+        h.basis_set_row(i, V[i])
+    _, c = h.step_reorth(j, nrows, scale=False)
+    c_ref = np.sum(V[j] * V[:nrows], axis=1)
+    scale = np.sum(np.abs(V[j]) * np.abs(V[:nrows]), axis=1)
+    assert np.all(np.abs(c - c_ref) <= 1e-13 * scale)
+    # the update is bit-exact GIVEN the device's own coefficients
+    expect = 2 * V[j] - np.sum(c[:, None] * V[:nrows], axis=0)
+    got = h.basis_get_row(j)
+    assert np.array_equal(got, expect)
+    for i in range(nrows):
+        if i != j:
+            assert np.array_equal(h.basis_get_row(i), V[i])
+    h.close()
+
+
+def test_scale_then_reorth(hip):
+    M, n, j = 30011, 8, 5
+    rng = np.random.default_rng(11)
+    V = np.zeros((n, M))
+    V[:j] = rng.standard_normal((j, M)) / np.sqrt(M)
+    r = rng.standard_normal(M)
+    h = hip.Handle(0)
+    ptr = np.arange(M + 1, dtype=np.int32)
+    h.set_csr(M, 0, ptr, ptr[:-1], np.ones(M))
+    h.basis_alloc(n)
+    for i in range(j):
+        h.basis_set_row(i, V[i])
+    h.r_set(r)
+    beta, c = h.step_reorth(j, j + 1, scale=True)
+    assert abs(beta - np.linalg.norm(r)) <= 1e-14 * np.linalg.norm(r)
+    w = r / beta  # bit-exact division given the device's beta
+    V[j] = w
+    expect = 2 * w - np.sum(c[:, None] * V[: j + 1], axis=0)
+    assert np.array_equal(h.basis_get_row(j), expect)
+    assert np.array_equal(h.r_get(), r)
+    h.close()
+
+
+def test_reference_static_reorthogonalize(hip):
+    from lanczos_amd import Lanczos
+
+    rng = np.random.default_rng(0)
+    V = rng.standard_normal((6, 999)) / 30
+    W = V.copy()
+    Lanczos.reorthogonalize(W, 3)
+    c = np.sum(V[3] * V, axis=1)
+    np.testing.assert_allclose(W[3], 2 * V[3] - np.sum(c[:, None] * V, axis=0), rtol=0, atol=1e-14)
+    assert np.array_equal(np.delete(W, 3, 0), np.delete(V, 3, 0))
