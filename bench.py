@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Lanczos iterations/s (+ per-kernel HBM roofline) on the
+M = 1e7 2-D periodic 5-point Laplacian, k = 200, full re-orthogonalisation, fp64.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE complete Lanczos solve (k iterations: k SpMVs, k three-term
+updates, k full re-orthogonalisations against the growing basis) on the
+device-resident matrix; value = K * k / time.  N > 1 (launched with
+torch.distributed.run) row-partitions the SAME problem over N GPUs (strong
+scaling) with RCCL all-reduces and neighbour halo exchange issued by
+liblanczos_hip.so; torch.distributed (gloo) is used only for rendezvous,
+barriers and the max-over-ranks of the timing.
+
+Per-kernel numbers come from hipEvents recorded around every launch on the
+library's compute stream inside the timed region (LZ_FLAG_PROFILE);
+`roofline.achieved` = algorithmic bytes / event time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_MFMA_PEAK_TFLOPS = 78.6
+
+WORKLOADS = {
+    # name: (kind, dims, k)
+    "lap2d_5pt_M1e7_k200": ("lap2d", (4000, 2500), 200),   # headline (BASELINE.json metric)
+    "lap2d_5pt_M1e6_k100": ("lap2d", (1000, 1000), 100),   # configs[1]
+    "lap3d_7pt_M1e8_k200": ("lap3d", (500, 500, 400), 200),  # configs[3] (8 GPUs)
+    "lap2d_5pt_M1e7_k500": ("lap2d", (4000, 2500), 500),   # configs[4] (8 GPUs)
+    "graph_M1e7_k200": ("graph", (10_000_000, 35_000_000), 200),  # configs[2]
+    "tiny": ("lap2d", (256, 128), 24),
+}
+
+
+def build_local(kind, dims, lo, hi):
+    from lanczos_amd import synthetic
+
+    if kind == "lap2d":
+        return synthetic.laplacian_2d_5pt(*dims, rows=(lo, hi))
+    if kind == "lap3d":
+        return synthetic.laplacian_3d_7pt(*dims, rows=(lo, hi))
+    if kind == "graph":
+        full = synthetic.random_graph_laplacian(dims[0], dims[1], seed=1234)
+        return full.row_slice(lo, hi)
+    raise ValueError(kind)
+
+
+def cpu_baseline(kind, dims, k, budget_s=40.0):
+    """Time the oracle's FAITHFUL restatement of the reference loop (all n rows swept, two
+    n x M temporaries) on this host for a bounded number of iterations."""
+    import psutil
+    import scipy
+
+    from lanczos_amd import synthetic
+    from oracle import lanczos_ref as oracle
+
+    M = int(np.prod(dims)) if kind != "graph" else dims[0]
+    avail = psutil.virtual_memory().available
+    n_cpu = k
+    while 3.3 * 8 * n_cpu * M > 0.6 * avail and n_cpu > 8:
+        n_cpu //= 2
+    H = build_local(kind, dims, 0, M).to_scipy()
+    v0 = oracle.start_vector(M, 99)
+    V = np.zeros((n_cpu, M))
+    V[0] = v0
+    r = H * V[0]
+    a0 = np.dot(r, V[0])
+    r = r - a0 * V[0]
+    times = []
+    j = 0
+    t_all = time.perf_counter()
+    while j < n_cpu and (j < 1 or time.perf_counter() - t_all < budget_s) and j < 4:
+        t0 = time.perf_counter()
+        b = np.linalg.norm(r)
+        V[j] = r / b
+        oracle.reorthogonalize(V, j)          # faithful: sweeps all n_cpu rows
+        r = H * V[j]
+        a = np.dot(V[j], r)
+        r = r - V[j] * a - V[j - 1] * b
+        times.append(time.perf_counter() - t0)
+        j += 1
+    t_iter = float(np.mean(times))
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = ";".join(f"{i.get('internal_api')}:{i.get('num_threads')}" for i in threadpool_info())
+    except Exception:
+        blas = "unknown"
+    out = {
+        "value": (1.0 / t_iter) * (n_cpu / k),  # reference cost per iteration is proportional to n (independent of j)
+        "unit": "iterations/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"{len(times)} iteration(s) of the faithful NumPy loop at M={M}, n={n_cpu} "
+        f"({'full' if n_cpu == k else 'reduced to fit host RAM; value scaled by n/k'}); {t_iter:.2f} s/iteration; "
+        f"only np.dot/norm are multi-threaded ({blas}); numpy {np.__version__}, scipy {scipy.__version__}",
+        "s_per_iteration": t_iter,
+        "n": n_cpu,
+    }
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="lap2d_5pt_M1e7_k200", choices=sorted(WORKLOADS))
+    ap.add_argument("--k", type=int, default=0, help="override the number of Lanczos iterations")
+    ap.add_argument("--options", type=int, default=0, help="extra lz_flags (A/B arms)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "host"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "halo", "allgather"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    # Load the HIP library BEFORE torch so the system ROCm runtime it was built against is the one in the process.
+    import lanczos_amd
+    from lanczos_amd import _capi, distributed, partition
+
+    lanczos_amd.load_library()
+    if world > 1:
+        boot = distributed.TorchBootstrap()
+    else:
+        boot = distributed.Bootstrap()
+
+    kind, dims, k = WORKLOADS[args.workload]
+    if args.k:
+        k = args.k
+    M = int(np.prod(dims)) if kind != "graph" else dims[0]
+    bounds = partition.row_bounds(M, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+
+    t0 = time.perf_counter()
+    local = build_local(kind, dims, lo, hi)
+    t_build = time.perf_counter() - t0
+
+    comm_used = "none" if world == 1 else args.backend
+    try:
+        solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend=args.backend, mode=args.mode,
+                                                options=args.options | _capi.FLAG_PROFILE)
+        ok = True
+    except _capi.LanczosHipError as e:
+        if world == 1 or args.backend != "rccl":
+            raise
+        print(f"[rank {rank}] RCCL setup failed ({e}); falling back to host-staged collectives", file=sys.stderr)
+        ok = False
+    if world > 1 and not all(boot.allgather_obj(ok)):
+        comm_used = "host-gloo (RCCL init failed)"
+        solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend="host", mode=args.mode,
+                                                options=args.options | _capi.FLAG_PROFILE)
+    v0 = solver.start_vector(99)[lo:hi].copy()
+
+    for _ in range(args.warmup):
+        solver.execute_Lanczos(k, v0_normalized_local=v0)
+    solver.timings()  # reset accumulators
+
+    boot.barrier()
+    solver.h.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        alpha, beta = solver.execute_Lanczos(k, v0_normalized_local=v0)
+    solver.h.synchronize()
+    boot.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = max(boot.allgather_obj(elapsed))
+    tm = solver.timings()
+
+    # sanity of the result (cheap): Ritz values finite, extreme one inside the Gershgorin bound
+    theta = solver.get_H_eigs(fetch=False)
+    assert np.isfinite(theta).all()
+
+    if rank == 0:
+        iters = args.steps * k
+        per_class = {}
+        for name in ("spmv", "qtw", "update", "three_term"):
+            c = tm[name]
+            if c["launches"] == 0 or c["ms"] <= 0:
+                continue
+            gbs = c["bytes"] / (c["ms"] * 1e-3) / 1e9
+            per_class[name] = {
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "avg_us": round(1e3 * c["ms"] / c["launches"], 2), "launches": c["launches"],
+                "bytes_per_launch": c["bytes"] / c["launches"], "share_of_device_time": round(c["ms"] / max(tm["total_ms"], 1e-9), 4),
+            }
+        dominant = max(per_class, key=lambda n: tm[n]["ms"]) if per_class else None
+        whole_bytes = sum(tm[n]["bytes"] for n in ("spmv", "qtw", "update", "three_term"))
+        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.isfile(traffic_file):  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
+            try:
+                tr = json.load(open(traffic_file)).get(args.workload, {})
+                for name, v in tr.items():
+                    if name in per_class:
+                        per_class[name]["traffic"] = v
+            except Exception:
+                pass
+        line = {
+            "metric": "Lanczos iterations/sec (+ SpMV GB/s vs HBM roofline), n=1e7 5-pt Laplacian k=200",
+            "value": round(iters / elapsed, 3),
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "matrix": kind, "dims": list(dims), "M": M, "k": k, "reorth": "full (reference CGS, 2 passes)",
+                       "partition": f"row-block x{world}", "exchange": solver.plan.mode, "comm": comm_used,
+                       "step": "one full k-iteration Lanczos solve"},
+            "roofline": dict(per_class[dominant], kernel=dominant) if dominant else None,
+            "roofline_all": per_class,
+            "spmv_gbps": per_class.get("spmv", {}).get("achieved"),
+            "spmv_frac_hbm_peak": per_class.get("spmv", {}).get("frac"),
+            "whole_iteration_gbps": round(whole_bytes / (tm["total_ms"] * 1e-3) / 1e9, 1) if tm["total_ms"] > 0 else None,
+            "device_ms_per_step": round(tm["total_ms"] / args.steps, 3),
+            "comm_ms_per_step": round(tm["comm"]["ms"] / args.steps, 3),
+            "final_ms_per_step": round(tm["final"]["ms"] / args.steps, 3),
+            "setup_s": {"matrix_build": round(t_build, 2)},
+            "device": solver.h.device_name(),
+            "ritz_min_max": [float(theta.min()), float(theta.max())],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(kind, dims, k)
+            except MemoryError as e:  # pragma: no cover
+                line["cpu_baseline"] = {"value": None, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        boot.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -844,6 +844,12 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
+  {
+    float ms = 0.f;
+    LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
+    h->acc.total_ms += ms;
+    h->run_timed = false;
+  }
   return LZ_OK;
 }
 

@@ -1,0 +1,178 @@
+"""Multi-GPU driver: one process per GPU, rows block-partitioned, RCCL collectives.
+
+Data path: liblanczos_hip.so calls RCCL directly (all-reduce of alpha, ||r||^2
+and the re-orthogonalisation coefficients; neighbour send/recv or all-gather of
+the SpMV input) on the compute stream - nothing passes through Python during
+the run.  Python only bootstraps: it plans the partition (partition.py) and
+hands the 128-byte RCCL unique id from rank 0 to the other ranks through a
+``Bootstrap`` (``TorchBootstrap`` = torch.distributed/gloo, the rendezvous the
+launcher already provides; PyTorch is plumbing here, never on the data path).
+
+``backend="host"`` stages the same collectives through host memory and the
+bootstrap; it exists so the partitioned path can be tested with several ranks
+on a single GPU (RCCL refuses two ranks on one device).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import _capi, partition
+
+
+class Bootstrap:
+    """Minimal control-plane interface (setup only)."""
+
+    rank = 0
+    world = 1
+
+    def allgather_obj(self, obj):
+        return [obj]
+
+    def broadcast_bytes(self, data, root=0):
+        return data
+
+    def barrier(self):
+        pass
+
+    # host-staged data path (backend="host")
+    def allreduce_sum(self, a):
+        return a
+
+    def exchange(self, peers, send_segments, recv_counts):
+        return []
+
+    def allgather_array(self, a):
+        return a
+
+
+class TorchBootstrap(Bootstrap):
+    """torch.distributed (gloo, CPU) rendezvous from the RANK/WORLD_SIZE/MASTER_* environment."""
+
+    def __init__(self, init=True):
+        import torch
+        import torch.distributed as dist
+
+        self._torch, self._dist = torch, dist
+        if init and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather_obj(self, obj):
+        out = [None] * self.world
+        self._dist.all_gather_object(out, obj)
+        return out
+
+    def broadcast_bytes(self, data, root=0):
+        box = [data if self.rank == root else None]
+        self._dist.broadcast_object_list(box, src=root)
+        return box[0]
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def allreduce_sum(self, a):
+        t = self._torch.from_numpy(a)
+        self._dist.all_reduce(t)
+        return a
+
+    def exchange(self, peers, send_segments, recv_counts):
+        torch, dist = self._torch, self._dist
+        recv = [torch.empty(int(c), dtype=torch.float64) for c in recv_counts]
+        reqs = []
+        for p, seg, r in zip(peers, send_segments, recv):
+            if len(seg):
+                reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(seg)), dst=int(p)))
+            if r.numel():
+                reqs.append(dist.irecv(r, src=int(p)))
+        for q in reqs:
+            q.wait()
+        return [r.numpy() for r in recv]
+
+    def allgather_array(self, a):
+        torch, dist = self._torch, self._dist
+        out = [torch.empty(len(a), dtype=torch.float64) for _ in range(self.world)]
+        dist.all_gather(out, torch.from_numpy(np.ascontiguousarray(a)))
+        return np.concatenate([o.numpy() for o in out])
+
+
+class DistributedLanczos:
+    """Row-partitioned Lanczos over ``boot.world`` ranks (this object = one rank).
+
+    ``local`` is this rank's row block as a ``synthetic.CSR``-like object (``rowptr``,
+    ``colidx`` with GLOBAL column ids, ``vals``) for the rows ``partition.row_bounds(M, world)``
+    assigns to ``boot.rank``.  Results: ``alpha``, ``beta``, ``H_eff`` replicated; ``V_local``
+    / ``H_eigvecs_local`` hold this rank's rows.
+    """
+
+    def __init__(self, local, M, boot=None, device_id=0, backend="rccl", mode="auto", options=0):
+        self.boot = boot or Bootstrap()
+        self.M = int(M)
+        self.rank, self.world = self.boot.rank, self.boot.world
+        bounds = partition.row_bounds(self.M, self.world)
+        self.lo, self.hi = bounds[self.rank], bounds[self.rank + 1]
+        rows = self.hi - self.lo
+        if len(local.rowptr) != rows + 1:
+            raise ValueError(f"rank {self.rank} must own rows [{self.lo}, {self.hi})")
+        modes = self.boot.allgather_obj(partition.plan_exchange(local.rowptr, local.colidx, self.M, self.world, self.rank, mode).mode)
+        if "allgather" in modes:
+            mode = "allgather"  # all ranks must agree
+        self.plan = partition.plan_exchange(local.rowptr, local.colidx, self.M, self.world, self.rank, mode)
+        if self.plan.mode == "halo":
+            gathered = self.boot.allgather_obj((self.plan.peers, self.plan.send_counts, self.plan.recv_counts))
+            partition.check_plans(self.plan, self.rank, gathered)
+        self.h = _capi.Handle(device_id)
+        self.h.set_options(options)
+        self.backend = backend
+        if self.world > 1:
+            if backend == "rccl":
+                uid = self.h.unique_id() if self.rank == 0 else None
+                uid = self.boot.broadcast_bytes(uid, root=0)
+                self.h.comm_init_rccl(self.world, self.rank, uid)
+            elif backend == "host":
+                self.h.comm_init_host(self.world, self.rank, self.boot.allreduce_sum, self.boot.exchange, self.boot.allgather_array)
+            else:
+                raise ValueError(f"unknown backend {backend!r}")
+        self.h.set_csr(self.M, self.lo, local.rowptr, self.plan.colidx, local.vals, ncols_ext=self.plan.ncols_ext)
+        if self.plan.mode == "halo":
+            self.h.set_halo(self.plan.peers, self.plan.send_counts, self.plan.send_idx, self.plan.recv_counts)
+        elif self.plan.mode == "allgather":
+            self.h.set_allgather(self.plan.chunk)
+        self.executed = False
+
+    def start_vector(self, seed=99, v0=None):
+        """The reference's start vector (Lanczos.py:93-100), generated identically on every rank."""
+        np.random.seed(seed)
+        v = np.random.uniform(-1, 1, size=(self.M)) if v0 is None else np.array(v0)
+        return v / np.linalg.norm(v)
+
+    def execute_Lanczos(self, n, seed=99, v0=None, v0_normalized_local=None):
+        if n > self.M:
+            raise ValueError("n cannot be larger than M!")
+        if v0_normalized_local is None:
+            v0_normalized_local = self.start_vector(seed, v0)[self.lo : self.hi]
+        self.n = n
+        self.alpha, self.beta = self.h.run(n, v0_normalized_local)
+        idx = np.arange(n)
+        H_eff = np.zeros((n, n))
+        H_eff[idx, idx] = self.alpha
+        H_eff[idx[:-1], idx[1:]] = self.beta
+        H_eff[idx[1:], idx[:-1]] = self.beta
+        self.H_eff = H_eff
+        self.executed = True
+        return self.alpha, self.beta
+
+    @property
+    def V_local(self):
+        """(rows_local, n) block of the basis."""
+        return self.h.get_basis().T
+
+    def get_H_eigs(self, fetch=True):
+        self.H_eigvals, S = np.linalg.eigh(self.H_eff)
+        self.H_eigvecs_local = self.h.ritz_vectors(S, fetch=fetch)
+        return self.H_eigvals
+
+    def timings(self):
+        return self.h.timings()

