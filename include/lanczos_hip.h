@@ -48,7 +48,8 @@ enum lz_flags {
   LZ_FLAG_QTW_MFMA = 2,       /* use the MFMA (v_mfma_f64_16x16x4_f64) Q^T w kernel        */
   LZ_FLAG_QTW_VALU = 4,       /* force the VALU/shuffle Q^T w kernel                      */
   LZ_FLAG_SPMV_SCALAR = 8,    /* force the plain one-thread-per-row CSR kernel            */
-  LZ_FLAG_FUSED_NORM = 16     /* multi-rank only: fold ||r||^2 into the Q^T r all-reduce   */
+  LZ_FLAG_FUSED_NORM = 16,    /* multi-rank only: fold ||r||^2 into the Q^T r all-reduce   */
+  LZ_FLAG_SPMV_STREAM = 32    /* force the generic CSR-stream kernel (no fixed-K fast path) */
 };
 
 /* kernel classes reported by lz_get_timings */
@@ -79,6 +80,10 @@ int lz_create(lz_handle* out, int device_id);
 int lz_destroy(lz_handle h);
 const char* lz_last_error(lz_handle h); /* h may be NULL: last error of lz_create */
 int lz_set_options(lz_handle h, int flags);
+/* A/B tuning knobs for kernel experiments (index 0: Q^T w slice length per block, 1: Q^T w
+ * kernel variant, 2: SpMV rows per block, 3: SpMV variant); takes effect at the next
+ * lz_set_csr / lz_basis_alloc.  Results never depend on them beyond summation order. */
+int lz_set_tuning(lz_handle h, int index, int value);
 int lz_device_synchronize(lz_handle h);
 int lz_device_name(lz_handle h, char* buf, size_t buflen);
 /* vectors are padded to 256-byte multiples on the device; in halo mode the ghost

@@ -23,6 +23,7 @@ FLAG_QTW_MFMA = 2
 FLAG_QTW_VALU = 4
 FLAG_SPMV_SCALAR = 8
 FLAG_FUSED_NORM = 16
+FLAG_SPMV_STREAM = 32
 
 KERNEL_CLASSES = ("spmv", "qtw", "update", "three_term", "final", "comm", "ritz")
 K_COUNT = len(KERNEL_CLASSES)
@@ -57,6 +58,7 @@ SIGNATURES = {
     "lz_destroy": (C.c_int, [_P]),
     "lz_last_error": (C.c_char_p, [_P]),
     "lz_set_options": (C.c_int, [_P, C.c_int]),
+    "lz_set_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
     "lz_device_synchronize": (C.c_int, [_P]),
     "lz_device_name": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "lz_padded_rows": (C.c_int64, [C.c_int64]),
@@ -168,6 +170,9 @@ class Handle:
 
     def set_options(self, flags):
         self.check(self.lib.lz_set_options(self._h, int(flags)))
+
+    def set_tuning(self, index, value):
+        self.check(self.lib.lz_set_tuning(self._h, int(index), int(value)))
 
     def synchronize(self):
         self.check(self.lib.lz_device_synchronize(self._h))

@@ -69,6 +69,7 @@ struct lz_context {
   std::string err;
   std::string name;
   int flags = 0;
+  int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // A/B knobs, see lz_set_tuning
 
   // partition
   int64_t Mg = 0, row0 = 0, rows = 0, ncols_ext = 0;
@@ -345,12 +346,12 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx) {
   {
     Scope sc(h, LZ_K_QTW, 8.0 * (nrows - 1) * M + (scale ? 16.0 : 8.0) * M, 2.0 * nrows * M);
     launch_qtw(h->d_V, h->ldv, h->rows_pad, nrows, j, scale ? h->d_r : nullptr, h->d_nrm2, h->d_beta + beta_idx, h->qplan,
-               h->d_part, h->flags, h->stream);
+               h->d_part, h->stream);
     LZ_TRY(check_launch(h, "qtw"));
   }
   {
     Scope sc(h, LZ_K_FINAL, 0, 0);
-    launch_final_rows(h->d_part, nrows, h->qplan.G, h->d_c, h->stream);
+    launch_final_rows(h->d_part, nrows, h->qplan.P, h->d_c, h->stream);
     LZ_TRY(check_launch(h, "final_rows"));
   }
   LZ_TRY(comm_allreduce(h, h->d_c, nrows));
@@ -386,14 +387,14 @@ int require_basis(lz_handle h, int j) {
   return LZ_OK;
 }
 
-void build_rowblocks(const int32_t* rowptr, int64_t rows, std::vector<int32_t>& blk) {
+void build_rowblocks(const int32_t* rowptr, int64_t rows, int rows_cap, int nnz_cap, std::vector<int32_t>& blk) {
   blk.clear();
   blk.push_back(0);
   int64_t r = 0;
   while (r < rows) {
     int64_t e = r;
     const int64_t k0 = rowptr[r];
-    while (e < rows && e - r < 512 && (int64_t)rowptr[e + 1] - k0 <= 4096) ++e;
+    while (e < rows && e - r < rows_cap && (int64_t)rowptr[e + 1] - k0 <= nnz_cap) ++e;
     if (e == r) e = r + 1;  // a single row longer than the LDS tile: block of its own
     blk.push_back((int32_t)e);
     r = e;
@@ -489,6 +490,12 @@ const char* lz_last_error(lz_handle h) { return h ? h->err.c_str() : g_create_er
 int lz_set_options(lz_handle h, int flags) {
   if (!h) return LZ_ERR_ARG;
   h->flags = flags;
+  return LZ_OK;
+}
+
+int lz_set_tuning(lz_handle h, int index, int value) {
+  if (!h || index < 0 || index >= 8) return LZ_ERR_ARG;
+  h->tune[index] = value;
   return LZ_OK;
 }
 
@@ -591,7 +598,13 @@ int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, 
     LZ_HIP(h, hipMemcpy(A.vals, vals, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
   }
   std::vector<int32_t> blk;
-  build_rowblocks(rowptr, rows_local, blk);
+  int rows_cap = h->tune[2] > 0 ? h->tune[2] : 512;
+  int nnz_cap = h->tune[4] > 0 ? h->tune[4] : 4096;
+  if (nnz_cap > 16384) nnz_cap = 16384;
+  build_rowblocks(rowptr, rows_local, rows_cap, nnz_cap, blk);
+  A.blk_nnz_cap = nnz_cap;
+  A.ablation = h->tune[3];
+  A.fixed_rb = h->tune[5] > 0 ? h->tune[5] : 512;
   LZ_TRY(dev_alloc(h, A.rowblk, blk.size()));
   LZ_HIP(h, hipMemcpy(A.rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   A.n_rowblk = (int)blk.size() - 1;
@@ -704,8 +717,8 @@ int lz_basis_alloc(lz_handle h, int n) {
     LZ_TRY(dev_alloc(h, h->d_nrm2, 2));
   }
   h->n = n;
-  h->qplan = plan_qtw(h->rows_pad);
-  size_t need = (size_t)(n + 4) * (size_t)h->qplan.G;
+  h->qplan = plan_qtw(h->rows_pad, h->flags, h->tune);
+  size_t need = (size_t)(n + 16) * (size_t)h->qplan.P;
   need = std::max<size_t>(need, 4096);
   need = std::max<size_t>(need, (size_t)(h->rows / 4 + 64));                     // dense gemv / scalar spmv partials
   need = std::max<size_t>(need, (size_t)h->csr.n_rowblk + 64);

@@ -29,6 +29,9 @@ struct CsrDev {
   int fixed_k = 0;            // > 0: every row has exactly fixed_k entries
   int32_t* rowblk = nullptr;  // CSR-stream row blocks: rows [rowblk[b], rowblk[b+1])
   int n_rowblk = 0;
+  int fixed_rb = 512;         // rows per block of the fixed-K kernel
+  int ablation = 0;           // timing-only ablation arm (tools/kbench.py), 0 in production
+  int blk_nnz_cap = 4096;     // products per row block (LDS tile of the CSR-stream kernel)
   int max_row_nnz = 0;
   double avg_row_nnz = 0;
 };
@@ -45,14 +48,17 @@ void launch_final_sum(const double* part, int n, double* out, hipStream_t s);
 void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s);
 
 struct QtwPlan {
-  int64_t L = 0;   // elements of w owned by one block (multiple of 512)
-  int G = 0;       // number of blocks
+  int64_t L = 0;    // elements of w owned by one block (multiple of 512)
+  int G = 0;        // number of blocks
+  int P = 0;        // partials per basis row (G for the VALU kernel, 4G for the MFMA kernel)
+  bool mfma = false;
+  int variant = 0;  // A/B knob (unroll / rows per tile)
 };
-QtwPlan plan_qtw(int64_t len);
+QtwPlan plan_qtw(int64_t len, int flags, const int* tune);
 // pass 1 of the re-orthogonalisation (+ optional v_j = r / sqrt(nrm2)):
 //   part[i*G + b] = sum_{m in block b} V[i][m] * V[j][m],  i in [0, nrows)
 void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                double* beta_slot, const QtwPlan& plan, double* part, int flags, hipStream_t s);
+                double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s);
 // pass 2: V[j] = 2 V[j] - sum_{i<nrows} c[i] V[i] (sequential, unfused: bitwise NumPy order)
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, hipStream_t s);
 // r = (r - alpha v_j) - beta v_jm1 ; part[b] = partial ||r||^2 ; returns number of partials

@@ -45,12 +45,28 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 }
 
 // ------------------------------------------------------------------ second-stage reductions
-__global__ __launch_bounds__(kTPB) void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
-  __shared__ double sm[kTPB / 64];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += kTPB) acc += part[i];
-  acc = block_sum(acc, sm);
-  if (threadIdx.x == 0) out[0] = acc;
+constexpr int kFinalThreads = 1024;
+__global__ __launch_bounds__(kFinalThreads) void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double sm[kFinalThreads / 64];
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int i = threadIdx.x;
+  for (; i + 3 * kFinalThreads < n; i += 4 * kFinalThreads) {
+    a0 += part[i];
+    a1 += part[i + kFinalThreads];
+    a2 += part[i + 2 * kFinalThreads];
+    a3 += part[i + 3 * kFinalThreads];
+  }
+  for (; i < n; i += kFinalThreads) a0 += part[i];
+  double acc = wave_sum((a0 + a1) + (a2 + a3));
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kFinalThreads / 64; ++k) t += sm[k];
+    out[0] = t;
+  }
 }
 
 __global__ __launch_bounds__(kTPB) void k_final_rows(const double* __restrict__ part, int G, double* __restrict__ c) {
@@ -63,7 +79,7 @@ __global__ __launch_bounds__(kTPB) void k_final_rows(const double* __restrict__ 
 }
 
 void launch_final_sum(const double* part, int n, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kTPB), 0, s, part, n, out);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kFinalThreads), 0, s, part, n, out);
 }
 void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s) {
   if (nrows <= 0) return;
@@ -95,15 +111,16 @@ __global__ __launch_bounds__(kTPB) void k_spmv_scalar(const int32_t* __restrict_
 // adds up its rows from LDS in CSR order (same order and rounding as SciPy's
 // csr_matvec: sum += a*x, no FMA).  Row blocks are precomputed on the host so
 // that one block's products fit the LDS tile.
-constexpr int kStreamNnz = 4096;   // products per block tile (32 KiB of LDS)
-constexpr int kStreamRows = 512;   // max rows per block
 
-template <int FIXED_K>
+// ABL != 0 instantiations are timing-only ablation arms for tools/kbench.py (wrong results on purpose):
+// 1 = no x gather, 2 = no colidx load, 4 = no vals load, 8 = no y store.
+template <int FIXED_K, int ABL = 0>
 __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict__ rowblk, const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ colidx, const double* __restrict__ vals,
                                                      const double* __restrict__ x, const double* __restrict__ xown,
-                                                     double* __restrict__ y, int fixed_k, double* __restrict__ part) {
-  __shared__ double prod[kStreamNnz + 2];
+                                                     double* __restrict__ y, int fixed_k, int nnz_cap,
+                                                     double* __restrict__ part) {
+  extern __shared__ double prod[];  // nnz_cap + 2 products
   __shared__ double sm[kTPB / 64];
   const int blk = xcd_remap(blockIdx.x, gridDim.x);
   const int r0 = rowblk[blk], r1 = rowblk[blk + 1];
@@ -111,17 +128,38 @@ __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict_
   const int k0 = K > 0 ? r0 * K : rowptr[r0];
   const int k1 = K > 0 ? r1 * K : rowptr[r1];
   double d = 0.0;
-  if (k1 - k0 <= kStreamNnz) {
-    // phase 1: products, two entries per lane per step, aligned to even k
+  if (k1 - k0 <= nnz_cap) {
+    // phase 1: products, two entries per lane per step, aligned to even k.  Batches of 4 steps:
+    // all (vals, colidx) loads of a batch are issued first, then its 8 x gathers, then the LDS
+    // stores - 3 dependent round trips per batch instead of 8.
     const int kk = k0 & ~1;
     const int npair = (k1 - kk + 1) >> 1;
-    for (int p = threadIdx.x; p < npair; p += kTPB) {
-      const int k = kk + 2 * p;
-      const double2 a = *reinterpret_cast<const double2*>(vals + k);
-      const int2 c = *reinterpret_cast<const int2*>(colidx + k);
-      const double p0 = (k >= k0) ? a.x * x[c.x] : 0.0;
-      const double p1 = (k + 1 < k1) ? a.y * x[c.y] : 0.0;
-      *reinterpret_cast<double2*>(&prod[2 * p]) = make_double2(p0, p1);
+    constexpr int NB = 4;
+    for (int pb = threadIdx.x; pb < npair; pb += NB * kTPB) {
+      double2 a[NB];
+      int2 c[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        int p = pb + kTPB * i;
+        if (p >= npair) p = pb;  // clamped duplicate, discarded below
+        const int k = kk + 2 * p;
+        a[i] = (ABL & 4) ? make_double2(1.0, 2.0) : *reinterpret_cast<const double2*>(vals + k);
+        c[i] = (ABL & 2) ? make_int2(k / (K > 0 ? K : 1), (k + 1) / (K > 0 ? K : 1)) : *reinterpret_cast<const int2*>(colidx + k);
+        if (ABL & 1) c[i] = make_int2(c[i].x & 1023, c[i].y & 1023);
+      }
+      double2 xv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) xv[i] = make_double2(x[c[i].x], x[c[i].y]);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int p = pb + kTPB * i;
+        if (p < npair) {
+          const int k = kk + 2 * p;
+          const double p0 = (k >= k0) ? a[i].x * xv[i].x : 0.0;
+          const double p1 = (k + 1 < k1) ? a[i].y * xv[i].y : 0.0;
+          *reinterpret_cast<double2*>(&prod[2 * p]) = make_double2(p0, p1);
+        }
+      }
     }
     __syncthreads();
     // phase 2: per-row sequential sums out of LDS
@@ -142,7 +180,7 @@ __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict_
       } else {
         for (int k = a; k < b; ++k) sum += prod[k];
       }
-      y[row] = sum;
+      if (!(ABL & 8)) y[row] = sum;
       d += xown[row] * sum;
     }
   } else {
@@ -162,6 +200,78 @@ __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict_
   if (threadIdx.x == 0) part[blk] = d;
 }
 
+// (c) fixed-K rows (stencils): every block owns exactly RB rows = RB*K contiguous entries, so all
+// trip counts are compile-time: each lane first issues ALL its 16-byte vals and 8-byte colidx loads
+// (NP of each), then all 2*NP x gathers, then stages the products in LDS; after one barrier each
+// lane adds up RB/256 rows from LDS in CSR order.  Three dependent memory round trips per block
+// instead of 2*NP, and an LDS tile of exactly RB*K products.  rowptr is never read.
+template <int K, int RB>
+__global__ __launch_bounds__(kTPB) void k_spmv_fixed(const int32_t* __restrict__ colidx, const double* __restrict__ vals,
+                                                    const double* __restrict__ x, const double* __restrict__ xown,
+                                                    double* __restrict__ y, int rows, double* __restrict__ part) {
+  constexpr int NNZ = RB * K;              // even (RB is a multiple of 256)
+  constexpr int NP = NNZ / 2 / kTPB;       // double2 pairs per lane
+  constexpr int RPT = RB / kTPB;           // rows per lane
+  static_assert(NNZ % (2 * kTPB) == 0, "RB*K must be a multiple of 512");
+  __shared__ double prod[NNZ];
+  __shared__ double sm[kTPB / 64];
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int r0 = blk * RB;
+  const int nr = rows - r0 < RB ? rows - r0 : RB;
+  const int64_t k0 = (int64_t)r0 * K;
+  const int kcnt = nr * K;                 // entries of this block
+  const double2* v2 = reinterpret_cast<const double2*>(vals + k0);
+  const int2* c2 = reinterpret_cast<const int2*>(colidx + k0);
+  double2 a[NP];
+  int2 c[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    int p = threadIdx.x + kTPB * i;
+    if (2 * p >= kcnt) p = 0;              // tail block: valid address, product discarded below
+    a[i] = v2[p];
+    c[i] = c2[p];
+  }
+  double2 xv[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xv[i] = make_double2(x[c[i].x], x[c[i].y]);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = threadIdx.x + kTPB * i;
+    double2 pr = make_double2(a[i].x * xv[i].x, a[i].y * xv[i].y);
+    if (2 * p >= kcnt) pr = make_double2(0.0, 0.0);
+    else if (2 * p + 1 >= kcnt) pr.y = 0.0;
+    *reinterpret_cast<double2*>(&prod[2 * p]) = pr;
+  }
+  __syncthreads();
+  double d = 0.0;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int lr = threadIdx.x + kTPB * q;
+    if (lr < nr) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) sum += prod[lr * K + k];
+      y[r0 + lr] = sum;
+      d += xown[r0 + lr] * sum;
+    }
+  }
+  d = block_sum(d, sm);
+  if (threadIdx.x == 0) part[blk] = d;
+}
+
+template <int K>
+static int launch_spmv_fixed(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int rb,
+                             hipStream_t s) {
+  if (rb == 1024) {
+    const int grid = (int)((A.rows + 1023) / 1024);
+    hipLaunchKernelGGL((k_spmv_fixed<K, 1024>), dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, x, x_own, y, (int)A.rows, part);
+    return grid;
+  }
+  const int grid = (int)((A.rows + 511) / 512);
+  hipLaunchKernelGGL((k_spmv_fixed<K, 512>), dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, x, x_own, y, (int)A.rows, part);
+  return grid;
+}
+
 int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
                     hipStream_t s) {
   if (A.rows == 0) return 0;
@@ -170,14 +280,33 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
     hipLaunchKernelGGL(k_spmv_scalar, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, x, x_own, y, A.rows, part);
     return grid;
   }
+  if (!A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) {
+    if (A.fixed_k == 5) return launch_spmv_fixed<5>(A, x, y, x_own, part, A.fixed_rb, s);
+    if (A.fixed_k == 7) return launch_spmv_fixed<7>(A, x, y, x_own, part, A.fixed_rb, s);
+  }
   const int grid = A.n_rowblk;
+  const size_t lds = (size_t)(A.blk_nnz_cap + 2) * sizeof(double);
+#define LZ_ABL(n)                                                                                                   \
+  case n:                                                                                                          \
+    hipLaunchKernelGGL((k_spmv_stream<5, n>), dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, \
+                       5, A.blk_nnz_cap, part);                                                                    \
+    return grid;
+  if (A.fixed_k == 5 && A.ablation) {
+    switch (A.ablation) {
+      LZ_ABL(1) LZ_ABL(2) LZ_ABL(3) LZ_ABL(4) LZ_ABL(7) LZ_ABL(8) LZ_ABL(15)
+      default: break;
+    }
+  }
+#undef LZ_ABL
   if (A.fixed_k == 5)
-    hipLaunchKernelGGL(k_spmv_stream<5>, dim3(grid), dim3(kTPB), 0, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, 5, part);
+    hipLaunchKernelGGL(k_spmv_stream<5>, dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, 5,
+                       A.blk_nnz_cap, part);
   else if (A.fixed_k == 7)
-    hipLaunchKernelGGL(k_spmv_stream<7>, dim3(grid), dim3(kTPB), 0, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, 7, part);
+    hipLaunchKernelGGL(k_spmv_stream<7>, dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, 7,
+                       A.blk_nnz_cap, part);
   else
-    hipLaunchKernelGGL(k_spmv_stream<0>, dim3(grid), dim3(kTPB), 0, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y,
-                       A.fixed_k, part);
+    hipLaunchKernelGGL(k_spmv_stream<0>, dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y,
+                       A.fixed_k, A.blk_nnz_cap, part);
   return grid;
 }
 
@@ -211,21 +340,25 @@ int launch_gemv_dense(const double* A, int64_t M, const double* x, double* y, do
 // ------------------------------------------------------------------ re-orthogonalisation pass 1: c = Q^T w
 // Block b owns the contiguous slice [b*L, b*L+cnt) of every basis row.  The
 // slice of w (= V[j], optionally formed here as r / beta and stored) is kept in
-// LDS; the block then streams the same slice of rows 0..nrows-1 (row j itself
-// comes from LDS), R rows at a time, each lane accumulating R partial dots, and
-// reduces them once per R rows.
-constexpr int kQtwR = 4;
+// LDS for the whole launch; the block then streams the same slice of rows
+// 0..nrows-1.
+//
+//  * VALU variant: R rows at a time, each lane accumulating R partial dots over
+//    U*R independent 16-byte loads, one shuffle + LDS reduction per R rows.
+//  * MFMA variant: each wave owns a quarter of the slice and walks 16-row tiles
+//    with v_mfma_f64_16x16x4_f64: A = 16 basis rows x 4 consecutive elements,
+//    B = the matching 4 entries of w broadcast over the 16 columns.  The
+//    contraction over the long dimension happens inside the matrix core, so the
+//    main loop has no cross-lane reduction and no barrier at all; 15/16 of the
+//    MFMA columns are redundant, which is affordable because the step is HBM
+//    bound (the matrix pipe is ~30 % busy at full HBM rate).
 constexpr int kQtwMaxL = 5120;  // 40 KiB of LDS -> 4 blocks per CU
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 template <bool SCALE>
-__global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
-                                                  const double* __restrict__ r, const double* __restrict__ nrm2,
-                                                  double* __restrict__ beta_slot, int64_t L, int G,
-                                                  double* __restrict__ part) {
-  extern __shared__ double2 sw[];
-  __shared__ double red[kQtwR][kTPB / 64];
-  const int64_t base = (int64_t)blockIdx.x * L;
-  const int cnt2 = (int)((len - base < L ? len - base : L) >> 1);  // double2 count of this slice
+__device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ldv, int j, const double* __restrict__ r,
+                                              const double* __restrict__ nrm2, double* __restrict__ beta_slot, int64_t base,
+                                              int cnt2, double2* sw) {
   double2* vj = reinterpret_cast<double2*>(V + (int64_t)j * ldv + base);
   double self = 0.0;
   if (SCALE) {
@@ -249,37 +382,51 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
       self = fma(v.y, v.y, self);
     }
   }
+  return self;
+}
+
+template <bool SCALE, int R, int U>
+__global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
+                                                  const double* __restrict__ r, const double* __restrict__ nrm2,
+                                                  double* __restrict__ beta_slot, int64_t L, int G,
+                                                  double* __restrict__ part) {
+  extern __shared__ double2 sw[];
+  __shared__ double red[R][kTPB / 64];
+  const int64_t base = (int64_t)blockIdx.x * L;
+  const int cnt2 = (int)((len - base < L ? len - base : L) >> 1);  // double2 count of this slice
+  const double self = qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt2, sw);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i0 = 0; i0 < nrows; i0 += kQtwR) {
-    const double2* row[kQtwR];
+  for (int i0 = 0; i0 < nrows; i0 += R) {
+    const double2* row[R];
 #pragma unroll
-    for (int q = 0; q < kQtwR; ++q) {
+    for (int q = 0; q < R; ++q) {
       int i = i0 + q;
       if (i >= nrows) i = nrows - 1;                    // clamped duplicate, result discarded
+      if (i == j) i = i > 0 ? i - 1 : (nrows > 1 ? 1 : 0);  // self term comes from LDS: do not stream row j
       row[q] = reinterpret_cast<const double2*>(V + (int64_t)i * ldv + base);
     }
-    double acc[kQtwR];
+    double acc[R];
 #pragma unroll
-    for (int q = 0; q < kQtwR; ++q) acc[q] = 0.0;
-#pragma unroll 2
+    for (int q = 0; q < R; ++q) acc[q] = 0.0;
+#pragma unroll U
     for (int t = threadIdx.x; t < cnt2; t += kTPB) {
       const double2 wv = sw[t];
 #pragma unroll
-      for (int q = 0; q < kQtwR; ++q) {
+      for (int q = 0; q < R; ++q) {
         const double2 v = row[q][t];
         acc[q] = fma(v.x, wv.x, acc[q]);
         acc[q] = fma(v.y, wv.y, acc[q]);
       }
     }
 #pragma unroll
-    for (int q = 0; q < kQtwR; ++q) {
-      if (i0 + q == j) acc[q] = self;  // the self term c_j = w.w from LDS-resident data (same values)
+    for (int q = 0; q < R; ++q) {
+      if (i0 + q == j) acc[q] = self;  // c_j = w.w from the LDS-resident values
       const double s = wave_sum(acc[q]);
       if (lane == 0) red[q][w] = s;
     }
     __syncthreads();
-    if (threadIdx.x < kQtwR && i0 + threadIdx.x < nrows) {
+    if (threadIdx.x < R && i0 + threadIdx.x < nrows) {
       double s = 0.0;
 #pragma unroll
       for (int k = 0; k < kTPB / 64; ++k) s += red[threadIdx.x][k];
@@ -289,25 +436,209 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
   }
 }
 
-QtwPlan plan_qtw(int64_t len) {
+// Software-pipelined VALU variant.  The (row-tile, position) items of a block are
+// walked as ONE stream with D register buffers of R loads each: the loads of item
+// k+D-1 are issued before item k is consumed, also across tile boundaries, so a
+// lane always has (D-1)*R .. D*R 16-byte loads in flight and nothing drains at the
+// per-tile reduction.  Each wave reduces and writes its own partials (no barrier in
+// the main loop): P = 4*G partials per basis row.
+template <bool SCALE, int R, int D>
+__global__ __launch_bounds__(kTPB) void k_qtw_pipe(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
+                                                  const double* __restrict__ r, const double* __restrict__ nrm2,
+                                                  double* __restrict__ beta_slot, int64_t L, int P,
+                                                  double* __restrict__ part) {
+  extern __shared__ double2 sw[];
+  const int64_t base = (int64_t)blockIdx.x * L;
+  const int cnt2 = (int)((len - base < L ? len - base : L) >> 1);
+  const int npos = (cnt2 + kTPB - 1) / kTPB;  // block-uniform
+  double self = qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt2, sw);
+  for (int t = cnt2 + threadIdx.x; t < npos * kTPB; t += kTPB) sw[t] = make_double2(0.0, 0.0);  // weights of the padding lanes
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int pid = blockIdx.x * (kTPB / 64) + w;
+  const int ntiles = (nrows + R - 1) / R;
+  const int K = ntiles * npos;
+  const double2* Vb = reinterpret_cast<const double2*>(V + base);
+  const int64_t ld2 = ldv >> 1;
+  double2 buf[D][R];
+  double acc[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) acc[q] = 0.0;
+  int ptile = 0, ppos = 0, ctile = 0, cpos = 0;
+
+  auto issue = [&](double2(&b)[R]) {
+    int t = threadIdx.x + kTPB * ppos;
+    if (t >= cnt2) t = cnt2 - 1;  // padding lane: valid address, zero weight
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      int i = ptile * R + q;
+      if (i >= nrows) i = nrows - 1;  // clamped duplicate, discarded at the store
+      b[q] = Vb[(int64_t)i * ld2 + t];
+    }
+    if (++ppos == npos) {
+      ppos = 0;
+      ++ptile;
+    }
+  };
+  auto consume = [&](const double2(&b)[R]) {
+    const double2 wv = sw[threadIdx.x + kTPB * cpos];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      acc[q] = fma(b[q].x, wv.x, acc[q]);
+      acc[q] = fma(b[q].y, wv.y, acc[q]);
+    }
+    if (++cpos == npos) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int row = ctile * R + q;
+        const double s = wave_sum(row == j ? self : acc[q]);  // c_j = w.w from the LDS-resident values
+        if (lane == 0 && row < nrows) part[(int64_t)row * P + pid] = s;
+        acc[q] = 0.0;
+      }
+      cpos = 0;
+      ++ctile;
+    }
+  };
+
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d)
+    if (d < K) issue(buf[d]);
+  for (int k = 0; k < K; k += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (k + d + D - 1 < K) issue(buf[(d + D - 1) % D]);
+      if (k + d < K) consume(buf[d]);
+    }
+  }
+}
+
+// MFMA variant.  Lane l of a wave: row r = l & 15 of the current 16-row tile,
+// k-group g = l >> 4.  Step s covers 8 consecutive elements of the slice
+// (64 B per row): the lane loads the double2 at element 8*s + 2*g of its row;
+// the two halves feed two MFMAs whose B operands are the matching w entries
+// (one ds_read_b128 per step, 4 distinct addresses per wave -> conflict free).
+// D layout (f64 16x16x4): lane l holds D[row = (l>>4) + 4*reg][col = l&15];
+// all 16 columns are equal, column-0 lanes write the per-wave partials.
+template <bool SCALE, int U, int T>
+__global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
+                                                  const double* __restrict__ r, const double* __restrict__ nrm2,
+                                                  double* __restrict__ beta_slot, int64_t L, int P,
+                                                  double* __restrict__ part) {
+  extern __shared__ double2 sw[];
+  const int64_t base = (int64_t)blockIdx.x * L;
+  const int cnt = (int)(len - base < L ? len - base : L);
+  qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
+  __syncthreads();  // also makes this block's V[j] stores visible to its own later loads
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int sub = (int)(L >> 2);                 // elements per wave (multiple of 128)
+  const int m_lo = w * sub;
+  int m_hi = m_lo + sub;
+  if (m_hi > cnt) m_hi = cnt;
+  const int nsteps = m_hi > m_lo ? (m_hi - m_lo) >> 3 : 0;  // multiple of 4 (cnt and sub are multiples of 32)
+  const int pid = blockIdx.x * (kTPB / 64) + w;
+  const double2* swl = sw + (m_lo >> 1) + g;     // + 4*s per step
+  for (int i0 = 0; i0 < nrows; i0 += 16 * T) {
+    const double2* a[T];
+    double4_t acc[T][2];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      int i = i0 + 16 * t + lr;
+      if (i >= nrows) i = nrows - 1;             // clamped duplicate, discarded at the store
+      a[t] = reinterpret_cast<const double2*>(V + (int64_t)i * ldv + base + m_lo) + g;
+      acc[t][0] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      acc[t][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+      double2 av[T][U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < T; ++t) av[t][u] = (s0 + u < nsteps) ? a[t][4 * (s0 + u)] : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double2 bv = (s0 + u < nsteps) ? swl[4 * (s0 + u)] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t][u].x, bv.x, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t][u].y, bv.y, acc[t][1], 0, 0, 0);
+        }
+      }
+    }
+    if (lr == 0) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = i0 + 16 * t + g + 4 * q;
+          if (row < nrows) part[(int64_t)row * P + pid] = acc[t][0][q] + acc[t][1][q];
+        }
+    }
+  }
+}
+
+QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   QtwPlan p;
-  int64_t L = round_up((len + 2047) / 2048, 512);
+  int64_t target = (tune && tune[0] > 0) ? tune[0] : 0;
+  int64_t L = target > 0 ? round_up(target, 512) : round_up((len + 2047) / 2048, 512);
   if (L < 512) L = 512;
   if (L > kQtwMaxL) L = kQtwMaxL;
   p.L = L;
   p.G = (int)((len + L - 1) / L);
+  p.mfma = (flags & LZ_FLAG_QTW_MFMA) != 0 && (flags & LZ_FLAG_QTW_VALU) == 0;
+  p.variant = tune ? tune[1] : 0;
+  p.P = (p.mfma || p.variant >= 8) ? p.G * (kTPB / 64) : p.G;
   return p;
 }
 
-void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                double* beta_slot, const QtwPlan& plan, double* part, int flags, hipStream_t s) {
+template <bool SCALE>
+static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
+                         double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s) {
   const size_t lds = (size_t)plan.L * sizeof(double);
+  const dim3 grid(plan.G), block(kTPB);
+#define LZ_QTW_ARGS V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, plan.P, part
+  if (plan.mfma) {
+    switch (plan.variant) {
+      case 1: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 2: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 16, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 3: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 4: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 5: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      default: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+    }
+  } else {
+    switch (plan.variant) {
+      case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 2: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 3: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 4: hipLaunchKernelGGL((k_qtw_valu<SCALE, 16, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 5: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 6: hipLaunchKernelGGL((k_qtw_valu<SCALE, 16, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 7: hipLaunchKernelGGL((k_qtw_valu<SCALE, 12, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 8: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 9: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 10: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 11: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 16, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 12: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 4, 6>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 13: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 14: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      default:  // measured best on MI355X (profiles/r01): 8 rows x 2 positions = 16 loads in flight per lane
+        if (nrows > 4)
+          hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS);
+        else
+          hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS);
+        break;
+    }
+  }
+#undef LZ_QTW_ARGS
+}
+
+void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
+                double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s) {
   if (r)
-    hipLaunchKernelGGL(k_qtw_valu<true>, dim3(plan.G), dim3(kTPB), lds, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L,
-                       plan.G, part);
+    launch_qtw_t<true>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
   else
-    hipLaunchKernelGGL(k_qtw_valu<false>, dim3(plan.G), dim3(kTPB), lds, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L,
-                       plan.G, part);
+    launch_qtw_t<false>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
 }
 
 // ------------------------------------------------------------------ re-orthogonalisation pass 2
@@ -407,7 +738,6 @@ void launch_gather(const double* x, const int32_t* idx, int64_t n, double* buf, 
 // A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; the 4 results per lane are
 // D[row = (l>>4) + 4*reg][col = l&15].  One wave owns a 32(m) x 64(i) tile
 // (8 accumulators), the 4 waves of a block stack along m.
-typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int kRitzMT = 2;  // 16-row m tiles per wave
 constexpr int kRitzNT = 4;  // 16-col i tiles per wave
 
