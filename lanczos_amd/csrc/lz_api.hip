@@ -233,7 +233,7 @@ int drain_events(lz_handle h) {
 
 // ---- collectives --------------------------------------------------------
 int comm_allreduce(lz_handle h, double* dbuf, int64_t count) {
-  if (h->world <= 1 || count <= 0) return LZ_OK;
+  if ((h->world <= 1 && !(h->tune[6] && h->comm_kind)) || count <= 0) return LZ_OK;
   Scope sc(h, LZ_K_COMM, 8.0 * count, 0);
   if (h->comm_kind == 1) {
     LZ_NCCL(h, g_rccl.AllReduce(dbuf, dbuf, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream));
@@ -255,7 +255,7 @@ int comm_allreduce(lz_handle h, double* dbuf, int64_t count) {
 int comm_exchange_x(lz_handle h, int j, const double** x_out) {
   double* vj = h->d_V + (int64_t)j * h->ldv;
   *x_out = vj;
-  if (h->world <= 1) return LZ_OK;
+  if (h->world <= 1 && !(h->tune[6] && h->comm_kind)) return LZ_OK;
   if (h->xmode == 1) {
     if (h->peers.empty()) return LZ_OK;
     Scope sc(h, LZ_K_COMM, 8.0 * (h->total_send + h->total_recv), 0);
