@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--k", type=int, default=0, help="override the number of Lanczos iterations")
     ap.add_argument("--options", type=int, default=0, help="extra lz_flags (A/B arms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents (roofline fields become null)")
     ap.add_argument("--backend", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--mode", default="auto", choices=["auto", "halo", "allgather"])
     args = ap.parse_args()
@@ -151,10 +152,11 @@ def main():
     local = build_local(kind, dims, lo, hi)
     t_build = time.perf_counter() - t0
 
+    prof = 0 if args.no_profile else _capi.FLAG_PROFILE
     comm_used = "none" if world == 1 else args.backend
     try:
         solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend=args.backend, mode=args.mode,
-                                                options=args.options | _capi.FLAG_PROFILE)
+                                                options=args.options | prof)
         ok = True
     except _capi.LanczosHipError as e:
         if world == 1 or args.backend != "rccl":
@@ -164,7 +166,7 @@ def main():
     if world > 1 and not all(boot.allgather_obj(ok)):
         comm_used = "host-gloo (RCCL init failed)"
         solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend="host", mode=args.mode,
-                                                options=args.options | _capi.FLAG_PROFILE)
+                                                options=args.options | prof)
     v0 = solver.start_vector(99)[lo:hi].copy()
 
     for _ in range(args.warmup):
@@ -186,6 +188,7 @@ def main():
     # sanity of the result (cheap): Ritz values finite, extreme one inside the Gershgorin bound
     theta = solver.get_H_eigs(fetch=False)
     assert np.isfinite(theta).all()
+    tr = solver.timings()["ritz"]
 
     if rank == 0:
         iters = args.steps * k
@@ -238,6 +241,10 @@ def main():
             "setup_s": {"matrix_build": round(t_build, 2)},
             "device": solver.h.device_name(),
             "ritz_min_max": [float(theta.min()), float(theta.max())],
+            "ritz_backtransform": {"ms": round(tr["ms"], 3), "tflops": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9, 2),
+                                   "bound": "mfma", "peak_tflops": FP64_MFMA_PEAK_TFLOPS,
+                                   "frac": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 4),
+                                   "note": "Y = V^T-layout x S (M x k x k) FP64 MFMA GEMM, outside the timed steps"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -5,7 +5,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -343,10 +345,13 @@ int step_spmv(lz_handle h, int j) {
 // V[j] = r / sqrt(nrm2) (if scale), then c = V[0:nrows] . V[j]; V[j] = 2 V[j] - c^T V[0:nrows]
 int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx) {
   const double M = (double)h->rows;
+  // fused-norm mode (multi-rank): one all-reduce carries [V_i . r (i < j), r . r]; beta and the scaling by
+  // 1/beta are applied afterwards.  Only valid for the in-loop call shape (row j is the newest row).
+  const bool fused = scale && (h->flags & LZ_FLAG_FUSED_NORM) && nrows == j + 1;
   {
-    Scope sc(h, LZ_K_QTW, 8.0 * (nrows - 1) * M + (scale ? 16.0 : 8.0) * M, 2.0 * nrows * M);
+    Scope sc(h, LZ_K_QTW, 8.0 * (nrows - 1) * M + (scale && !fused ? 16.0 : 8.0) * M, 2.0 * nrows * M);
     launch_qtw(h->d_V, h->ldv, h->rows_pad, nrows, j, scale ? h->d_r : nullptr, h->d_nrm2, h->d_beta + beta_idx, h->qplan,
-               h->d_part, h->stream);
+               h->d_part, fused ? 2 : (scale ? 1 : 0), h->stream);
     LZ_TRY(check_launch(h, "qtw"));
   }
   {
@@ -355,16 +360,21 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx) {
     LZ_TRY(check_launch(h, "final_rows"));
   }
   LZ_TRY(comm_allreduce(h, h->d_c, nrows));
+  if (fused) {
+    Scope sc(h, LZ_K_FINAL, 0, 0);
+    launch_fused_prepare(h->d_c, j, h->d_beta + beta_idx, h->stream);
+    LZ_TRY(check_launch(h, "fused_prepare"));
+  }
   {
-    Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + 16.0 * M, 2.0 * nrows * M);
-    launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, h->stream);
+    Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + (fused ? 16.0 : 16.0) * M, 2.0 * nrows * M);
+    launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->stream);
     LZ_TRY(check_launch(h, "update"));
   }
   return LZ_OK;
 }
 
 // r = r - alpha V[j] - beta V[jm1]; d_nrm2[0] = sum over ranks of ||r||^2
-int step_three_term(lz_handle h, int j, int jm1, const double* d_alpha, const double* d_beta) {
+int step_three_term(lz_handle h, int j, int jm1, const double* d_alpha, const double* d_beta, bool need_norm = true) {
   const double M = (double)h->rows;
   int np = 0;
   {
@@ -373,6 +383,7 @@ int step_three_term(lz_handle h, int j, int jm1, const double* d_alpha, const do
                            d_beta, h->rows_pad, h->d_part, h->stream);
     LZ_TRY(check_launch(h, "three_term"));
   }
+  if (!need_norm) return LZ_OK;  // fused-norm mode: ||r||^2 travels with the next Q^T r all-reduce
   {
     Scope sc(h, LZ_K_FINAL, 0, 0);
     launch_final_sum(h->d_part, np, h->d_nrm2, h->stream);
@@ -839,24 +850,34 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   if (!v0_local || !alpha_out || !beta_out) return fail(h, LZ_ERR_ARG, "lz_run: NULL buffer");
   if (n < 2) return fail(h, LZ_ERR_ARG, "lz_run: n must be >= 2 (the reference's beta array has n-1 entries)");
   if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run: n cannot be larger than M");
+  const bool dbg = getenv("LZ_DEBUG_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   LZ_TRY(lz_basis_alloc(h, n));
+  const double t1 = now();
   LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const double t2 = now();
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
   // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
   LZ_TRY(step_spmv(h, 0));
-  LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr));
+  const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0;
+  LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
   for (int j = 0; j < n; ++j) {
     const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
     LZ_TRY(step_reorth(h, j, j + 1, true, bidx));
     LZ_TRY(step_spmv(h, j));
     // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
-    LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx));
+    LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, !fused));
   }
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
+  const double t3 = now();
   h->run_timed = true;
   LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
+  if (dbg)
+    fprintf(stderr, "[lz_run] alloc+memset %.3f ms, v0 upload %.3f ms, enqueue loop %.3f ms, drain+D2H %.3f ms\n", t1 - t0, t2 - t1,
+            t3 - t2, now() - t3);
   {
     float ms = 0.f;
     LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));

@@ -58,9 +58,11 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune);
 // pass 1 of the re-orthogonalisation (+ optional v_j = r / sqrt(nrm2)):
 //   part[i*G + b] = sum_{m in block b} V[i][m] * V[j][m],  i in [0, nrows)
 void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s);
+                double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s);
 // pass 2: V[j] = 2 V[j] - sum_{i<nrows} c[i] V[i] (sequential, unfused: bitwise NumPy order)
-void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, hipStream_t s);
+void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
+                   const double* beta, hipStream_t s);
+void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s);
 // r = (r - alpha v_j) - beta v_jm1 ; part[b] = partial ||r||^2 ; returns number of partials
 int launch_three_term(double* r, const double* vj, const double* vjm1, const double* alpha, const double* beta,
                       int64_t len, double* part, hipStream_t s);

@@ -355,13 +355,15 @@ int launch_gemv_dense(const double* A, int64_t M, const double* x, double* y, do
 constexpr int kQtwMaxL = 5120;  // 40 KiB of LDS -> 4 blocks per CU
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-template <bool SCALE>
+// SCALE: 0 = w is V[j] as stored; 1 = w = r / sqrt(nrm2), stored to V[j] (beta to beta_slot);
+//        2 = w = r as is, nothing stored (fused-norm mode: the caller divides by beta afterwards).
+template <int SCALE>
 __device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ldv, int j, const double* __restrict__ r,
                                               const double* __restrict__ nrm2, double* __restrict__ beta_slot, int64_t base,
                                               int cnt2, double2* sw) {
   double2* vj = reinterpret_cast<double2*>(V + (int64_t)j * ldv + base);
   double self = 0.0;
-  if (SCALE) {
+  if (SCALE == 1) {
     const double beta = sqrt(nrm2[0]);
     if (blockIdx.x == 0 && threadIdx.x == 0) beta_slot[0] = beta;
     const double2* rr = reinterpret_cast<const double2*>(r + base);
@@ -375,8 +377,9 @@ __device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ld
       self = fma(v.y, v.y, self);
     }
   } else {
+    const double2* src = SCALE == 2 ? reinterpret_cast<const double2*>(r + base) : vj;
     for (int t = threadIdx.x; t < cnt2; t += kTPB) {
-      const double2 v = vj[t];
+      const double2 v = src[t];
       sw[t] = v;
       self = fma(v.x, v.x, self);
       self = fma(v.y, v.y, self);
@@ -385,7 +388,7 @@ __device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ld
   return self;
 }
 
-template <bool SCALE, int R, int U>
+template <int SCALE, int R, int U>
 __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                   const double* __restrict__ r, const double* __restrict__ nrm2,
                                                   double* __restrict__ beta_slot, int64_t L, int G,
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
 // lane always has (D-1)*R .. D*R 16-byte loads in flight and nothing drains at the
 // per-tile reduction.  Each wave reduces and writes its own partials (no barrier in
 // the main loop): P = 4*G partials per basis row.
-template <bool SCALE, int R, int D>
+template <int SCALE, int R, int D>
 __global__ __launch_bounds__(kTPB) void k_qtw_pipe(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                   const double* __restrict__ r, const double* __restrict__ nrm2,
                                                   double* __restrict__ beta_slot, int64_t L, int P,
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_pipe(double* __restrict__ V, int64
 // (one ds_read_b128 per step, 4 distinct addresses per wave -> conflict free).
 // D layout (f64 16x16x4): lane l holds D[row = (l>>4) + 4*reg][col = l&15];
 // all 16 columns are equal, column-0 lanes write the per-wave partials.
-template <bool SCALE, int U, int T>
+template <int SCALE, int U, int T>
 __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                   const double* __restrict__ r, const double* __restrict__ nrm2,
                                                   double* __restrict__ beta_slot, int64_t L, int P,
@@ -527,6 +530,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
   extern __shared__ double2 sw[];
   const int64_t base = (int64_t)blockIdx.x * L;
   const int cnt = (int)(len - base < L ? len - base : L);
+  static_assert(SCALE != 2, "the MFMA kernel streams row j from V[j]; fused-norm mode uses the VALU kernel");
   qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
   __syncthreads();  // also makes this block's V[j] stores visible to its own later loads
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -587,58 +591,51 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   p.G = (int)((len + L - 1) / L);
   p.mfma = (flags & LZ_FLAG_QTW_MFMA) != 0 && (flags & LZ_FLAG_QTW_VALU) == 0;
   p.variant = tune ? tune[1] : 0;
-  p.P = (p.mfma || p.variant >= 8) ? p.G * (kTPB / 64) : p.G;
+  p.P = (p.mfma || p.variant == 8 || p.variant == 9) ? p.G * (kTPB / 64) : p.G;
   return p;
 }
 
-template <bool SCALE>
+template <int SCALE>
 static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
                          double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s) {
   const size_t lds = (size_t)plan.L * sizeof(double);
   const dim3 grid(plan.G), block(kTPB);
 #define LZ_QTW_ARGS V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, plan.P, part
-  if (plan.mfma) {
-    switch (plan.variant) {
-      case 1: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 2: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 16, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 3: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 4: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 5: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      default: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+  if constexpr (SCALE != 2) {
+    if (plan.mfma) {
+      switch (plan.variant) {
+        case 1: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+        case 2: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 16, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+        case 3: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+        case 4: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+        default: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      }
+      return;
     }
-  } else {
-    switch (plan.variant) {
-      case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 2: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 3: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 4: hipLaunchKernelGGL((k_qtw_valu<SCALE, 16, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 5: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 6: hipLaunchKernelGGL((k_qtw_valu<SCALE, 16, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 7: hipLaunchKernelGGL((k_qtw_valu<SCALE, 12, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 8: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 9: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 10: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 11: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 16, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 12: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 4, 6>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 13: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 14: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      default:  // measured best on MI355X (profiles/r01): 8 rows x 2 positions = 16 loads in flight per lane
-        if (nrows > 4)
-          hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS);
-        else
-          hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS);
-        break;
-    }
+  }
+  switch (plan.variant) {
+    case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+    case 6: hipLaunchKernelGGL((k_qtw_valu<SCALE, 16, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+    case 8: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+    case 9: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;
+    default:  // measured best on MI355X (profiles/r01): 8 rows x 2 positions = 16 loads in flight per lane
+      if (nrows > 4)
+        hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS);
+      else
+        hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS);
+      break;
   }
 #undef LZ_QTW_ARGS
 }
 
 void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s) {
-  if (r)
-    launch_qtw_t<true>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
+                double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s) {
+  if (mode == 2)
+    launch_qtw_t<2>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
+  else if (mode == 1)
+    launch_qtw_t<1>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
   else
-    launch_qtw_t<false>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
+    launch_qtw_t<0>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
 }
 
 // ------------------------------------------------------------------ re-orthogonalisation pass 2
@@ -646,18 +643,28 @@ void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const dou
 // order of np.sum(c[:, None] * V, axis=0) (Lanczos.py:249), products and sums
 // rounded separately.  One double2 column position per lane; the row loop is
 // unrolled so 8 independent 16-byte loads are in flight per lane.
+template <bool FUSED>
 __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t ldv, int64_t n2, int nrows, int j,
-                                                const double* __restrict__ c) {
+                                                const double* __restrict__ c, const double* __restrict__ r,
+                                                const double* __restrict__ beta) {
   const int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x;
   if (i >= n2) return;
   const double2* col = reinterpret_cast<const double2*>(V) + i;
   const int64_t ld2 = ldv >> 1;
+  double2* out = reinterpret_cast<double2*>(V) + (int64_t)j * ld2 + i;
+  double2 w;
+  if (FUSED) {  // fused-norm mode: V[j] has not been formed yet, w = r / beta
+    const double b = beta[0];
+    w = reinterpret_cast<const double2*>(r)[i];
+    w.x = w.x / b;
+    w.y = w.y / b;
+  }
   double tx = 0.0, ty = 0.0;
   int k = 0;
   for (; k + 8 <= nrows; k += 8) {
     double2 q[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) q[u] = col[(int64_t)(k + u) * ld2];
+    for (int u = 0; u < 8; ++u) q[u] = (FUSED && k + u == j) ? w : col[(int64_t)(k + u) * ld2];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const double ck = c[k + u];
@@ -666,20 +673,39 @@ __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t
     }
   }
   for (; k < nrows; ++k) {
-    const double2 q = col[(int64_t)k * ld2];
+    const double2 q = (FUSED && k == j) ? w : col[(int64_t)k * ld2];
     const double ck = c[k];
     tx = tx + ck * q.x;
     ty = ty + ck * q.y;
   }
-  double2* out = reinterpret_cast<double2*>(V) + (int64_t)j * ld2 + i;
-  const double2 v = *out;
+  const double2 v = FUSED ? w : *out;
   *out = make_double2(2.0 * v.x - tx, 2.0 * v.y - ty);
 }
 
-void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, hipStream_t s) {
+void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
+                   const double* beta, hipStream_t s) {
   const int64_t n2 = len >> 1;
   const int grid = (int)((n2 + kTPB - 1) / kTPB);
-  hipLaunchKernelGGL(k_update, dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c);
+  if (r_fused)
+    hipLaunchKernelGGL(k_update<true>, dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+  else
+    hipLaunchKernelGGL(k_update<false>, dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+}
+
+// fused-norm mode: c holds the all-reduced [V_0.r, ..., V_{j-1}.r, r.r]; turn it into the coefficients of
+// w = r / beta:  beta = sqrt(r.r), c_i /= beta, c_j = (r.r) / beta^2
+__global__ void k_fused_prepare(double* __restrict__ c, int j, double* __restrict__ beta_slot) {
+  const double rr = c[j];
+  const double b = sqrt(rr);
+  for (int i = threadIdx.x; i < j; i += blockDim.x) c[i] = c[i] / b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    c[j] = rr / (b * b);
+    beta_slot[0] = b;
+  }
+}
+void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_fused_prepare, dim3(1), dim3(kTPB), 0, s, c, j, beta_slot);
 }
 
 // ------------------------------------------------------------------ three-term recurrence + ||r||^2
@@ -791,11 +817,111 @@ __global__ __launch_bounds__(kTPB) void k_ritz_gemm(const double* __restrict__ V
     }
 }
 
+// v2: one wave owns 32 rows (m) x NT*16 columns (all of them when n <= 256), so V is streamed from
+// HBM exactly once per column group; S (L2 resident) is re-read by every wave.  Operands are
+// prefetched in registers: B one k-step ahead, A (the HBM stream) four k-steps ahead.
+template <int NT>
+__global__ __launch_bounds__(kTPB) void k_ritz_gemm2(const double* __restrict__ V, int64_t ldv, int64_t rows, int n,
+                                                    const double* __restrict__ S, int npad, double* __restrict__ Y,
+                                                    int64_t ldy) {
+  constexpr int PA = 4;  // A prefetch distance (k-steps)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int64_t m0 = ((int64_t)blockIdx.x * (kTPB / 64) + w) * 32;
+  if (m0 >= rows) return;  // wave-uniform
+  const int ct0 = blockIdx.y * NT;
+  const int CT = npad / 16;
+  const int kpad = (n + 3) & ~3;
+  const int nsteps = kpad / 4;
+  int64_t ma = m0 + lr, mb = m0 + 16 + lr;
+  if (ma >= rows) ma = rows - 1;
+  if (mb >= rows) mb = rows - 1;
+  int colb[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) colb[b] = 16 * (ct0 + b < CT ? ct0 + b : CT - 1) + lr;
+  double4_t acc[2][NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    acc[0][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    acc[1][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  }
+  auto vrow = [&](int step) {
+    int kr = 4 * step + lk;
+    if (kr >= n) kr = n - 1;  // matching S row is zero
+    return V + (int64_t)kr * ldv;
+  };
+  double ra[PA][2];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int st = p < nsteps ? p : nsteps - 1;
+    const double* vr = vrow(st);
+    ra[p][0] = vr[ma];
+    ra[p][1] = vr[mb];
+  }
+  double bcur[NT];
+  {
+    const double* sr = S + (int64_t)lk * npad;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bcur[b] = sr[colb[b]];
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += PA) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int st = s0 + p;
+      if (st < nsteps) {
+        const double a0 = ra[p][0], a1 = ra[p][1];
+        {  // refill this ring slot with step st + PA
+          const int nx = st + PA < nsteps ? st + PA : nsteps - 1;
+          const double* vr = vrow(nx);
+          ra[p][0] = vr[ma];
+          ra[p][1] = vr[mb];
+        }
+        double bnxt[NT];
+        {
+          const int nx = st + 1 < nsteps ? st + 1 : st;
+          const double* sr = S + (int64_t)(4 * nx + lk) * npad;
+#pragma unroll
+          for (int b = 0; b < NT; ++b) bnxt[b] = sr[colb[b]];
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          acc[0][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bcur[b], acc[0][b], 0, 0, 0);
+          acc[1][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bcur[b], acc[1][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bcur[b] = bnxt[b];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      if (ct0 + b >= CT) continue;
+      const int col = 16 * (ct0 + b) + lr;
+      if (col >= n) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t m = m0 + 16 * a + lk + 4 * g;
+        if (m < rows) Y[m * ldy + col] = acc[a][b][g];
+      }
+    }
+}
+
 void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
                       int64_t ldy, hipStream_t s) {
-  const int64_t mt = 16 * kRitzMT * (kTPB / 64);  // 128 rows per block
-  dim3 grid((unsigned)((rows + mt - 1) / mt), (unsigned)((npad / 16 + kRitzNT - 1) / kRitzNT));
-  hipLaunchKernelGGL(k_ritz_gemm, grid, dim3(kTPB), 0, s, V, ldv, rows, n, Spad, npad, Y, ldy);
+  const int CT = npad / 16;
+  const int ngroups = (CT + 15) / 16;
+  const int NT = (CT + ngroups - 1) / ngroups;
+  dim3 grid((unsigned)((rows + 127) / 128), (unsigned)ngroups);
+#define LZ_RITZ(nt) \
+  case nt: hipLaunchKernelGGL((k_ritz_gemm2<nt>), grid, dim3(kTPB), 0, s, V, ldv, rows, n, Spad, npad, Y, ldy); break;
+  switch (NT) {
+    LZ_RITZ(1) LZ_RITZ(2) LZ_RITZ(3) LZ_RITZ(4) LZ_RITZ(5) LZ_RITZ(6) LZ_RITZ(7) LZ_RITZ(8)
+    LZ_RITZ(9) LZ_RITZ(10) LZ_RITZ(11) LZ_RITZ(12) LZ_RITZ(13) LZ_RITZ(14) LZ_RITZ(15) LZ_RITZ(16)
+    default: break;
+  }
+#undef LZ_RITZ
 }
 
 }  // namespace lz

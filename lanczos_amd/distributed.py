@@ -107,7 +107,7 @@ class DistributedLanczos:
     / ``H_eigvecs_local`` hold this rank's rows.
     """
 
-    def __init__(self, local, M, boot=None, device_id=0, backend="rccl", mode="auto", options=0):
+    def __init__(self, local, M, boot=None, device_id=0, backend="rccl", mode="auto", options=0, fused_norm=True):
         self.boot = boot or Bootstrap()
         self.M = int(M)
         self.rank, self.world = self.boot.rank, self.boot.world
@@ -123,6 +123,10 @@ class DistributedLanczos:
         if self.plan.mode == "halo":
             gathered = self.boot.allgather_obj((self.plan.peers, self.plan.send_counts, self.plan.recv_counts))
             partition.check_plans(self.plan, self.rank, gathered)
+        if fused_norm and self.world > 1:
+            # one all-reduce per re-orthogonalisation carries [Q^T r, r.r] (saves a latency-bound collective per iteration)
+            options |= _capi.FLAG_FUSED_NORM
+        self.options = options
         self.h = _capi.Handle(device_id)
         self.h.set_options(options)
         self.backend = backend

@@ -33,7 +33,7 @@ WORKER = textwrap.dedent('''
     for name, build, M, mode, n in cases:
         b = partition.row_bounds(M, boot.world)
         lo, hi = b[boot.rank], b[boot.rank + 1]
-        s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode)
+        s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode, fused_norm=(name != "lap3d"))
         a, bta = s.execute_Lanczos(n)
         theta = s.get_H_eigs()
         V = s.V_local

@@ -146,3 +146,27 @@ def test_error_surface_on_device():
     s.execute_Lanczos(2)
     d, _ = load_golden("lap2d_8x8_n2")
     assert ritz_close(s.H_eigvals, d["H_eigvals"])
+
+
+@pytest.mark.parametrize("flags", [2, 16, 32, 8])
+def test_kernel_variants_agree(flags):
+    """MFMA Q^T w (2), fused-norm (16), generic CSR-stream (32) and scalar SpMV (8) arms against the default path."""
+    from lanczos_amd import _capi
+
+    A = synthetic.laplacian_2d_5pt(300, 200)
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    out = []
+    for f in (0, flags):
+        h = _capi.Handle(0)
+        h.set_options(f)
+        h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+        a, b = h.run(60, v0)
+        V = h.get_basis()
+        out.append((a, b, V))
+        h.close()
+    (a0, b0, V0), (a1, b1, V1) = out
+    assert np.abs(a1 - a0).max() < 1e-11 and np.abs(b1 - b0).max() < 1e-11
+    assert np.abs(V1[:10] - V0[:10]).max() < 1e-10
+    assert np.abs(V1 @ V1.T - np.eye(60)).max() < 1e-12
