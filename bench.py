@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--options", type=int, default=0, help="extra lz_flags (A/B arms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents (roofline fields become null)")
+    ap.add_argument("--profile-stride", type=int, default=8, help="bracket only every n-th iteration with hipEvents (each event costs ~3 us)")
+    ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed runtime pre-warm (used under rocprofv3 --pmc)")
     ap.add_argument("--backend", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--mode", default="auto", choices=["auto", "halo", "allgather"])
     args = ap.parse_args()
@@ -168,6 +170,18 @@ def main():
         solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend="host", mode=args.mode,
                                                 options=args.options | prof)
     v0 = solver.start_vector(99)[lo:hi].copy()
+    # Per-kernel events cost ~3 us each (1.8 % of the headline run when every launch is bracketed): sample every
+    # stride-th iteration (centred, so the sampled launches have the same mean basis size as all launches).
+    stride = max(1, args.profile_stride)
+    solver.h.set_tuning(7, stride)
+
+    # Setup (not a step): let the runtime finish its one-time work (code-object load of every kernel variant, clock
+    # ramp) on a short solve; a ~60 ms one-off stall was observed ~0.1 s after the first launches of a process.
+    t_pre = time.perf_counter()
+    while not args.no_prewarm and time.perf_counter() - t_pre < 0.6:
+        solver.execute_Lanczos(min(k, 12), v0_normalized_local=v0)
+    if world > 1:
+        boot.barrier()
 
     for _ in range(args.warmup):
         solver.execute_Lanczos(k, v0_normalized_local=v0)
@@ -195,21 +209,22 @@ def main():
         per_class = {}
         for name in ("spmv", "qtw", "update", "three_term"):
             c = tm[name]
-            if c["launches"] == 0 or c["ms"] <= 0:
+            if c["timed_launches"] == 0 or c["ms"] <= 0:
                 continue
-            gbs = c["bytes"] / (c["ms"] * 1e-3) / 1e9
+            gbs = c["timed_bytes"] / (c["ms"] * 1e-3) / 1e9
             per_class[name] = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_us": round(1e3 * c["ms"] / c["launches"], 2), "launches": c["launches"],
-                "bytes_per_launch": c["bytes"] / c["launches"], "share_of_device_time": round(c["ms"] / max(tm["total_ms"], 1e-9), 4),
+                "traffic": None, "avg_us": round(1e3 * c["ms"] / c["timed_launches"], 2), "launches": c["launches"],
+                "timed_launches": c["timed_launches"], "bytes_per_launch": c["timed_bytes"] / c["timed_launches"],
+                "share_of_device_time": round(c["ms"] * c["launches"] / c["timed_launches"] / max(tm["total_ms"], 1e-9), 4),
             }
         dominant = max(per_class, key=lambda n: tm[n]["ms"]) if per_class else None
         whole_bytes = sum(tm[n]["bytes"] for n in ("spmv", "qtw", "update", "three_term"))
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.isfile(traffic_file):  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
             try:
-                tr = json.load(open(traffic_file)).get(args.workload, {})
-                for name, v in tr.items():
+                measured = json.load(open(traffic_file)).get(args.workload, {})
+                for name, v in measured.items():
                     if name in per_class:
                         per_class[name]["traffic"] = v
             except Exception:
@@ -229,6 +244,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "matrix": kind, "dims": list(dims), "M": M, "k": k, "reorth": "full (reference CGS, 2 passes)",
                        "partition": f"row-block x{world}", "exchange": solver.plan.mode, "comm": comm_used,
+                       "fused_norm_allreduce": bool(solver.options & _capi.FLAG_FUSED_NORM), "profile_stride": stride,
                        "step": "one full k-iteration Lanczos solve"},
             "roofline": dict(per_class[dominant], kernel=dominant) if dominant else None,
             "roofline_all": per_class,

@@ -65,11 +65,14 @@ enum lz_kernel_class {
 };
 
 typedef struct lz_timings {
-  double ms[LZ_K_COUNT];        /* summed device time per class (hipEvent)        */
-  double bytes[LZ_K_COUNT];     /* summed ALGORITHMIC bytes per class */
-  double flops[LZ_K_COUNT];     /* summed algorithmic flops per class             */
-  int64_t launches[LZ_K_COUNT]; /* number of launches per class                   */
-  double total_ms;              /* device time of the whole lz_run (events)       */
+  double ms[LZ_K_COUNT];             /* summed device time of the TIMED launches per class (hipEvent)   */
+  double timed_bytes[LZ_K_COUNT];    /* ALGORITHMIC bytes of the timed launches    */
+  int64_t timed_launches[LZ_K_COUNT];/* launches bracketed by events (all of them, or 1 iteration in     */
+                                     /* `stride` when lz_set_tuning(h, 7, stride) samples the profiling) */
+  double bytes[LZ_K_COUNT];          /* algorithmic bytes of ALL launches per class                      */
+  double flops[LZ_K_COUNT];          /* algorithmic flops of all launches per class                      */
+  int64_t launches[LZ_K_COUNT];      /* number of launches per class                                     */
+  double total_ms;                   /* device time of the whole lz_run(s) (events)                      */
 } lz_timings;
 
 /* ---- library / device ------------------------------------------------- */
@@ -80,9 +83,10 @@ int lz_create(lz_handle* out, int device_id);
 int lz_destroy(lz_handle h);
 const char* lz_last_error(lz_handle h); /* h may be NULL: last error of lz_create */
 int lz_set_options(lz_handle h, int flags);
-/* A/B tuning knobs for kernel experiments (index 0: Q^T w slice length per block, 1: Q^T w
- * kernel variant, 2: SpMV rows per block, 3: SpMV variant); takes effect at the next
- * lz_set_csr / lz_basis_alloc.  Results never depend on them beyond summation order. */
+/* Tuning knobs (index 0: Q^T w slice length per block, 1: Q^T w kernel variant, 2/4: CSR-stream rows /
+ * entries per block, 3: SpMV timing-ablation arm, 5: fixed-K rows per block, 6: issue the collectives
+ * even when world == 1, 7: profile only every value-th iteration of lz_run); they take effect at the next
+ * lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order. */
 int lz_set_tuning(lz_handle h, int index, int value);
 int lz_device_synchronize(lz_handle h);
 int lz_device_name(lz_handle h, char* buf, size_t buflen);

@@ -32,6 +32,8 @@ K_COUNT = len(KERNEL_CLASSES)
 class LzTimings(C.Structure):
     _fields_ = [
         ("ms", C.c_double * K_COUNT),
+        ("timed_bytes", C.c_double * K_COUNT),
+        ("timed_launches", C.c_int64 * K_COUNT),
         ("bytes", C.c_double * K_COUNT),
         ("flops", C.c_double * K_COUNT),
         ("launches", C.c_int64 * K_COUNT),
@@ -308,7 +310,8 @@ class Handle:
         self.check(self.lib.lz_get_timings(self._h, C.byref(t)))
         out = {"total_ms": t.total_ms}
         for i, k in enumerate(KERNEL_CLASSES):
-            out[k] = {"ms": t.ms[i], "bytes": t.bytes[i], "flops": t.flops[i], "launches": int(t.launches[i])}
+            out[k] = {"ms": t.ms[i], "timed_bytes": t.timed_bytes[i], "timed_launches": int(t.timed_launches[i]),
+                      "bytes": t.bytes[i], "flops": t.flops[i], "launches": int(t.launches[i])}
         return out
 
     # -- single steps

@@ -124,6 +124,7 @@ struct lz_context {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
   hipEvent_t run_a = nullptr, run_b = nullptr;
   bool run_timed = false;
+  bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
   lz_timings acc;
 };
 
@@ -191,8 +192,10 @@ struct Scope {
     h->acc.bytes[cls] += bytes;
     h->acc.flops[cls] += flops;
     h->acc.launches[cls] += 1;
-    on = (h->flags & LZ_FLAG_PROFILE) != 0;
+    on = (h->flags & LZ_FLAG_PROFILE) != 0 && h->prof_iter;
     if (on) {
+      h->acc.timed_bytes[cls] += bytes;
+      h->acc.timed_launches[cls] += 1;
       if (!h->free_events.empty()) {
         a = h->free_events.back().first;
         b = h->free_events.back().second;
@@ -862,13 +865,16 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_TRY(step_spmv(h, 0));
   const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0;
   LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
+  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
   for (int j = 0; j < n; ++j) {
+    h->prof_iter = (j % pstride) == pstride / 2;  // centred sample: same mean j as the full run
     const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
     LZ_TRY(step_reorth(h, j, j + 1, true, bidx));
     LZ_TRY(step_spmv(h, j));
     // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
     LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, !fused));
   }
+  h->prof_iter = true;
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
   const double t3 = now();
   h->run_timed = true;

@@ -400,7 +400,10 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
   const double self = qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt2, sw);
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i0 = 0; i0 < nrows; i0 += R) {
+  // Tiles are walked from the newest rows down to row 0: pass 2 (k_update) must add rows in ascending
+  // order, so the last ~256 MB this pass reads (rows 0, 1, ...) are the first pass 2 needs - they are still in
+  // the Infinity Cache.
+  for (int i0 = ((nrows - 1) / R) * R; i0 >= 0; i0 -= R) {
     const double2* row[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {

@@ -75,6 +75,7 @@ def main():
             for k in ("spmv", "qtw", "update", "three_term", "final"):
                 if t[k]["launches"]:
                     d = res[name].setdefault(k, {"us": [], "bytes": t[k]["bytes"] / t[k]["launches"]})
+                    assert t[k]["timed_launches"] == t[k]["launches"]
                     d["us"].append(1e3 * t[k]["ms"] / t[k]["launches"])
     for name in res:
         for k, d in res[name].items():
