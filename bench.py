@@ -200,9 +200,14 @@ def main():
     tm = solver.timings()
 
     # sanity of the result (cheap): Ritz values finite, extreme one inside the Gershgorin bound
-    theta = solver.get_H_eigs(fetch=False)
+    try:
+        theta = solver.get_H_eigs(fetch=False)
+        tr = solver.timings()["ritz"]
+    except _capi.LanczosHipError as e:  # e.g. no room for a second M x k array next to the basis
+        print(f"[rank {rank}] Ritz back-transform skipped: {e}", file=sys.stderr)
+        theta = np.linalg.eigvalsh(solver.H_eff)
+        tr = {"ms": 0.0, "flops": 0.0}
     assert np.isfinite(theta).all()
-    tr = solver.timings()["ritz"]
 
     if rank == 0:
         iters = args.steps * k

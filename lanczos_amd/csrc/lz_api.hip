@@ -71,7 +71,7 @@ struct lz_context {
   std::string err;
   std::string name;
   int flags = 0;
-  int tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // A/B knobs, see lz_set_tuning
+  int tune[16] = {0};  // A/B knobs, see lz_set_tuning
 
   // partition
   int64_t Mg = 0, row0 = 0, rows = 0, ncols_ext = 0;
@@ -370,7 +370,7 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx) {
   }
   {
     Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + (fused ? 16.0 : 16.0) * M, 2.0 * nrows * M);
-    launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->stream);
+    launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream);
     LZ_TRY(check_launch(h, "update"));
   }
   return LZ_OK;
@@ -508,7 +508,7 @@ int lz_set_options(lz_handle h, int flags) {
 }
 
 int lz_set_tuning(lz_handle h, int index, int value) {
-  if (!h || index < 0 || index >= 8) return LZ_ERR_ARG;
+  if (!h || index < 0 || index >= 16) return LZ_ERR_ARG;
   h->tune[index] = value;
   return LZ_OK;
 }

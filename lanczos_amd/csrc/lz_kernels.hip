@@ -44,6 +44,27 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / kNumXCD;
 }
 
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+typedef int i2v_t __attribute__((ext_vector_type(2)));
+// Streamed-once data (basis rows, matrix entries) is loaded non-temporally so it does not push the
+// re-used data (x, w, the most recent basis rows) out of L2 / Infinity Cache.  VAR == 0: plain load.
+template <int VAR>
+__device__ __forceinline__ double2 ld_stream(const double2* p) {
+  if (VAR == 1) {
+    const d2v_t v = __builtin_nontemporal_load(reinterpret_cast<const d2v_t*>(p));
+    return make_double2(v.x, v.y);
+  }
+  return *p;
+}
+template <int VAR>
+__device__ __forceinline__ int2 ld_stream(const int2* p) {
+  if (VAR == 1) {
+    const i2v_t v = __builtin_nontemporal_load(reinterpret_cast<const i2v_t*>(p));
+    return make_int2(v.x, v.y);
+  }
+  return *p;
+}
+
 // ------------------------------------------------------------------ second-stage reductions
 constexpr int kFinalThreads = 1024;
 __global__ __launch_bounds__(kFinalThreads) void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
@@ -143,8 +164,8 @@ __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict_
         int p = pb + kTPB * i;
         if (p >= npair) p = pb;  // clamped duplicate, discarded below
         const int k = kk + 2 * p;
-        a[i] = (ABL & 4) ? make_double2(1.0, 2.0) : *reinterpret_cast<const double2*>(vals + k);
-        c[i] = (ABL & 2) ? make_int2(k / (K > 0 ? K : 1), (k + 1) / (K > 0 ? K : 1)) : *reinterpret_cast<const int2*>(colidx + k);
+        a[i] = (ABL & 4) ? make_double2(1.0, 2.0) : ld_stream<1>(reinterpret_cast<const double2*>(vals + k));
+        c[i] = (ABL & 2) ? make_int2(k / (K > 0 ? K : 1), (k + 1) / (K > 0 ? K : 1)) : ld_stream<1>(reinterpret_cast<const int2*>(colidx + k));
         if (ABL & 1) c[i] = make_int2(c[i].x & 1023, c[i].y & 1023);
       }
       double2 xv[NB];
@@ -205,7 +226,7 @@ __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict_
 // (NP of each), then all 2*NP x gathers, then stages the products in LDS; after one barrier each
 // lane adds up RB/256 rows from LDS in CSR order.  Three dependent memory round trips per block
 // instead of 2*NP, and an LDS tile of exactly RB*K products.  rowptr is never read.
-template <int K, int RB>
+template <int K, int RB, int NT = 1>
 __global__ __launch_bounds__(kTPB) void k_spmv_fixed(const int32_t* __restrict__ colidx, const double* __restrict__ vals,
                                                     const double* __restrict__ x, const double* __restrict__ xown,
                                                     double* __restrict__ y, int rows, double* __restrict__ part) {
@@ -228,8 +249,8 @@ __global__ __launch_bounds__(kTPB) void k_spmv_fixed(const int32_t* __restrict__
   for (int i = 0; i < NP; ++i) {
     int p = threadIdx.x + kTPB * i;
     if (2 * p >= kcnt) p = 0;              // tail block: valid address, product discarded below
-    a[i] = v2[p];
-    c[i] = c2[p];
+    a[i] = ld_stream<NT>(v2 + p);
+    c[i] = ld_stream<NT>(c2 + p);
   }
   double2 xv[NP];
 #pragma unroll
@@ -268,7 +289,10 @@ static int launch_spmv_fixed(const CsrDev& A, const double* x, double* y, const 
     return grid;
   }
   const int grid = (int)((A.rows + 511) / 512);
-  hipLaunchKernelGGL((k_spmv_fixed<K, 512>), dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, x, x_own, y, (int)A.rows, part);
+  if (rb == 513)  // A/B arm: plain (cached) loads of the matrix stream
+    hipLaunchKernelGGL((k_spmv_fixed<K, 512, 0>), dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, x, x_own, y, (int)A.rows, part);
+  else
+    hipLaunchKernelGGL((k_spmv_fixed<K, 512>), dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, x, x_own, y, (int)A.rows, part);
   return grid;
 }
 
@@ -388,7 +412,7 @@ __device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ld
   return self;
 }
 
-template <int SCALE, int R, int U>
+template <int SCALE, int R, int U, int NT = 1>
 __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                   const double* __restrict__ r, const double* __restrict__ nrm2,
                                                   double* __restrict__ beta_slot, int64_t L, int G,
@@ -420,7 +444,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
       const double2 wv = sw[t];
 #pragma unroll
       for (int q = 0; q < R; ++q) {
-        const double2 v = row[q][t];
+        const double2 v = ld_stream<NT>(row[q] + t);
         acc[q] = fma(v.x, wv.x, acc[q]);
         acc[q] = fma(v.y, wv.y, acc[q]);
       }
@@ -619,6 +643,7 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
   switch (plan.variant) {
     case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
     case 6: hipLaunchKernelGGL((k_qtw_valu<SCALE, 16, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+    case 7: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 0>), grid, block, lds, s, LZ_QTW_ARGS); break;  // plain (cached) loads
     case 8: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
     case 9: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;
     default:  // measured best on MI355X (profiles/r01): 8 rows x 2 positions = 16 loads in flight per lane
@@ -646,7 +671,7 @@ void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const dou
 // order of np.sum(c[:, None] * V, axis=0) (Lanczos.py:249), products and sums
 // rounded separately.  One double2 column position per lane; the row loop is
 // unrolled so 8 independent 16-byte loads are in flight per lane.
-template <bool FUSED>
+template <bool FUSED, int VAR = 0, int UN = 8>
 __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t ldv, int64_t n2, int nrows, int j,
                                                 const double* __restrict__ c, const double* __restrict__ r,
                                                 const double* __restrict__ beta) {
@@ -664,12 +689,12 @@ __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t
   }
   double tx = 0.0, ty = 0.0;
   int k = 0;
-  for (; k + 8 <= nrows; k += 8) {
-    double2 q[8];
+  for (; k + UN <= nrows; k += UN) {
+    double2 q[UN];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) q[u] = (FUSED && k + u == j) ? w : col[(int64_t)(k + u) * ld2];
+    for (int u = 0; u < UN; ++u) q[u] = (FUSED && k + u == j) ? w : ld_stream<VAR>(col + (int64_t)(k + u) * ld2);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const double ck = c[k + u];
       tx = tx + ck * q[u].x;
       ty = ty + ck * q[u].y;
@@ -686,13 +711,25 @@ __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
-                   const double* beta, hipStream_t s) {
+                   const double* beta, int variant, hipStream_t s) {
   const int64_t n2 = len >> 1;
   const int grid = (int)((n2 + kTPB - 1) / kTPB);
+  if (!r_fused && variant == 1) {  // A/B arm: plain (cached) loads
+    hipLaunchKernelGGL((k_update<false, 0, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+    return;
+  }
+  if (!r_fused && variant == 2) {
+    hipLaunchKernelGGL((k_update<false, 0, 16>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+    return;
+  }
+  if (!r_fused && variant == 3) {
+    hipLaunchKernelGGL((k_update<false, 1, 16>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+    return;
+  }
   if (r_fused)
-    hipLaunchKernelGGL(k_update<true>, dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+    hipLaunchKernelGGL((k_update<true, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
   else
-    hipLaunchKernelGGL(k_update<false>, dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+    hipLaunchKernelGGL((k_update<false, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
 }
 
 // fused-norm mode: c holds the all-reduced [V_0.r, ..., V_{j-1}.r, r.r]; turn it into the coefficients of
@@ -725,11 +762,11 @@ __global__ __launch_bounds__(kTPB) void k_three_term(double* __restrict__ r, con
   double acc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kTPB) {
     double2 x = r2[i];
-    const double2 v = v2[i];
+    const double2 v = ld_stream<1>(v2 + i);
     x.x = x.x - v.x * a;
     x.y = x.y - v.y * a;
     if (vjm1) {
-      const double2 m = m2[i];
+      const double2 m = ld_stream<1>(m2 + i);
       x.x = x.x - m.x * b;
       x.y = x.y - m.y * b;
     }

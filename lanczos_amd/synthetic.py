@@ -71,9 +71,8 @@ def _stencil(dims, rows=None):
         cols[:, c + 1] = r + np.where(coord == 0, (d - 1) * stride, -stride)
         c += 2
         stride *= d
-    order = np.argsort(cols, axis=1, kind="stable")
-    cols = np.take_along_axis(cols, order, axis=1)
-    vals = np.where(order == 0, float(2 * len(dims)), -1.0)
+    cols.sort(axis=1)  # in place; the diagonal is wherever the row's own index lands
+    vals = np.where(cols == r[:, None].astype(np.int32), float(2 * len(dims)), -1.0)
     rowptr = (np.arange(hi - lo + 1, dtype=np.int64) * k).astype(np.int32)
     return CSR(rowptr, np.ascontiguousarray(cols).reshape(-1), np.ascontiguousarray(vals).reshape(-1), (hi - lo, M))
 
