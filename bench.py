@@ -9,8 +9,9 @@ updates, k full re-orthogonalisations against the growing basis) on the
 device-resident matrix; value = K * k / time.  N > 1 (launched with
 torch.distributed.run) row-partitions the SAME problem over N GPUs (strong
 scaling) with RCCL all-reduces and neighbour halo exchange issued by
-liblanczos_hip.so; torch.distributed (gloo) is used only for rendezvous,
-barriers and the max-over-ranks of the timing.
+liblanczos_hip.so; the control plane is used only for rendezvous,
+barriers and the max-over-ranks of the timing (by default a torch-free Unix-socket
+bootstrap that reads the launcher's RANK / WORLD_SIZE / MASTER_PORT).
 
 Per-kernel numbers come from hipEvents recorded around every launch on the
 library's compute stream inside the timed region (LZ_FLAG_PROFILE);
@@ -121,6 +122,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents (roofline fields become null)")
     ap.add_argument("--profile-stride", type=int, default=8, help="bracket only every n-th iteration with hipEvents (each event costs ~3 us)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed runtime pre-warm (used under rocprofv3 --pmc)")
+    ap.add_argument("--device", type=int, default=-1, help="GPU index (default: LOCAL_RANK); lets several ranks share one GPU with --backend host")
+    ap.add_argument("--bootstrap", default="socket", choices=["socket", "torch"])
     ap.add_argument("--backend", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--mode", default="auto", choices=["auto", "halo", "allgather"])
     args = ap.parse_args()
@@ -139,10 +142,16 @@ def main():
 
     lanczos_amd.load_library()
     if world > 1:
-        boot = distributed.TorchBootstrap()
+        # Rendezvous, barriers and the max-over-ranks go over a pure-Python Unix-socket bootstrap keyed by the
+        # launcher's MASTER_PORT: importing torch here would map its bundled ROCm 7.0 runtime + RCCL next to the
+        # system ROCm 7.2 libraries the HIP library uses (observed: double free at exit).  --bootstrap torch
+        # uses torch.distributed/gloo instead.
+        boot = distributed.TorchBootstrap() if args.bootstrap == "torch" else distributed.SocketBootstrap()
     else:
         boot = distributed.Bootstrap()
 
+    if args.device >= 0:
+        local_rank = args.device
     kind, dims, k = WORKLOADS[args.workload]
     if args.k:
         k = args.k
@@ -178,10 +187,11 @@ def main():
     # Setup (not a step): let the runtime finish its one-time work (code-object load of every kernel variant, clock
     # ramp) on a short solve; a ~60 ms one-off stall was observed ~0.1 s after the first launches of a process.
     t_pre = time.perf_counter()
-    while not args.no_prewarm and time.perf_counter() - t_pre < 0.6:
+    while not args.no_prewarm:
         solver.execute_Lanczos(min(k, 12), v0_normalized_local=v0)
-    if world > 1:
-        boot.barrier()
+        # every rank must run the same number of solves (they contain collectives): agree on when to stop
+        if all(boot.allgather_obj(time.perf_counter() - t_pre >= 0.6)):
+            break
 
     for _ in range(args.warmup):
         solver.execute_Lanczos(k, v0_normalized_local=v0)

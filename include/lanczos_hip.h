@@ -99,6 +99,7 @@ int64_t lz_padded_rows(int64_t rows);
  * partition below is this build's own design: rows are split in contiguous
  * blocks, alpha/beta/c are summed with an all-reduce, and the SpMV input is
  * exchanged either as neighbour halos (send/recv lists) or as an all-gather. */
+int lz_comm_load(void);                           /* dlopen RCCL now (optional; lz_comm_* do it lazily) */
 int lz_comm_unique_id(void* id, size_t id_bytes); /* >= 128 bytes; rank 0 calls, host broadcasts */
 int lz_comm_init_rccl(lz_handle h, int world, int rank, const void* id, size_t id_bytes);
 /* host-staged collectives (tests / fallback): the library copies device data to

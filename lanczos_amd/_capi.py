@@ -64,6 +64,7 @@ SIGNATURES = {
     "lz_device_synchronize": (C.c_int, [_P]),
     "lz_device_name": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "lz_padded_rows": (C.c_int64, [C.c_int64]),
+    "lz_comm_load": (C.c_int, []),
     "lz_comm_unique_id": (C.c_int, [_P, C.c_size_t]),
     "lz_comm_init_rccl": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t]),
     "lz_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, HOST_ALLGATHER_FN, _P]),
@@ -118,6 +119,14 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def preload_rccl():
+    """dlopen the system RCCL now (before any other library maps a different copy of librccl.so.1)."""
+    lib = load_library()
+    st = lib.lz_comm_load()
+    if st != LZ_OK:
+        raise LanczosHipError(st, lib.lz_last_error(None).decode())
 
 
 def dptr(a):

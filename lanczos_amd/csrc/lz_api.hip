@@ -529,6 +529,12 @@ int lz_device_name(lz_handle h, char* buf, size_t buflen) {
 int64_t lz_padded_rows(int64_t rows) { return round_up(rows, kPadDoubles); }
 
 // ---- communication -------------------------------------------------------
+int lz_comm_load(void) {
+  const char* e = load_rccl();
+  if (e) return fail(nullptr, LZ_ERR_COMM, e);
+  return LZ_OK;
+}
+
 int lz_comm_unique_id(void* id, size_t id_bytes) {
   if (!id || id_bytes < sizeof(ncclUniqueId)) return fail(nullptr, LZ_ERR_ARG, "id buffer must hold at least 128 bytes");
   const char* e = load_rccl();

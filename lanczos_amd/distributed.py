@@ -47,6 +47,139 @@ class Bootstrap:
         return a
 
 
+class SocketBootstrap(Bootstrap):
+    """Pure-Python single-node rendezvous over a Unix-domain socket (star topology, rank 0 is the hub).
+
+    Needs only RANK / WORLD_SIZE (as exported by ``torch.distributed.run`` or any other launcher) and a
+    key shared by the ranks of one launch - by default ``MASTER_PORT`` plus the launcher's pid - so no
+    TCP port is taken and no PyTorch (with its bundled copies of the ROCm runtime and RCCL) is mapped
+    into the process next to the system ROCm libraries liblanczos_hip.so is built against.
+    Control plane only: unique-id broadcast, plan checks, barriers, the max-over-ranks of timings
+    (and, for ``backend="host"``, the host-staged test collectives).
+    """
+
+    def __init__(self, rank=None, world=None, key=None, timeout=600.0):
+        import atexit
+        import socket
+        import time
+
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        if key is None:
+            key = os.environ.get("LZ_RDZV_KEY") or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        self.path = os.path.join(os.environ.get("LZ_RDZV_DIR", "/tmp"), f"lz_rdzv_{key}.sock")
+        self._conns = {}
+        self._sock = None
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            try:
+                os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+            srv.bind(self.path)
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            atexit.register(self._cleanup)
+            self._srv = srv
+            while len(self._conns) < self.world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout)
+                r = self._recv(c)
+                self._conns[int(r)] = c
+        else:
+            deadline = time.time() + timeout
+            while True:
+                s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    s.connect(self.path)
+                    break
+                except (FileNotFoundError, ConnectionRefusedError):
+                    s.close()
+                    if time.time() > deadline:
+                        raise TimeoutError(f"rank {self.rank}: no rendezvous socket at {self.path}")
+                    time.sleep(0.05)
+            s.settimeout(timeout)
+            self._sock = s
+            self._send(s, self.rank)
+
+    def _cleanup(self):
+        try:
+            os.unlink(self.path)
+        except OSError:
+            pass
+
+    @staticmethod
+    def _send(sock, obj):
+        import pickle
+        import struct
+
+        data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+        sock.sendall(struct.pack("<Q", len(data)) + data)
+
+    @staticmethod
+    def _recv(sock):
+        import pickle
+        import struct
+
+        def read(n):
+            buf = bytearray()
+            while len(buf) < n:
+                chunk = sock.recv(min(n - len(buf), 1 << 20))
+                if not chunk:
+                    raise ConnectionError("rendezvous peer closed the connection")
+                buf += chunk
+            return bytes(buf)
+
+        (n,) = struct.unpack("<Q", read(8))
+        return pickle.loads(read(n))
+
+    def _hub(self, obj, combine):
+        """rank 0 collects one object per rank, ``combine(list) -> per-rank replies``; everyone gets its reply."""
+        if self.world == 1:
+            return combine([obj])[0]
+        if self.rank == 0:
+            items = [obj] + [None] * (self.world - 1)
+            for r in range(1, self.world):
+                items[r] = self._recv(self._conns[r])
+            replies = combine(items)
+            for r in range(1, self.world):
+                self._send(self._conns[r], replies[r])
+            return replies[0]
+        self._send(self._sock, obj)
+        return self._recv(self._sock)
+
+    def allgather_obj(self, obj):
+        return self._hub(obj, lambda items: [items] * len(items))
+
+    def broadcast_bytes(self, data, root=0):
+        return self.allgather_obj(data)[root]
+
+    def barrier(self):
+        self.allgather_obj(None)
+
+    def allreduce_sum(self, a):
+        def combine(items):
+            total = items[0].copy()
+            for x in items[1:]:
+                total = total + x
+            return [total] * len(items)
+
+        a[...] = self._hub(np.array(a, dtype=np.float64), combine)
+        return a
+
+    def exchange(self, peers, send_segments, recv_counts):
+        def combine(items):  # items[r] = {dst: segment}
+            return [{src: items[src][dst] for src in range(len(items)) if dst in items[src]} for dst in range(len(items))]
+
+        got = self._hub({int(p): np.ascontiguousarray(s) for p, s in zip(peers, send_segments)}, combine)
+        return [got.get(int(p), np.zeros(0)) for p in peers]
+
+    def allgather_array(self, a):
+        return np.concatenate(self.allgather_obj(np.ascontiguousarray(a)))
+
+
 class TorchBootstrap(Bootstrap):
     """torch.distributed (gloo, CPU) rendezvous from the RANK/WORLD_SIZE/MASTER_* environment."""
 

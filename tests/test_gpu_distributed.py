@@ -24,7 +24,7 @@ WORKER = textwrap.dedent('''
     lanczos_amd.load_library()                      # system ROCm runtime first, torch (gloo only) second
     from lanczos_amd import distributed, partition, synthetic
     from oracle import lanczos_ref as oracle
-    boot = distributed.TorchBootstrap()
+    boot = distributed.SocketBootstrap() if os.environ.get("LZ_BOOT") == "socket" else distributed.TorchBootstrap()
     out = {}
     cases = [("lap2d", lambda lo, hi: synthetic.laplacian_2d_5pt(96, 80, rows=(lo, hi)), 96 * 80, "auto", 40),
              ("lap3d", lambda lo, hi: synthetic.laplacian_3d_7pt(24, 20, 18, rows=(lo, hi)), 24 * 20 * 18, "halo", 30),
@@ -60,7 +60,7 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, LZ_ROOT=ROOT, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, LZ_ROOT=ROOT, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0", LZ_BOOT="socket" if world == 2 else "torch")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)

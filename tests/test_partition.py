@@ -153,3 +153,44 @@ def test_two_rank_gloo_partitioned_lanczos(tmp_path):
         for name in ("lap2d", "graph"):
             da, db, dv, _ = per_rank[name]
             assert da < 1e-11 and db < 1e-11 and dv < 1e-9, (name, per_rank[name])
+
+
+def _sock_worker(rank, world, key, q):
+    import numpy as np
+
+    from lanczos_amd import distributed
+
+    b = distributed.SocketBootstrap(rank=rank, world=world, key=key, timeout=60)
+    out = {}
+    out["gather"] = b.allgather_obj(("r", rank))
+    out["bcast"] = b.broadcast_bytes(b"uid" if rank == 0 else None)
+    out["sum"] = b.allreduce_sum(np.arange(4, dtype=np.float64) + rank).tolist()
+    peers = [p for p in range(world) if p != rank]
+    got = b.exchange(peers, [np.full(2, 10.0 * rank + p) for p in peers], [2] * len(peers))
+    out["xchg"] = [g.tolist() for g in got]
+    out["ag"] = b.allgather_array(np.full(2, float(rank))).tolist()
+    b.barrier()
+    q.put((rank, out))
+
+
+def test_socket_bootstrap_collectives():
+    import multiprocessing as mp
+    import uuid
+
+    world, key = 3, uuid.uuid4().hex[:12]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_sock_worker, args=(r, world, key, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        o = res[r]
+        assert o["gather"] == [("r", i) for i in range(world)] and o["bcast"] == b"uid"
+        assert o["sum"] == [3.0 + 3 * i for i in range(4)]
+        peers = [p for p in range(world) if p != r]
+        assert o["xchg"] == [[10.0 * p + r] * 2 for p in peers]
+        assert o["ag"] == [0.0, 0.0, 1.0, 1.0, 2.0, 2.0]
