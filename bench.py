@@ -38,6 +38,7 @@ WORKLOADS = {
     "lap3d_7pt_M1e8_k200": ("lap3d", (500, 500, 400), 200),  # configs[3] (8 GPUs)
     "lap2d_5pt_M1e7_k500": ("lap2d", (4000, 2500), 500),   # configs[4] (8 GPUs)
     "graph_M1e7_k200": ("graph", (10_000_000, 35_000_000), 200),  # configs[2]
+    "lap2d_5pt_M1.25e6_k200": ("lap2d", (4000, 313), 200),  # one rank's share of the headline at N = 8 (compute floor)
     "tiny": ("lap2d", (256, 128), 24),
 }
 

@@ -679,7 +679,8 @@ int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* se
   h->roff.assign(npeers, 0);
   int64_t ts = 0, tr = 0;
   for (int p = 0; p < npeers; ++p) {
-    if (peers[p] < 0 || peers[p] >= h->world || peers[p] == h->rank || send_counts[p] < 0 || recv_counts[p] < 0)
+    const bool self_ok = h->tune[6] != 0;  // test knob: a rank may exchange with itself (1-rank RCCL send/recv test)
+    if (peers[p] < 0 || peers[p] >= h->world || (peers[p] == h->rank && !self_ok) || send_counts[p] < 0 || recv_counts[p] < 0)
       return fail(h, LZ_ERR_ARG, "lz_set_halo: bad peer or count");
     h->soff[p] = ts;
     h->roff[p] = tr;

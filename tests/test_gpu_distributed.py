@@ -95,3 +95,38 @@ def test_rccl_single_rank_communicator():
     assert h.timings()["comm"]["launches"] >= 60
     h.close()
     h0.close()
+
+
+def test_rccl_self_send_recv_halo():
+    """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the compute stream, with a 1-rank communicator
+    exchanging with itself: the vertical wrap-around neighbours of a periodic 2-D stencil are routed through the
+    ghost tail (packed by k_gather, sent and received by RCCL) instead of being read in place.  Must equal the
+    plain run bit for bit."""
+    nx, ny = 64, 48
+    A = synthetic.laplacian_2d_5pt(nx, ny)
+    M = A.shape[0]
+    v0 = np.random.RandomState(99).uniform(-1, 1, M)
+    v0 /= np.linalg.norm(v0)
+    h0 = _capi.Handle(0)
+    h0.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    a0, b0 = h0.run(25, v0)
+    V0 = h0.get_basis()
+
+    rows_pad = (M + 31) // 32 * 32
+    row_of = np.repeat(np.arange(M), np.diff(A.rowptr))
+    wrap = np.abs(A.colidx.astype(np.int64) - row_of) > nx  # entries that cross the periodic seam in y
+    ghost_cols = np.unique(A.colidx[wrap])
+    col = A.colidx.astype(np.int64).copy()
+    col[wrap] = rows_pad + np.searchsorted(ghost_cols, A.colidx[wrap])
+    h = _capi.Handle(0)
+    h.comm_init_rccl(1, 0, h.unique_id())
+    h.set_tuning(6, 1)
+    h.set_csr(M, 0, A.rowptr, col.astype(np.int32), A.vals, ncols_ext=rows_pad + len(ghost_cols))
+    h.set_halo([0], [len(ghost_cols)], ghost_cols.astype(np.int32), [len(ghost_cols)])
+    a1, b1 = h.run(25, v0)
+    assert len(ghost_cols) == 2 * nx
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
+    assert np.array_equal(V0, h.get_basis())
+    assert h.timings()["comm"]["launches"] >= 3 * 25
+    h.close()
+    h0.close()
