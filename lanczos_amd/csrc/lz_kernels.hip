@@ -611,8 +611,14 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   QtwPlan p;
   int64_t target = (tune && tune[0] > 0) ? tune[0] : 0;
-  int64_t L = target > 0 ? round_up(target, 512) : round_up((len + 2047) / 2048, 512);
-  if (L < 512) L = 512;
+  // Measured on MI355X (profiles/r01/ab_qtw_slice_small.json): long slices amortise the per-tile reduction, as long
+  // as there are still a few blocks per CU: 5120 (40 KiB LDS, 4 blocks/CU) for >= 1024 blocks, else 2560, 1024, 512.
+  int64_t L;
+  if (target > 0) L = round_up(target, 512);
+  else if (len >= (int64_t)5120 * 1024) L = 5120;
+  else if (len >= (int64_t)2560 * 384) L = 2560;
+  else if (len >= (int64_t)1024 * 256) L = 1024;
+  else L = 512;
   if (L > kQtwMaxL) L = kQtwMaxL;
   p.L = L;
   p.G = (int)((len + L - 1) / L);
