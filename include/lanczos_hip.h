@@ -151,6 +151,8 @@ int lz_get_basis(lz_handle h, double* V_out, int64_t ld);
 /* Ritz back-transform Y = V_cols * S  (Lanczos.py:153-156: n GEMVs np.dot(V, S[:, i])):
  * S is (n, n) row-major (columns = eigenvectors of H_eff), Y_out is (rows_local, n) row-major. */
 int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out);
+/* copy the device-resident Y of the last lz_ritz_vectors call to the host: (rows_local, n) row-major */
+int lz_get_ritz_vectors(lz_handle h, double* Y_out);
 /* Device-side versions of the two checks get_H_eigs runs on Y (Lanczos.py:157-158,
  * 288-323): column norms (n) and the (n, n) Gram matrix Y^T Y, computed on the
  * device-resident Y of the last lz_ritz_vectors call (summed over ranks). */

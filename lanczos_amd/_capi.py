@@ -75,6 +75,7 @@ SIGNATURES = {
     "lz_run": (C.c_int, [_P, C.c_int, _D, _D, _D]),
     "lz_get_basis": (C.c_int, [_P, _D, C.c_int64]),
     "lz_ritz_vectors": (C.c_int, [_P, _D, _D]),
+    "lz_get_ritz_vectors": (C.c_int, [_P, _D]),
     "lz_ritz_gram": (C.c_int, [_P, _D]),
     "lz_ritz_quality": (C.c_int, [_P, _D]),
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
@@ -302,6 +303,11 @@ class Handle:
         S = f64(S)
         Y = np.empty((self.rows, self.n)) if fetch else None
         self.check(self.lib.lz_ritz_vectors(self._h, dptr(S), dptr(Y) if fetch else None))
+        return Y
+
+    def ritz_fetch(self):
+        Y = np.empty((self.rows, self.n))
+        self.check(self.lib.lz_get_ritz_vectors(self._h, dptr(Y)))
         return Y
 
     def ritz_gram(self):

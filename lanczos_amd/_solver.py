@@ -64,6 +64,7 @@ class LanczosBase:
         self.H_exact_eigs_have_been_found = False
         self._handle = None
         self._V = None
+        self._H_eigvecs_host = None
         self._timings = None
 
     def _say(self, msg):
@@ -176,23 +177,45 @@ class LanczosBase:
             raise ValueError(_NOT_EXECUTED)
         self._say("+++ Converting eigenvectors from H_eff to H basis.")
         H_eff_eigvals, H_eff_eigvecs = np.linalg.eigh(self.H_eff)
-        # Y = V S on the device (FP64 MFMA GEMM), Lanczos.py:153-156
-        H_eigvecs_lanczos = self._handle.ritz_vectors(H_eff_eigvecs)
-        if "normalized" in checks:
-            self.test_is_normalized(H_eigvecs_lanczos, tol=0.001)
-        if "orthogonal" in checks:
-            self.test_is_orthogonal(H_eigvecs_lanczos, tol=0.01)
+        # Y = V S on the device (FP64 MFMA GEMM), Lanczos.py:153-156.  Y stays on the device; the two checks of
+        # Lanczos.py:157-158 only need its n x n Gram matrix, which the device forms too.
+        self._handle.ritz_vectors(H_eff_eigvecs, fetch=False)
+        self._H_eigvecs_host = None
+        if checks:
+            G = self._handle.ritz_gram()
+            norms = np.sqrt(np.diag(G))
+            if "normalized" in checks:
+                pick = norms[np.argmin(np.abs(norms - 1))]  # like test_is_normalized: the norm CLOSEST to 1
+                assert np.abs(pick - 1) < 0.001, "VECTOR HAS NORM %.4f. IS NOT NORMALIZED." % pick
+            if "orthogonal" in checks:
+                off = np.abs(G - np.diag(np.diag(G)))
+                a, b = np.unravel_index(np.argmax(off), off.shape)
+                worst = np.sqrt(off[a, b])
+                assert worst < 0.01, "VECTORS %d AND %d NOT ORTHOGONAL! INNER PRODUCT %.4f" % (a, b, worst)
         self._H_eigvals = H_eff_eigvals
-        self._H_eigvecs = H_eigvecs_lanczos
         self._say("+++ Finished Converting.")
         self.H_eigs_have_been_found = True
+
+    @property
+    def _H_eigvecs(self):
+        """(M, n) Ritz vectors, C-order; copied off the device on first use."""
+        if self._H_eigvecs_host is None:
+            self._H_eigvecs_host = self._handle.ritz_fetch()
+        return self._H_eigvecs_host
 
     def get_H_eigs(self):
         self._ritz(self._check_eigs)
 
     # ------------------------------------------------------------------ diagnostics (host, NumPy)
     def _eigvec_quality(self):
-        """cos^2 between H x / |H x| and x for every Ritz vector (Lanczos.py:169-175)."""
+        """cos^2 between H x / |H x| and x for every Ritz vector (Lanczos.py:169-175); computed on the
+        device-resident Ritz vectors when the matrix is CSR, else with NumPy on the host copy."""
+        if not self.H_eigs_have_been_found:
+            self.get_H_eigs()
+        try:
+            return self._handle.ritz_quality()
+        except _capi.LanczosHipError:
+            pass
         H, X = self.H, self.H_eigvecs
         HX = H @ X if scipy.sparse.issparse(H) else np.asarray(H) @ X
         HX = HX / np.linalg.norm(HX, axis=0)

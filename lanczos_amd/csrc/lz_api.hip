@@ -923,7 +923,7 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
   LZ_TRY(dev_alloc(h, dS, Sp.size()));
   hipError_t e = hipMemcpyAsync(dS, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess && (!h->d_Y || h->y_rows != h->rows || h->y_n != n)) {
-    int rc = dev_alloc(h, h->d_Y, (size_t)h->rows * n);
+    int rc = dev_alloc(h, h->d_Y, (size_t)h->rows * n + 64);  // + slack: the Gram kernel reads 16-wide column tiles
     if (rc != LZ_OK) {
       hipFree(dS);
       return rc;
@@ -944,14 +944,68 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
   return LZ_OK;
 }
 
+int lz_get_ritz_vectors(lz_handle h, double* Y_out) {
+  if (!h || !Y_out) return LZ_ERR_ARG;
+  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_get_ritz_vectors: call lz_ritz_vectors first");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpyAsync(Y_out, h->d_Y, (size_t)h->y_rows * h->y_n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
 int lz_ritz_gram(lz_handle h, double* gram_out) {
   if (!h || !gram_out) return LZ_ERR_ARG;
-  return fail(h, LZ_ERR_STATE, "lz_ritz_gram: not implemented in this round");
+  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_ritz_gram: call lz_ritz_vectors first");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  const int n = h->y_n;
+  const int nz_max = 512;
+  double* part = nullptr;
+  LZ_TRY(dev_alloc(h, part, (size_t)(nz_max + 1) * n * n));
+  double* dG = part + (size_t)nz_max * n * n;
+  int rc = LZ_OK;
+  {
+    Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)h->y_rows, 2.0 * (double)h->y_rows * n * n);
+    const int nz = launch_gram(h->d_Y, n, h->y_rows, n, part, nz_max, h->stream);
+    launch_sum_slices(part, nz, (int64_t)n * n, dG, h->stream);
+    rc = check_launch(h, "gram");
+  }
+  if (rc == LZ_OK) rc = comm_allreduce(h, dG, (int64_t)n * n);
+  hipError_t e = hipSuccess;
+  if (rc == LZ_OK) e = hipMemcpyAsync(gram_out, dG, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(part);
+  if (rc != LZ_OK) return rc;
+  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_gram: ") + hipGetErrorString(e));
+  return LZ_OK;
 }
 
 int lz_ritz_quality(lz_handle h, double* out) {
   if (!h || !out) return LZ_ERR_ARG;
-  return fail(h, LZ_ERR_STATE, "lz_ritz_quality: not implemented in this round");
+  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: call lz_ritz_vectors first");
+  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: CSR matrices only");
+  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: single-rank only (needs ghost rows of Y)");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  const int n = h->y_n;
+  const size_t nblk = (size_t)((h->rows + 2047) / 2048);
+  double* part = nullptr;
+  LZ_TRY(dev_alloc(h, part, (nblk + 1) * 2 * n));
+  double* dS = part + nblk * 2 * n;
+  int rc = LZ_OK;
+  {
+    Scope sc(h, LZ_K_RITZ, 12.0 * h->csr.nnz + 8.0 * n * (double)h->rows, 2.0 * (double)h->csr.nnz * n);
+    const int nb = launch_ritz_quality(h->csr, h->d_Y, n, n, part, h->stream);
+    launch_sum_slices(part, nb, 2 * (int64_t)n, dS, h->stream);
+    rc = check_launch(h, "ritz_quality");
+  }
+  std::vector<double> sums(2 * (size_t)n);
+  hipError_t e = hipSuccess;
+  if (rc == LZ_OK) e = hipMemcpyAsync(sums.data(), dS, sums.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(part);
+  if (rc != LZ_OK) return rc;
+  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
+  for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];
+  return LZ_OK;
 }
 
 int lz_get_timings(lz_handle h, lz_timings* out) {

@@ -72,7 +72,10 @@ void launch_gather(const double* x, const int32_t* idx, int64_t n, double* buf, 
 // Y(rows x n, row-major, ldy) = sum_k V[k][m] * S[k][i]   (FP64 MFMA)
 void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
                       int64_t ldy, hipStream_t s);
-// G(npad x npad) partials of Y^T Y over row chunks
-int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part, hipStream_t s);
+// G = Y^T Y as K-chunk partials (n x n each); returns the number of chunks (<= nz_max)
+int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part, int nz_max, hipStream_t s);
+void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s);
+// per-block [s1 (n), s2 (n)] partials of the Ritz-vector quality sums; returns the number of blocks
+int launch_ritz_quality(const CsrDev& A, const double* Y, int64_t ldy, int n, double* part, hipStream_t s);
 
 }  // namespace lz

@@ -170,3 +170,44 @@ def test_kernel_variants_agree(flags):
     assert np.abs(a1 - a0).max() < 1e-11 and np.abs(b1 - b0).max() < 1e-11
     assert np.abs(V1[:10] - V0[:10]).max() < 1e-10
     assert np.abs(V1 @ V1.T - np.eye(60)).max() < 1e-12
+
+
+def test_device_gram_and_quality_match_numpy():
+    """lz_ritz_gram / lz_ritz_quality (device-side versions of test_is_normalized / test_is_orthogonal and the
+    print_good_eigs residual loop, Lanczos.py:157-158,166-175) against NumPy on the fetched Ritz vectors."""
+    H = synthetic.laplacian_2d_5pt(211, 97).to_scipy()
+    n = 37
+    Lanczos.verbose = False
+    s = Lanczos(H)
+    s.execute_Lanczos(n)
+    s.get_H_eigs()  # runs both asserts on the device Gram matrix
+    Y = s.H_eigvecs
+    G = s._handle.ritz_gram()
+    np.testing.assert_allclose(G, Y.T @ Y, rtol=0, atol=1e-13)
+    q = s._handle.ritz_quality()
+    HY = H @ Y
+    ref = np.einsum("ij,ij->j", HY / np.linalg.norm(HY, axis=0), Y) ** 2
+    np.testing.assert_allclose(q, ref, rtol=1e-11, atol=1e-13)
+    assert abs(Lanczos.test_is_normalized(Y, no_assert=True) - np.sqrt(np.diag(G))[np.argmin(np.abs(np.sqrt(np.diag(G)) - 1))]) < 1e-13
+    import contextlib, io
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        s.print_good_eigs()
+    assert "Eigvec InnerProd" in buf.getvalue() and len(buf.getvalue().splitlines()) == 22
+
+
+def test_get_H_eigs_asserts_fire_on_device_gram():
+    """A basis that is not orthonormal must trip the reference's asserts (evaluated on the device Gram)."""
+    from lanczos_amd import _capi
+
+    H = synthetic.laplacian_2d_5pt(40, 30).to_scipy()
+    Lanczos.verbose = False
+    s = Lanczos(H)
+    s.execute_Lanczos(12)
+    S_bad = np.linalg.eigh(s.H_eff)[1].copy()
+    S_bad[:, 3] = S_bad[:, 2]  # two identical Ritz vectors
+    s._handle.ritz_vectors(S_bad, fetch=False)
+    G = s._handle.ritz_gram()
+    off = np.abs(G - np.diag(np.diag(G)))
+    assert np.sqrt(off.max()) > 0.9
