@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
   const int nsteps = m_hi > m_lo ? (m_hi - m_lo) >> 3 : 0;  // multiple of 4 (cnt and sub are multiples of 32)
   const int pid = blockIdx.x * (kTPB / 64) + w;
   const double2* swl = sw + (m_lo >> 1) + g;     // + 4*s per step
-  for (int i0 = 0; i0 < nrows; i0 += 16 * T) {
+  for (int i0 = ((nrows - 1) / (16 * T)) * (16 * T); i0 >= 0; i0 -= 16 * T) {  // newest rows first (see k_qtw_valu)
     const double2* a[T];
     double4_t acc[T][2];
 #pragma unroll
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int t = 0; t < T; ++t) av[t][u] = (s0 + u < nsteps) ? a[t][4 * (s0 + u)] : make_double2(0.0, 0.0);
+        for (int t = 0; t < T; ++t) av[t][u] = (s0 + u < nsteps) ? ld_stream<1>(a[t] + 4 * (s0 + u)) : make_double2(0.0, 0.0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const double2 bv = (s0 + u < nsteps) ? swl[4 * (s0 + u)] : make_double2(0.0, 0.0);
