@@ -194,3 +194,23 @@ def test_socket_bootstrap_collectives():
         peers = [p for p in range(world) if p != r]
         assert o["xchg"] == [[10.0 * p + r] * 2 for p in peers]
         assert o["ag"] == [0.0, 0.0, 1.0, 1.0, 2.0, 2.0]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_headline_partition_plan(world):
+    """The M = 1e7 headline grid (4000 x 2500) split over 2/4/8 ranks: every rank exchanges exactly one grid row
+    (4000 doubles = 32 KB) with each of its two slab neighbours (periodic wrap makes rank 0 and P-1 neighbours)."""
+    nx, ny = 4000, 2500
+    M = nx * ny
+    b = partition.row_bounds(M, world)
+    assert b[-1] == M and all((b[i + 1] - b[i]) > 0 for i in range(world))
+    for r in (0, world // 2, world - 1):
+        loc = synthetic.laplacian_2d_5pt(nx, ny, rows=(b[r], b[r + 1]))
+        p = partition.plan_exchange(loc.rowptr, loc.colidx, M, world, r)
+        assert p.mode == "halo"
+        expect_peers = sorted({(r - 1) % world, (r + 1) % world})
+        assert list(p.peers) == expect_peers
+        total = 2 * nx
+        assert int(p.recv_counts.sum()) == total and int(p.send_counts.sum()) == total
+        assert p.ncols_ext == p.rows_pad + total
+        assert p.colidx.max() < p.ncols_ext and p.colidx.min() >= 0
