@@ -1,0 +1,60 @@
+// Device-side helpers shared by the kernel translation units (gfx950: wave = 64 lanes).
+#pragma once
+
+#include "lz_internal.h"
+
+namespace lz {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // lane 0 holds the sum
+}
+
+// sum over the block; result valid in thread 0.  `sm` has kTPB/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < kTPB / 64; ++i) t += sm[i];
+  }
+  __syncthreads();
+  return t;
+}
+
+// Bijective XCD-aware remap: blocks b, b+8, b+16, ... share an XCD (round-robin
+// dispatch), so give each XCD one contiguous band of tiles -> neighbouring
+// tiles (which re-use the same x entries in a stencil SpMV) share an L2.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg / kNumXCD, r = nwg % kNumXCD, x = b % kNumXCD;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / kNumXCD;
+}
+
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+typedef int i2v_t __attribute__((ext_vector_type(2)));
+// Streamed-once data (basis rows, matrix entries) is loaded non-temporally so it does not push the
+// re-used data (x, w, the most recent basis rows) out of L2 / Infinity Cache.  VAR == 0: plain load.
+template <int VAR>
+__device__ __forceinline__ double2 ld_stream(const double2* p) {
+  if (VAR == 1) {
+    const d2v_t v = __builtin_nontemporal_load(reinterpret_cast<const d2v_t*>(p));
+    return make_double2(v.x, v.y);
+  }
+  return *p;
+}
+template <int VAR>
+__device__ __forceinline__ int2 ld_stream(const int2* p) {
+  if (VAR == 1) {
+    const i2v_t v = __builtin_nontemporal_load(reinterpret_cast<const i2v_t*>(p));
+    return make_int2(v.x, v.y);
+  }
+  return *p;
+}
+
+}  // namespace lz

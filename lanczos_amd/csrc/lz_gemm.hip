@@ -1,0 +1,190 @@
+// FP64-MFMA kernels: Ritz back-transform Y = V^T-layout x S, Gram matrix Y^T Y, Ritz-vector quality sums.
+#include "lz_device.h"
+
+namespace lz {
+
+// ------------------------------------------------------------------ Ritz back-transform (FP64 MFMA)
+// Y[m][i] = sum_k V[k][m] * S[k][i].  v_mfma_f64_16x16x4_f64: lane l supplies
+// A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; the 4 results per lane are
+// D[row = (l>>4) + 4*reg][col = l&15].  One wave owns a 32(m) x 64(i) tile
+// (8 accumulators), the 4 waves of a block stack along m.
+// C[z][m][i] = sum_{k in K-chunk z} A[k][m] * B[k][i]  ("TN" product of two row-major, k-major operands).
+//   Ritz back-transform: A = V (k = basis index, m = matrix row), B = S, one chunk:  Y = V^T S.
+//   Gram matrix        : A = B = Y (k = matrix row), split over gridDim.z chunks:   G = Y^T Y.
+// One wave owns 32 rows (m) x NT*16 columns (all of them when ncols <= 256), so A is streamed from HBM exactly
+// once per column group; B rows are re-read by every wave (L2).  Operands are prefetched in registers: B one
+// k-step ahead, A (the HBM stream) four k-steps ahead.  B must be readable up to 15 doubles past a row's end.
+template <int NT>
+__global__ __launch_bounds__(kTPB) void k_gemm_tn(const double* __restrict__ A, int64_t lda, int64_t mdim, int64_t kcount,
+                                                 int64_t kchunk, const double* __restrict__ B, int64_t ldb, int ncols,
+                                                 double* __restrict__ C, int64_t ldc, int64_t zstride) {
+  constexpr int PA = 4;  // A prefetch distance (k-steps)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int64_t m0 = ((int64_t)blockIdx.x * (kTPB / 64) + w) * 32;
+  if (m0 >= mdim) return;  // wave-uniform
+  const int64_t k_lo = (int64_t)blockIdx.z * kchunk;
+  const int64_t k_hi = k_lo + kchunk < kcount ? k_lo + kchunk : kcount;
+  const int nsteps = k_hi > k_lo ? (int)((k_hi - k_lo + 3) >> 2) : 0;
+  const int ct0 = blockIdx.y * NT;
+  const int CT = (ncols + 15) / 16;
+  int64_t ma = m0 + lr, mb = m0 + 16 + lr;
+  if (ma >= mdim) ma = mdim - 1;
+  if (mb >= mdim) mb = mdim - 1;
+  int colb[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) colb[b] = 16 * (ct0 + b < CT ? ct0 + b : CT - 1) + lr;
+  double4_t acc[2][NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    acc[0][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    acc[1][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  }
+  auto load_a = [&](int step, double& x0, double& x1) {
+    int64_t kr = k_lo + 4 * (int64_t)step + lk;
+    const bool ok = kr < k_hi;  // rows past the chunk contribute zero whatever B holds there
+    if (!ok) kr = k_hi - 1;
+    const double* ar = A + kr * lda;
+    x0 = ok ? ar[ma] : 0.0;
+    x1 = ok ? ar[mb] : 0.0;
+  };
+  auto brow = [&](int step) {
+    int64_t kr = k_lo + 4 * (int64_t)step + lk;
+    if (kr >= k_hi) kr = k_hi - 1;
+    return B + kr * ldb;
+  };
+  double ra[PA][2];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    ra[p][0] = ra[p][1] = 0.0;
+    if (nsteps > 0) load_a(p < nsteps ? p : nsteps - 1, ra[p][0], ra[p][1]);
+  }
+  double bcur[NT];
+  if (nsteps > 0) {
+    const double* sr = brow(0);
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bcur[b] = sr[colb[b]];
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += PA) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int st = s0 + p;
+      if (st < nsteps) {
+        const double a0 = ra[p][0], a1 = ra[p][1];
+        load_a(st + PA < nsteps ? st + PA : nsteps - 1, ra[p][0], ra[p][1]);  // refill this ring slot
+        double bnxt[NT];
+        {
+          const double* sr = brow(st + 1 < nsteps ? st + 1 : st);
+#pragma unroll
+          for (int b = 0; b < NT; ++b) bnxt[b] = sr[colb[b]];
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          acc[0][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bcur[b], acc[0][b], 0, 0, 0);
+          acc[1][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bcur[b], acc[1][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bcur[b] = bnxt[b];
+      }
+    }
+  }
+  double* Cz = C + (int64_t)blockIdx.z * zstride;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      if (ct0 + b >= CT) continue;
+      const int col = 16 * (ct0 + b) + lr;
+      if (col >= ncols) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t m = m0 + 16 * a + lk + 4 * g;
+        if (m < mdim) Cz[m * ldc + col] = acc[a][b][g];
+      }
+    }
+}
+
+static void launch_gemm_tn(const double* A, int64_t lda, int64_t mdim, int64_t kcount, int64_t kchunk, int nz, const double* B,
+                           int64_t ldb, int ncols, double* C, int64_t ldc, int64_t zstride, hipStream_t s) {
+  const int CT = (ncols + 15) / 16;
+  const int ngroups = (CT + 15) / 16;
+  const int NT = (CT + ngroups - 1) / ngroups;
+  dim3 grid((unsigned)((mdim + 127) / 128), (unsigned)ngroups, (unsigned)nz);
+#define LZ_TN(nt)                                                                                                          \
+  case nt:                                                                                                                 \
+    hipLaunchKernelGGL((k_gemm_tn<nt>), grid, dim3(kTPB), 0, s, A, lda, mdim, kcount, kchunk, B, ldb, ncols, C, ldc, zstride); \
+    break;
+  switch (NT) {
+    LZ_TN(1) LZ_TN(2) LZ_TN(3) LZ_TN(4) LZ_TN(5) LZ_TN(6) LZ_TN(7) LZ_TN(8)
+    LZ_TN(9) LZ_TN(10) LZ_TN(11) LZ_TN(12) LZ_TN(13) LZ_TN(14) LZ_TN(15) LZ_TN(16)
+    default: break;
+  }
+#undef LZ_TN
+}
+
+void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
+                      int64_t ldy, hipStream_t s) {
+  launch_gemm_tn(V, ldv, rows, n, n, 1, Spad, npad, n, Y, ldy, 0, s);
+}
+
+// out[i] = sum_z part[z*count + i] (fixed order)
+__global__ __launch_bounds__(kTPB) void k_sum_slices(const double* __restrict__ part, int nz, int64_t count,
+                                                    double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  if (i >= count) return;
+  double a0 = 0.0, a1 = 0.0;
+  int z = 0;
+  for (; z + 1 < nz; z += 2) {
+    a0 += part[(int64_t)z * count + i];
+    a1 += part[(int64_t)(z + 1) * count + i];
+  }
+  if (z < nz) a0 += part[(int64_t)z * count + i];
+  out[i] = a0 + a1;
+}
+void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((count + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, part, nz, count, out);
+}
+
+// G = Y^T Y as nz K-chunk partials (n x n each) in `part`; returns nz.  Y needs 16 doubles of slack at its end.
+int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part, int nz_max, hipStream_t s) {
+  int nz = (int)((rows + 2047) / 2048);
+  if (nz > nz_max) nz = nz_max;
+  if (nz < 1) nz = 1;
+  int64_t kchunk = (rows + nz - 1) / nz;
+  kchunk = (kchunk + 3) & ~(int64_t)3;
+  nz = (int)((rows + kchunk - 1) / kchunk);
+  launch_gemm_tn(Y, ldy, n, rows, kchunk, nz, Y, ldy, n, part, n, (int64_t)n * n, s);
+  return nz;
+}
+
+// Eigenvector quality sums for every Ritz vector at once (print_good_eigs, Lanczos.py:169-175):
+//   z = A y_i ;  s1_i = z . y_i ;  s2_i = z . z        (quality_i = s1_i^2 / s2_i)
+// Y is (rows x n) row-major, so row r of A Y is a sum of whole rows of Y: each lane owns columns i, i+256, ...
+// and walks the block's rows; matrix entries are wave-uniform (scalar) loads, Y rows are coalesced 16-row... reads.
+__global__ __launch_bounds__(kTPB) void k_ritz_quality(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                      const double* __restrict__ vals, const double* __restrict__ Y,
+                                                      int64_t ldy, int64_t rows, int n, int rows_per_block,
+                                                      double* __restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int i = threadIdx.x; i < n; i += kTPB) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t r = r0; r < r1; ++r) {
+      const int a = rowptr[r], b = rowptr[r + 1];
+      double z = 0.0;
+      for (int k = a; k < b; ++k) z = fma(vals[k], Y[(int64_t)colidx[k] * ldy + i], z);
+      s1 = fma(z, Y[r * ldy + i], s1);
+      s2 = fma(z, z, s2);
+    }
+    part[(int64_t)blockIdx.x * 2 * n + i] = s1;
+    part[(int64_t)blockIdx.x * 2 * n + n + i] = s2;
+  }
+}
+int launch_ritz_quality(const CsrDev& A, const double* Y, int64_t ldy, int n, double* part, hipStream_t s) {
+  const int rpb = 2048;
+  const int grid = (int)((A.rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(k_ritz_quality, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, Y, ldy, A.rows, n, rpb, part);
+  return grid;
+}
+
+}  // namespace lz

@@ -1,0 +1,272 @@
+// Hand-written gfx950 SpMV kernels of the Lanczos hot path: r = A v_j with the alpha partials fused.
+//
+// All kernels here are HBM-bandwidth bound (<= 0.25 flop/byte), so the design
+// rules are: 16-byte coalesced accesses, many independent loads in flight per
+// lane, non-temporal loads for data that is streamed once, deterministic
+// two-stage reductions (wave shuffle -> LDS -> per-block partial -> tiny
+// second-stage kernel), and no atomics.
+//
+// Arithmetic contract (DESIGN.md "numerics"): element-wise results follow the
+// reference CPU branch's NumPy expression order with NO fused multiply-add
+// (compiled with -ffp-contract=off), so SpMV row sums, the re-orthogonalisation
+// update and the three-term recurrence are bit-identical to NumPy/SciPy given
+// the same scalar inputs; only the inner products differ (summation order).
+#include "lz_device.h"
+
+namespace lz {
+
+// ------------------------------------------------------------------ CSR SpMV
+// (a) plain one-thread-per-row kernel: baseline / A-B arm.
+__global__ __launch_bounds__(kTPB) void k_spmv_scalar(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                     const double* __restrict__ vals, const double* __restrict__ x,
+                                                     const double* __restrict__ xown, double* __restrict__ y, int64_t rows,
+                                                     double* __restrict__ part) {
+  __shared__ double sm[kTPB / 64];
+  const int64_t row = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  double d = 0.0;
+  if (row < rows) {
+    double sum = 0.0;
+    const int a = rowptr[row], b = rowptr[row + 1];
+    for (int k = a; k < b; ++k) sum += vals[k] * x[colidx[k]];
+    y[row] = sum;
+    d = xown[row] * sum;
+  }
+  d = block_sum(d, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = d;
+}
+
+// (b) CSR-stream: the block's contiguous slice of vals/colidx is read with
+// 16-byte/8-byte coalesced loads, products are staged in LDS, then each thread
+// adds up its rows from LDS in CSR order (same order and rounding as SciPy's
+// csr_matvec: sum += a*x, no FMA).  Row blocks are precomputed on the host so
+// that one block's products fit the LDS tile.
+
+// ABL != 0 instantiations are timing-only ablation arms for tools/kbench.py (wrong results on purpose):
+// 1 = no x gather, 2 = no colidx load, 4 = no vals load, 8 = no y store.
+template <int FIXED_K, int ABL = 0>
+__global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict__ rowblk, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ colidx, const double* __restrict__ vals,
+                                                     const double* __restrict__ x, const double* __restrict__ xown,
+                                                     double* __restrict__ y, int fixed_k, int nnz_cap,
+                                                     double* __restrict__ part) {
+  extern __shared__ double prod[];  // nnz_cap + 2 products
+  __shared__ double sm[kTPB / 64];
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int r0 = rowblk[blk], r1 = rowblk[blk + 1];
+  const int K = FIXED_K > 0 ? FIXED_K : fixed_k;
+  const int k0 = K > 0 ? r0 * K : rowptr[r0];
+  const int k1 = K > 0 ? r1 * K : rowptr[r1];
+  double d = 0.0;
+  if (k1 - k0 <= nnz_cap) {
+    // phase 1: products, two entries per lane per step, aligned to even k.  Batches of 4 steps:
+    // all (vals, colidx) loads of a batch are issued first, then its 8 x gathers, then the LDS
+    // stores - 3 dependent round trips per batch instead of 8.
+    const int kk = k0 & ~1;
+    const int npair = (k1 - kk + 1) >> 1;
+    constexpr int NB = 4;
+    for (int pb = threadIdx.x; pb < npair; pb += NB * kTPB) {
+      double2 a[NB];
+      int2 c[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        int p = pb + kTPB * i;
+        if (p >= npair) p = pb;  // clamped duplicate, discarded below
+        const int k = kk + 2 * p;
+        a[i] = (ABL & 4) ? make_double2(1.0, 2.0) : ld_stream<1>(reinterpret_cast<const double2*>(vals + k));
+        c[i] = (ABL & 2) ? make_int2(k / (K > 0 ? K : 1), (k + 1) / (K > 0 ? K : 1)) : ld_stream<1>(reinterpret_cast<const int2*>(colidx + k));
+        if (ABL & 1) c[i] = make_int2(c[i].x & 1023, c[i].y & 1023);
+      }
+      double2 xv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) xv[i] = make_double2(x[c[i].x], x[c[i].y]);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int p = pb + kTPB * i;
+        if (p < npair) {
+          const int k = kk + 2 * p;
+          const double p0 = (k >= k0) ? a[i].x * xv[i].x : 0.0;
+          const double p1 = (k + 1 < k1) ? a[i].y * xv[i].y : 0.0;
+          *reinterpret_cast<double2*>(&prod[2 * p]) = make_double2(p0, p1);
+        }
+      }
+    }
+    __syncthreads();
+    // phase 2: per-row sequential sums out of LDS
+    const int shift = k0 - kk;  // 0 or 1
+    for (int row = r0 + threadIdx.x; row < r1; row += kTPB) {
+      int a, b;
+      if (K > 0) {
+        a = (row - r0) * K + shift;
+        b = a + K;
+      } else {
+        a = rowptr[row] - kk;
+        b = rowptr[row + 1] - kk;
+      }
+      double sum = 0.0;
+      if (FIXED_K > 0) {
+#pragma unroll
+        for (int k = 0; k < FIXED_K; ++k) sum += prod[a + k];
+      } else {
+        for (int k = a; k < b; ++k) sum += prod[k];
+      }
+      if (!(ABL & 8)) y[row] = sum;
+      d += xown[row] * sum;
+    }
+  } else {
+    // long row(s): the host gives such a row a block of its own
+    for (int row = r0; row < r1; ++row) {
+      const int a = rowptr[row], b = rowptr[row + 1];
+      double acc = 0.0;
+      for (int k = a + threadIdx.x; k < b; k += kTPB) acc = fma(vals[k], x[colidx[k]], acc);
+      acc = block_sum(acc, sm);
+      if (threadIdx.x == 0) {
+        y[row] = acc;
+        d += xown[row] * acc;
+      }
+    }
+  }
+  d = block_sum(d, sm);
+  if (threadIdx.x == 0) part[blk] = d;
+}
+
+// (c) fixed-K rows (stencils): every block owns exactly RB rows = RB*K contiguous entries, so all
+// trip counts are compile-time: each lane first issues ALL its 16-byte vals and 8-byte colidx loads
+// (NP of each), then all 2*NP x gathers, then stages the products in LDS; after one barrier each
+// lane adds up RB/256 rows from LDS in CSR order.  Three dependent memory round trips per block
+// instead of 2*NP, and an LDS tile of exactly RB*K products.  rowptr is never read.
+template <int K, int RB, int NT = 1>
+__global__ __launch_bounds__(kTPB) void k_spmv_fixed(const int32_t* __restrict__ colidx, const double* __restrict__ vals,
+                                                    const double* __restrict__ x, const double* __restrict__ xown,
+                                                    double* __restrict__ y, int rows, double* __restrict__ part) {
+  constexpr int NNZ = RB * K;              // even (RB is a multiple of 256)
+  constexpr int NP = NNZ / 2 / kTPB;       // double2 pairs per lane
+  constexpr int RPT = RB / kTPB;           // rows per lane
+  static_assert(NNZ % (2 * kTPB) == 0, "RB*K must be a multiple of 512");
+  __shared__ double prod[NNZ];
+  __shared__ double sm[kTPB / 64];
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int r0 = blk * RB;
+  const int nr = rows - r0 < RB ? rows - r0 : RB;
+  const int64_t k0 = (int64_t)r0 * K;
+  const int kcnt = nr * K;                 // entries of this block
+  const double2* v2 = reinterpret_cast<const double2*>(vals + k0);
+  const int2* c2 = reinterpret_cast<const int2*>(colidx + k0);
+  double2 a[NP];
+  int2 c[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    int p = threadIdx.x + kTPB * i;
+    if (2 * p >= kcnt) p = 0;              // tail block: valid address, product discarded below
+    a[i] = ld_stream<NT>(v2 + p);
+    c[i] = ld_stream<NT>(c2 + p);
+  }
+  double2 xv[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) xv[i] = make_double2(x[c[i].x], x[c[i].y]);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int p = threadIdx.x + kTPB * i;
+    double2 pr = make_double2(a[i].x * xv[i].x, a[i].y * xv[i].y);
+    if (2 * p >= kcnt) pr = make_double2(0.0, 0.0);
+    else if (2 * p + 1 >= kcnt) pr.y = 0.0;
+    *reinterpret_cast<double2*>(&prod[2 * p]) = pr;
+  }
+  __syncthreads();
+  double d = 0.0;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int lr = threadIdx.x + kTPB * q;
+    if (lr < nr) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) sum += prod[lr * K + k];
+      y[r0 + lr] = sum;
+      d += xown[r0 + lr] * sum;
+    }
+  }
+  d = block_sum(d, sm);
+  if (threadIdx.x == 0) part[blk] = d;
+}
+
+template <int K>
+static int launch_spmv_fixed(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int rb,
+                             hipStream_t s) {
+  if (rb == 1024) {
+    const int grid = (int)((A.rows + 1023) / 1024);
+    hipLaunchKernelGGL((k_spmv_fixed<K, 1024>), dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, x, x_own, y, (int)A.rows, part);
+    return grid;
+  }
+  const int grid = (int)((A.rows + 511) / 512);
+  if (rb == 513)  // A/B arm: plain (cached) loads of the matrix stream
+    hipLaunchKernelGGL((k_spmv_fixed<K, 512, 0>), dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, x, x_own, y, (int)A.rows, part);
+  else
+    hipLaunchKernelGGL((k_spmv_fixed<K, 512>), dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, x, x_own, y, (int)A.rows, part);
+  return grid;
+}
+
+int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
+                    hipStream_t s) {
+  if (A.rows == 0) return 0;
+  if (flags & LZ_FLAG_SPMV_SCALAR) {
+    const int grid = (int)((A.rows + kTPB - 1) / kTPB);
+    hipLaunchKernelGGL(k_spmv_scalar, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, x, x_own, y, A.rows, part);
+    return grid;
+  }
+  if (!A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) {
+    if (A.fixed_k == 5) return launch_spmv_fixed<5>(A, x, y, x_own, part, A.fixed_rb, s);
+    if (A.fixed_k == 7) return launch_spmv_fixed<7>(A, x, y, x_own, part, A.fixed_rb, s);
+  }
+  const int grid = A.n_rowblk;
+  const size_t lds = (size_t)(A.blk_nnz_cap + 2) * sizeof(double);
+#define LZ_ABL(n)                                                                                                   \
+  case n:                                                                                                          \
+    hipLaunchKernelGGL((k_spmv_stream<5, n>), dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, \
+                       5, A.blk_nnz_cap, part);                                                                    \
+    return grid;
+  if (A.fixed_k == 5 && A.ablation) {
+    switch (A.ablation) {
+      LZ_ABL(1) LZ_ABL(2) LZ_ABL(3) LZ_ABL(4) LZ_ABL(7) LZ_ABL(8) LZ_ABL(15)
+      default: break;
+    }
+  }
+#undef LZ_ABL
+  if (A.fixed_k == 5)
+    hipLaunchKernelGGL(k_spmv_stream<5>, dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, 5,
+                       A.blk_nnz_cap, part);
+  else if (A.fixed_k == 7)
+    hipLaunchKernelGGL(k_spmv_stream<7>, dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, 7,
+                       A.blk_nnz_cap, part);
+  else
+    hipLaunchKernelGGL(k_spmv_stream<0>, dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y,
+                       A.fixed_k, A.blk_nnz_cap, part);
+  return grid;
+}
+
+// ------------------------------------------------------------------ dense GEMV (row-major A, one wave per row)
+__global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ A, int64_t M, const double* __restrict__ x,
+                                                    double* __restrict__ y, double* __restrict__ part) {
+  __shared__ double sm[kTPB / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * (kTPB / 64) + w;
+  double d = 0.0;
+  if (row < M) {
+    const double* a = A + row * M;
+    double acc = 0.0;
+    for (int64_t c = lane; c < M; c += 64) acc = fma(a[c], x[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      y[row] = acc;
+      d = x[row] * acc;
+    }
+  }
+  d = block_sum(d, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = d;
+}
+
+int launch_gemv_dense(const double* A, int64_t M, const double* x, double* y, double* part, hipStream_t s) {
+  const int grid = (int)((M + kTPB / 64 - 1) / (kTPB / 64));
+  hipLaunchKernelGGL(k_gemv_dense, dim3(grid), dim3(kTPB), 0, s, A, M, x, y, part);
+  return grid;
+}
+
+}  // namespace lz
