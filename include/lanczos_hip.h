@@ -128,6 +128,17 @@ int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, 
  * conversion the reference's GPU path performs for ndarray input
  * (1Dbox.py:27 -> Lanczos.py:88) with a real dense GEMV. */
 int lz_set_dense(lz_handle h, int64_t M, const double* A);
+/* Assemble the reference's regular-grid Hamiltonian directly in device CSR (replaces the
+ * Python-loop COO build of Python/Regular/Hamiltonian.py:45-128 plus `H = -T + V; H.sort_indices()` of
+ * 3Ddeuteron.py:80-81): periodic N^3 grid, flat index x + y N + z N^2, `points` = 7 or 27, weights4 =
+ * {centre, face, edge, corner} as the host computed them (7-point uses the first two).  Entries are
+ * T_factor * w (negated if negate_T), plus potential[row] (N^3 host doubles, may be NULL) on the diagonal;
+ * columns sorted.  The matrix becomes the handle's operator, exactly as after lz_set_csr. */
+int lz_build_stencil3d(lz_handle h, int N, int points, double T_factor, const double* weights4, const double* potential,
+                       int negate_T);
+int lz_csr_info(lz_handle h, int64_t* rows, int64_t* nnz);
+/* download the handle's CSR matrix (sizes from lz_csr_info) */
+int lz_get_csr(lz_handle h, int32_t* rowptr, int32_t* colidx, double* vals);
 /* halo plan: for peer p (npeers of them) send x[send_idx[..]] (local row
  * indices, send_counts[p] of them, concatenated) and receive recv_counts[p]
  * doubles into the ghost region, in peer order. */

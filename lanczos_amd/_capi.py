@@ -70,6 +70,9 @@ SIGNATURES = {
     "lz_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, HOST_ALLGATHER_FN, _P]),
     "lz_set_csr": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _I32, _I32, _D]),
     "lz_set_dense": (C.c_int, [_P, C.c_int64, _D]),
+    "lz_build_stencil3d": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _D, _D, C.c_int]),
+    "lz_csr_info": (C.c_int, [_P, _I64, _I64]),
+    "lz_get_csr": (C.c_int, [_P, _I32, _I32, _D]),
     "lz_set_halo": (C.c_int, [_P, C.c_int, _I32, _I64, _I32, _I64]),
     "lz_set_allgather": (C.c_int, [_P, C.c_int64]),
     "lz_run": (C.c_int, [_P, C.c_int, _D, _D, _D]),
@@ -272,6 +275,24 @@ class Handle:
             raise ValueError("dense H must be square")
         self.check(self.lib.lz_set_dense(self._h, A.shape[0], dptr(A)))
         self.rows = A.shape[0]
+
+    def build_stencil3d(self, N, points, T_factor, weights4, potential=None, negate_T=False):
+        w = f64(weights4)
+        assert w.shape == (4,)
+        pot = None if potential is None else f64(potential).reshape(-1)
+        if pot is not None and pot.shape != (N**3,):
+            raise ValueError("potential must have N^3 entries")
+        self.check(self.lib.lz_build_stencil3d(self._h, int(N), int(points), float(T_factor), dptr(w), None if pot is None else dptr(pot), int(bool(negate_T))))
+        self.rows = N**3
+
+    def get_csr(self):
+        rows, nnz = C.c_int64(), C.c_int64()
+        self.check(self.lib.lz_csr_info(self._h, C.byref(rows), C.byref(nnz)))
+        rowptr = np.empty(rows.value + 1, dtype=np.int32)
+        colidx = np.empty(nnz.value, dtype=np.int32)
+        vals = np.empty(nnz.value)
+        self.check(self.lib.lz_get_csr(self._h, i32ptr(rowptr), i32ptr(colidx), dptr(vals)))
+        return rowptr, colidx, vals
 
     def set_halo(self, peers, send_counts, send_idx, recv_counts):
         peers = np.ascontiguousarray(peers, dtype=np.int32)

@@ -415,6 +415,38 @@ void build_rowblocks(const int32_t* rowptr, int64_t rows, int rows_cap, int nnz_
   }
 }
 
+// shared tail of lz_set_csr / lz_build_stencil3d: row blocks for the CSR-stream kernel + bookkeeping
+int finish_csr(lz_handle h, const int32_t* rowptr_host, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext,
+               int64_t nnz, int fixed_k, int max_nnz) {
+  CsrDev& A = h->csr;
+  std::vector<int32_t> blk;
+  int rows_cap = h->tune[2] > 0 ? h->tune[2] : 512;
+  int nnz_cap = h->tune[4] > 0 ? h->tune[4] : 4096;
+  if (nnz_cap > 16384) nnz_cap = 16384;
+  build_rowblocks(rowptr_host, rows_local, rows_cap, nnz_cap, blk);
+  A.blk_nnz_cap = nnz_cap;
+  A.ablation = h->tune[3];
+  A.fixed_rb = h->tune[5] > 0 ? h->tune[5] : 512;
+  LZ_TRY(dev_alloc(h, A.rowblk, blk.size()));
+  LZ_HIP(h, hipMemcpy(A.rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  A.n_rowblk = (int)blk.size() - 1;
+  A.rows = rows_local;
+  A.ncols = ncols_ext;
+  A.nnz = nnz;
+  A.fixed_k = fixed_k;
+  A.max_row_nnz = max_nnz;
+  A.avg_row_nnz = (double)nnz / (double)rows_local;
+  h->Mg = M_global;
+  h->row0 = row0;
+  h->rows = rows_local;
+  h->ncols_ext = ncols_ext;
+  h->rows_pad = round_up(rows_local, kPadDoubles);
+  h->ldv = h->rows_pad;
+  h->xmode = 0;
+  h->kind = 1;
+  return LZ_OK;
+}
+
 }  // namespace
 
 // ======================================================================= C ABI
@@ -617,31 +649,60 @@ int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, 
     LZ_HIP(h, hipMemcpy(A.colidx, colidx, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
     LZ_HIP(h, hipMemcpy(A.vals, vals, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
   }
-  std::vector<int32_t> blk;
-  int rows_cap = h->tune[2] > 0 ? h->tune[2] : 512;
-  int nnz_cap = h->tune[4] > 0 ? h->tune[4] : 4096;
-  if (nnz_cap > 16384) nnz_cap = 16384;
-  build_rowblocks(rowptr, rows_local, rows_cap, nnz_cap, blk);
-  A.blk_nnz_cap = nnz_cap;
-  A.ablation = h->tune[3];
-  A.fixed_rb = h->tune[5] > 0 ? h->tune[5] : 512;
-  LZ_TRY(dev_alloc(h, A.rowblk, blk.size()));
-  LZ_HIP(h, hipMemcpy(A.rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  A.n_rowblk = (int)blk.size() - 1;
-  A.rows = rows_local;
-  A.ncols = ncols_ext;
-  A.nnz = nnz;
-  A.fixed_k = fixed_k;
-  A.max_row_nnz = max_nnz;
-  A.avg_row_nnz = (double)nnz / (double)rows_local;
-  h->Mg = M_global;
-  h->row0 = row0;
-  h->rows = rows_local;
-  h->ncols_ext = ncols_ext;
-  h->rows_pad = round_up(rows_local, kPadDoubles);
-  h->ldv = h->rows_pad;
-  h->xmode = 0;
-  h->kind = 1;
+  return finish_csr(h, rowptr, M_global, row0, rows_local, ncols_ext, nnz, fixed_k, max_nnz);
+}
+
+int lz_build_stencil3d(lz_handle h, int N, int points, double T_factor, const double* weights4, const double* potential,
+                       int negate_T) {
+  if (!h) return LZ_ERR_ARG;
+  if (N < 3 || (points != 7 && points != 27) || !weights4) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d: need N >= 3, points in {7, 27}, 4 weights");
+  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_build_stencil3d: single-rank only");
+  const int64_t M = (int64_t)N * N * N, nnz = M * points;
+  if (nnz >= (int64_t)1 << 31) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d: nnz exceeds int32 CSR indexing");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  h->kind = 0;
+  LZ_TRY(dev_free(h, h->d_dense));
+  LZ_TRY(dev_free(h, h->d_V));
+  h->n = 0;
+  CsrDev& A = h->csr;
+  LZ_TRY(dev_alloc(h, A.rowptr, (size_t)M + 1));
+  LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
+  LZ_TRY(dev_alloc(h, A.vals, (size_t)nnz + 2));
+  LZ_HIP(h, hipMemsetAsync(A.colidx + nnz, 0, 2 * sizeof(int32_t), h->stream));
+  LZ_HIP(h, hipMemsetAsync(A.vals + nnz, 0, 2 * sizeof(double), h->stream));
+  double* dpot = nullptr;
+  if (potential) {
+    LZ_TRY(dev_alloc(h, dpot, (size_t)M));
+    LZ_HIP(h, hipMemcpyAsync(dpot, potential, (size_t)M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  launch_build_stencil3d(N, points, T_factor, weights4, negate_T, dpot, A.rowptr, A.colidx, A.vals, h->stream);
+  int rc = check_launch(h, "build_stencil3d");
+  hipError_t e = hipStreamSynchronize(h->stream);
+  if (dpot) hipFree(dpot);
+  if (rc != LZ_OK) return rc;
+  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_build_stencil3d: ") + hipGetErrorString(e));
+  std::vector<int32_t> rowptr((size_t)M + 1);
+  for (int64_t i = 0; i <= M; ++i) rowptr[(size_t)i] = (int32_t)(i * points);
+  return finish_csr(h, rowptr.data(), M, 0, M, M, nnz, points, points);
+}
+
+int lz_csr_info(lz_handle h, int64_t* rows, int64_t* nnz) {
+  if (!h || !rows || !nnz) return LZ_ERR_ARG;
+  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_csr_info: no CSR matrix set");
+  *rows = h->csr.rows;
+  *nnz = h->csr.nnz;
+  return LZ_OK;
+}
+
+int lz_get_csr(lz_handle h, int32_t* rowptr, int32_t* colidx, double* vals) {
+  if (!h || !rowptr || !colidx || !vals) return LZ_ERR_ARG;
+  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_get_csr: no CSR matrix set");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  const CsrDev& A = h->csr;
+  LZ_HIP(h, hipMemcpy(rowptr, A.rowptr, ((size_t)A.rows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  LZ_HIP(h, hipMemcpy(colidx, A.colidx, (size_t)A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+  LZ_HIP(h, hipMemcpy(vals, A.vals, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost));
   return LZ_OK;
 }
 

@@ -40,6 +40,8 @@ struct CsrDev {
 // y = A x (rows), part[b] = sum_{rows of block b} x_own[i] * y[i]; returns number of partials written
 int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
                     hipStream_t s);
+void launch_build_stencil3d(int N, int points, double tf, const double* w, int negate, const double* pot, int32_t* rowptr,
+                            int32_t* colidx, double* vals, hipStream_t s);
 int launch_gemv_dense(const double* A, int64_t M, const double* x, double* y, double* part, hipStream_t s);
 
 // out[0] = sum(part[0..n)) (fixed order)

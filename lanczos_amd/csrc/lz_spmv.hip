@@ -269,4 +269,65 @@ int launch_gemv_dense(const double* A, int64_t M, const double* x, double* y, do
   return grid;
 }
 
+// ------------------------------------------------------------------ stencil Hamiltonian assembly on the device
+// CSR of  sign * T_factor * Laplacian (+ diagonal potential)  on the reference's periodic N^3 grid
+// (Python/Regular/Hamiltonian.py:73-128): flat index x + y N + z N^2, neighbours wrap, 7-point weights
+// (-6, 1) or 27-point weights (centre, face, edge, corner) passed in `w` exactly as the host computed them.
+// One lane builds one row: P (column, value) pairs, insertion-sorted by column like SciPy's sort_indices.
+// Values follow SciPy's arithmetic of `-T + V`: t = T_factor * w; entry = sign * t (+ potential on the diagonal).
+template <int P>
+__global__ __launch_bounds__(kTPB) void k_build_stencil3d(int N, double tf, double w0, double w1, double w2, double w3,
+                                                         int negate, const double* __restrict__ pot,
+                                                         int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx,
+                                                         double* __restrict__ vals) {
+  const int64_t M = (int64_t)N * N * N;
+  const int64_t row = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  if (row > M) return;
+  if (row == M) {
+    rowptr[M] = (int32_t)(M * P);
+    return;
+  }
+  rowptr[row] = (int32_t)(row * P);
+  const int x = (int)(row % N), y = (int)((row / N) % N), z = (int)(row / ((int64_t)N * N));
+  int32_t c[P];
+  double v[P];
+  int cnt = 0;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int nz = (dx != 0) + (dy != 0) + (dz != 0);
+        if (P == 7 && nz > 1) continue;
+        const int xx = (x + dx + N) % N, yy = (y + dy + N) % N, zz = (z + dz + N) % N;
+        const int32_t col = (int32_t)(xx + (int64_t)yy * N + (int64_t)zz * N * N);
+        const double w = nz == 0 ? w0 : (nz == 1 ? w1 : (nz == 2 ? w2 : w3));
+        double t = tf * w;
+        if (negate) t = -t;
+        if (nz == 0 && pot) t = t + pot[row];
+        // insertion sort by column (P <= 27)
+        int k = cnt++;
+        while (k > 0 && c[k - 1] > col) {
+          c[k] = c[k - 1];
+          v[k] = v[k - 1];
+          --k;
+        }
+        c[k] = col;
+        v[k] = t;
+      }
+#pragma unroll 1
+  for (int k = 0; k < P; ++k) {
+    colidx[row * P + k] = c[k];
+    vals[row * P + k] = v[k];
+  }
+}
+
+void launch_build_stencil3d(int N, int points, double tf, const double* w, int negate, const double* pot, int32_t* rowptr,
+                            int32_t* colidx, double* vals, hipStream_t s) {
+  const int64_t M = (int64_t)N * N * N;
+  const unsigned grid = (unsigned)((M + 1 + kTPB - 1) / kTPB);
+  if (points == 7)
+    hipLaunchKernelGGL(k_build_stencil3d<7>, dim3(grid), dim3(kTPB), 0, s, N, tf, w[0], w[1], w[2], w[3], negate, pot, rowptr, colidx, vals);
+  else
+    hipLaunchKernelGGL(k_build_stencil3d<27>, dim3(grid), dim3(kTPB), 0, s, N, tf, w[0], w[1], w[2], w[3], negate, pot, rowptr, colidx, vals);
+}
+
 }  // namespace lz

@@ -135,6 +135,32 @@ def main():
     H.sort_indices()
     case("deuteron3d_N12_27pt_n100", H, 100, seed=78, keep_V=True)
 
+    # (iii-b) the reference's builder itself at N = 6: T (7- and 27-point), V, H - pins the device assembly kernel
+    N6 = 6
+    dx6 = 25.0 / N6
+    Tf6 = 197.327**2 / (2 * 469.4592) / dx6**2
+    ham6 = ref_hamiltonian.Hamiltonian(N6, 25, deuteron_potential, Tf6)
+    out = {"N": N6, "L": 25, "T_factor": Tf6, "weights_27point": ham6.weights_27point, "weights_7point": ham6.weights_7point,
+           "x": ham6.x}
+    for pts in ("7", "27"):
+        for f in ("T_matrices/T_N=6_Laplace=%s.npz" % pts,):
+            if os.path.exists(f):
+                os.unlink(f)
+        quiet(ham6.create_sparse_T, pts)
+        T = ham6.T_sparse.copy()
+        out["T%s_sorted_as_built" % pts] = bool(T.has_sorted_indices)
+        T.sort_indices()
+        out["T%s_rowptr" % pts], out["T%s_colidx" % pts], out["T%s_vals" % pts] = T.indptr, T.indices, T.data
+        quiet(ham6.create_sparse_V)
+        Hh = -ham6.T_sparse + ham6.V_sparse
+        Hh.sort_indices()
+        out["H%s_rowptr" % pts], out["H%s_colidx" % pts], out["H%s_vals" % pts] = Hh.indptr, Hh.indices, Hh.data
+    out["V_diag"] = ham6.V_sparse.diagonal()
+    out["neighbors_7_of_row_0"] = np.array(ham6.Laplacian_7point(0)[0])
+    out["neighbors_27_of_row_215"] = np.array(ham6.Laplacian_27point(215)[0])
+    np.savez_compressed(os.path.join(OUT, "hamiltonian_N6.npz"), **out)
+    print("hamiltonian_N6 fixture written; T sorted as built:", out["T7_sorted_as_built"], out["T27_sorted_as_built"])
+
     # (iv) 1Dbox.py:5-22 matrix, N = 500, n = 50 (dense there; wrapped as CSR for the CPU path)
     Nb = 500
     pot = np.zeros(Nb)
