@@ -39,6 +39,7 @@ WORKLOADS = {
     "lap2d_5pt_M1e7_k500": ("lap2d", (4000, 2500), 500),   # configs[4] (8 GPUs)
     "graph_M1e7_k200": ("graph", (10_000_000, 35_000_000), 200),  # configs[2]
     "lap2d_5pt_M1.25e6_k200": ("lap2d", (4000, 313), 200),  # one rank's share of the headline at N = 8 (compute floor)
+    "deuteron3d_N160_27pt_k400": ("deuteron27", (160,), 400),  # the reference's largest configured run (3Ddeuteron.py:63-95)
     "tiny": ("lap2d", (256, 128), 24),
 }
 
@@ -53,6 +54,15 @@ def build_local(kind, dims, lo, hi):
     if kind == "graph":
         full = synthetic.random_graph_laplacian(dims[0], dims[1], seed=1234)
         return full.row_slice(lo, hi)
+    if kind == "deuteron27":  # H = -T + V of 3Ddeuteron.py, assembled on the device by the Hamiltonian mirror
+        from lanczos_amd import Hamiltonian
+
+        N = dims[0]
+        Hamiltonian.verbose = False
+        Hamiltonian.vectorize_potential = True
+        ham = Hamiltonian(N, 25, synthetic.deuteron_potential, 197.327**2 / (2 * 469.4592) / (25.0 / N) ** 2)
+        H = ham.build_H("27")
+        return synthetic.CSR(H.indptr, H.indices, H.data, H.shape).row_slice(lo, hi)
     raise ValueError(kind)
 
 
@@ -65,7 +75,7 @@ def cpu_baseline(kind, dims, k, budget_s=40.0):
     from lanczos_amd import synthetic
     from oracle import lanczos_ref as oracle
 
-    M = int(np.prod(dims)) if kind != "graph" else dims[0]
+    M = dims[0] if kind == "graph" else (dims[0] ** 3 if kind == "deuteron27" else int(np.prod(dims)))
     avail = psutil.virtual_memory().available
     n_cpu = k
     while 3.3 * 8 * n_cpu * M > 0.6 * avail and n_cpu > 8:
@@ -156,7 +166,7 @@ def main():
     kind, dims, k = WORKLOADS[args.workload]
     if args.k:
         k = args.k
-    M = int(np.prod(dims)) if kind != "graph" else dims[0]
+    M = dims[0] if kind == "graph" else (dims[0] ** 3 if kind == "deuteron27" else int(np.prod(dims)))
     bounds = partition.row_bounds(M, world)
     lo, hi = bounds[rank], bounds[rank + 1]
 

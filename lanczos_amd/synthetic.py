@@ -20,6 +20,7 @@ __all__ = [
     "laplacian_3d_7pt",
     "random_graph_laplacian",
     "dense_symmetric",
+    "deuteron_potential",
     "reference_start_vector",
 ]
 
@@ -119,6 +120,13 @@ def dense_symmetric(M, seed=0):
     """Config C1: ``A = standard_normal((M, M)); (A + A.T) / 2`` with ``default_rng(seed)``."""
     A = np.random.default_rng(seed).standard_normal((M, M))
     return (A + A.T) / 2
+
+
+def deuteron_potential(x, y, z):
+    """The potential of the reference's deuteron drivers (constants of 3Ddeuteron.py:51-61): hard core + well."""
+    r = np.sqrt(x**2 + y**2 + z**2)
+    eWell = 54.531
+    return 40.0 * eWell * np.exp(-((r / 0.25) ** 4.0)) - 65.4823128982115 * np.exp(-((r / 1.7) ** 4.0))
 
 
 def reference_start_vector(M, seed=99):
