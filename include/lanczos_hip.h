@@ -49,7 +49,12 @@ enum lz_flags {
   LZ_FLAG_QTW_VALU = 4,       /* force the VALU/shuffle Q^T w kernel                      */
   LZ_FLAG_SPMV_SCALAR = 8,    /* force the plain one-thread-per-row CSR kernel            */
   LZ_FLAG_FUSED_NORM = 16,    /* multi-rank only: fold ||r||^2 into the Q^T r all-reduce   */
-  LZ_FLAG_SPMV_STREAM = 32    /* force the generic CSR-stream kernel (no fixed-K fast path) */
+  LZ_FLAG_SPMV_STREAM = 32,   /* force the generic CSR-stream kernel (no fixed-K fast path) */
+  LZ_FLAG_REORTH_PARTIAL = 64 /* opt-in: partial re-orthogonalisation (Simon 1984).  The reference sweeps the whole basis
+                                 every step; with this flag the sweep (same kernels, same arithmetic) runs only when the
+                                 omega-recurrence estimate of the loss of orthogonality exceeds sqrt(eps), on that and the
+                                 next step.  The basis stays semi-orthogonal (<= sqrt(eps)), which keeps T - and so the
+                                 Ritz values - within O(eps ||A||) of the full-sweep run; V itself differs at that level. */
 };
 
 /* kernel classes reported by lz_get_timings */
@@ -172,6 +177,8 @@ int lz_ritz_gram(lz_handle h, double* gram_out);
  * out[i] = (A y_i . y_i)^2 / (||A y_i||^2), for all n columns. */
 int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
+/* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
+int lz_last_sweeps(lz_handle h, int* sweeps);
 
 /* ---- single steps (unit parity tests drive the kernels one by one) ------ */
 /* allocate a zeroed basis of n rows + r (what lz_run does first, Lanczos.py:104-107) */

@@ -7,12 +7,12 @@ Drop-in for the ``Lanczos`` / ``IrrLanczos`` classes of jgslunde/Lanczos
 re-orthogonalisation) and the Ritz back-transform run as hand-written HIP
 kernels in ``liblanczos_hip.so``, reached through ctypes - no PyTorch.
 """
-from ._capi import (FLAG_FUSED_NORM, FLAG_PROFILE, FLAG_QTW_MFMA, FLAG_QTW_VALU, FLAG_SPMV_SCALAR, LanczosHipError,
+from ._capi import (FLAG_FUSED_NORM, FLAG_REORTH_PARTIAL, FLAG_PROFILE, FLAG_QTW_MFMA, FLAG_QTW_VALU, FLAG_SPMV_SCALAR, LanczosHipError,
                     load_library)
 from .hamiltonian import Hamiltonian
 from .irregular import IrrLanczos
 from .regular import Lanczos
 
 __all__ = ["Lanczos", "IrrLanczos", "Hamiltonian", "LanczosHipError", "load_library", "FLAG_PROFILE", "FLAG_QTW_MFMA", "FLAG_QTW_VALU",
-           "FLAG_SPMV_SCALAR", "FLAG_FUSED_NORM"]
+           "FLAG_SPMV_SCALAR", "FLAG_FUSED_NORM", "FLAG_REORTH_PARTIAL"]
 __version__ = "0.1.0"

@@ -24,6 +24,7 @@ FLAG_QTW_VALU = 4
 FLAG_SPMV_SCALAR = 8
 FLAG_FUSED_NORM = 16
 FLAG_SPMV_STREAM = 32
+FLAG_REORTH_PARTIAL = 64
 
 KERNEL_CLASSES = ("spmv", "qtw", "update", "three_term", "final", "comm", "ritz")
 K_COUNT = len(KERNEL_CLASSES)
@@ -82,6 +83,7 @@ SIGNATURES = {
     "lz_ritz_gram": (C.c_int, [_P, _D]),
     "lz_ritz_quality": (C.c_int, [_P, _D]),
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
+    "lz_last_sweeps": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_basis_alloc": (C.c_int, [_P, C.c_int]),
     "lz_basis_set_row": (C.c_int, [_P, C.c_int, _D]),
     "lz_basis_get_row": (C.c_int, [_P, C.c_int, _D]),
@@ -340,6 +342,11 @@ class Handle:
         q = np.empty(self.n)
         self.check(self.lib.lz_ritz_quality(self._h, dptr(q)))
         return q
+
+    def last_sweeps(self):
+        k = C.c_int()
+        self.check(self.lib.lz_last_sweeps(self._h, C.byref(k)))
+        return k.value
 
     def timings(self):
         t = LzTimings()

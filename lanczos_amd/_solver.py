@@ -54,6 +54,8 @@ class LanczosBase:
     verbose = True  # the reference prints "+++ ..." progress lines; set False to silence
     device_id = 0
     options = 0     # lz_flags forwarded to lz_set_options (see include/lanczos_hip.h)
+    reorth = "full"  # "full" = the reference's sweep at every step; "partial" = opt-in Simon partial
+                     # re-orthogonalisation (same sweep kernels, run only when semi-orthogonality is about to be lost)
     _check_eigs = ("normalized", "orthogonal")  # which asserts get_H_eigs runs (Lanczos.py:157-158)
 
     def __init__(self, H):
@@ -149,13 +151,16 @@ class LanczosBase:
         if self._handle is None:
             self._handle = _capi.Handle(self.device_id)
         h = self._handle
-        h.set_options(self.options)
+        if self.reorth not in ("full", "partial"):
+            raise ValueError("reorth must be 'full' or 'partial'")
+        h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0))
         if packed[0] == "csr":
             h.set_csr(M, 0, packed[1], packed[2], packed[3])
         else:
             h.set_dense(packed[1])
         alpha, beta = h.run(n, v0)
         self._timings = h.timings()
+        self.sweeps = h.last_sweeps()  # steps that ran the re-orthogonalisation sweep (== n for reorth="full")
 
         # H_eff (Lanczos.py:121-130): symmetric tridiagonal, assembled on the host from 2n-1 doubles
         H_eff = np.zeros((n, n))

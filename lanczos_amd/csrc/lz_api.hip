@@ -124,6 +124,7 @@ struct lz_context {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
   hipEvent_t run_a = nullptr, run_b = nullptr;
   bool run_timed = false;
+  int last_sweeps = 0;
   bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
   lz_timings acc;
 };
@@ -350,7 +351,7 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx) {
   const double M = (double)h->rows;
   // fused-norm mode (multi-rank): one all-reduce carries [V_i . r (i < j), r . r]; beta and the scaling by
   // 1/beta are applied afterwards.  Only valid for the in-loop call shape (row j is the newest row).
-  const bool fused = scale && (h->flags & LZ_FLAG_FUSED_NORM) && nrows == j + 1;
+  const bool fused = scale && (h->flags & LZ_FLAG_FUSED_NORM) && !(h->flags & LZ_FLAG_REORTH_PARTIAL) && nrows == j + 1;
   {
     Scope sc(h, LZ_K_QTW, 8.0 * (nrows - 1) * M + (scale && !fused ? 16.0 : 8.0) * M, 2.0 * nrows * M);
     launch_qtw(h->d_V, h->ldv, h->rows_pad, nrows, j, scale ? h->d_r : nullptr, h->d_nrm2, h->d_beta + beta_idx, h->qplan,
@@ -931,17 +932,80 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
   // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
   LZ_TRY(step_spmv(h, 0));
-  const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0;
+  const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL);
   LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
   const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+  const bool partial = (h->flags & LZ_FLAG_REORTH_PARTIAL) != 0;
+  // Partial re-orthogonalisation (opt-in): Simon's omega-recurrence on the host, fed with alpha_j and beta_{j+1}
+  // (two doubles copied back per step).  omega_{j,k} estimates v_j . v_k; a sweep is due when it exceeds sqrt(eps).
+  const double eps = 2.220446049250313e-16, thresh = 1.4901161193847656e-08;
+  std::vector<double> w_prev, w_cur, w_new, ha, hb;  // omega_{j-2,:}, omega_{j-1,:}, omega_{j,:}; alpha_k; beta_k (norm forming V[k])
+  if (partial) {
+    w_prev.assign((size_t)n + 1, 0.0);
+    w_cur.assign((size_t)n + 1, 0.0);
+    w_new.assign((size_t)n + 1, 0.0);
+    ha.assign((size_t)n + 1, 0.0);
+    hb.assign((size_t)n + 1, 0.0);
+    double nrm2 = 0.0;
+    LZ_HIP(h, hipMemcpyAsync(&nrm2, h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    hb[0] = std::sqrt(nrm2);
+  }
+  bool force_next = false;
+  double normA = 0.0;
+  int sweeps = 0;
   for (int j = 0; j < n; ++j) {
     h->prof_iter = (j % pstride) == pstride / 2;  // centred sample: same mean j as the full run
     const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
-    LZ_TRY(step_reorth(h, j, j + 1, true, bidx));
+    bool sweep = true;
+    if (partial) {
+      bool due = false;
+      if (j >= 1) {
+        // beta_j omega_{j,k} = beta_{k+1} omega_{j-1,k+1} + (alpha_k - alpha_{j-1}) omega_{j-1,k} + beta_k omega_{j-1,k-1}
+        //                      - beta_{j-1} omega_{j-2,k}  (+ rounding of size eps ||A||),   k <= j-2
+        std::fill(w_new.begin(), w_new.end(), 0.0);
+        w_new[(size_t)j] = 1.0;
+        w_new[(size_t)j - 1] = eps;
+        double worst = 0.0;
+        for (int k = 0; k + 2 <= j; ++k) {
+          double t = hb[(size_t)k + 1] * w_cur[(size_t)k + 1] + (ha[(size_t)k] - ha[(size_t)j - 1]) * w_cur[(size_t)k] -
+                     hb[(size_t)j - 1] * w_prev[(size_t)k];
+          if (k > 0) t += hb[(size_t)k] * w_cur[(size_t)k - 1];
+          t += (t < 0 ? -1.0 : 1.0) * 2.0 * eps * normA;
+          w_new[(size_t)k] = t / hb[(size_t)j];
+          worst = std::max(worst, std::fabs(w_new[(size_t)k]));
+        }
+        due = worst > thresh;
+        std::swap(w_prev, w_cur);
+        std::swap(w_cur, w_new);
+      }
+      sweep = (j == 0) || due || force_next;  // a due sweep also covers the next vector (both feed the recurrence)
+      force_next = due;
+      if (sweep)
+        for (int k = 0; k < j; ++k) w_cur[(size_t)k] = eps;
+    }
+    if (sweep) {
+      ++sweeps;
+      LZ_TRY(step_reorth(h, j, j + 1, true, bidx));
+    } else {
+      Scope sc(h, LZ_K_QTW, 16.0 * (double)h->rows, (double)h->rows);
+      launch_scale_store(h->d_V + (int64_t)j * h->ldv, h->d_r, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream);
+      LZ_TRY(check_launch(h, "scale_store"));
+    }
     LZ_TRY(step_spmv(h, j));
     // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
-    LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, !fused));
+    LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, !fused || partial));
+    if (partial) {
+      double two[2] = {0.0, 0.0};
+      LZ_HIP(h, hipMemcpyAsync(&two[0], h->d_alpha + j, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      LZ_HIP(h, hipMemcpyAsync(&two[1], h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      LZ_HIP(h, hipStreamSynchronize(h->stream));
+      ha[(size_t)j] = two[0];
+      hb[(size_t)j + 1] = std::sqrt(two[1]);
+      normA = std::max(normA, std::fabs(two[0]) + hb[(size_t)j] + hb[(size_t)j + 1]);
+    }
   }
+  h->last_sweeps = sweeps;
   h->prof_iter = true;
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
   const double t3 = now();
@@ -1066,6 +1130,12 @@ int lz_ritz_quality(lz_handle h, double* out) {
   if (rc != LZ_OK) return rc;
   if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
   for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];
+  return LZ_OK;
+}
+
+int lz_last_sweeps(lz_handle h, int* sweeps) {
+  if (!h || !sweeps) return LZ_ERR_ARG;
+  *sweeps = h->last_sweeps;
   return LZ_OK;
 }
 

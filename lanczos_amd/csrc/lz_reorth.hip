@@ -434,6 +434,28 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
     hipLaunchKernelGGL((k_update<false, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
 }
 
+// partial re-orthogonalisation mode, steps without a sweep: V[j] = r / sqrt(nrm2) and nothing else
+__global__ __launch_bounds__(kTPB) void k_scale_store(double* __restrict__ vj, const double* __restrict__ r,
+                                                     const double* __restrict__ nrm2, double* __restrict__ beta_slot, int64_t n2) {
+  const double beta = sqrt(nrm2[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) beta_slot[0] = beta;
+  const double2* r2 = reinterpret_cast<const double2*>(r);
+  double2* v2 = reinterpret_cast<double2*>(vj);
+  for (int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kTPB) {
+    double2 x = r2[i];
+    x.x = x.x / beta;
+    x.y = x.y / beta;
+    v2[i] = x;
+  }
+}
+void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s) {
+  const int64_t n2 = len >> 1;
+  int64_t g = (n2 + kTPB - 1) / kTPB;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_scale_store, dim3((int)g), dim3(kTPB), 0, s, vj, r, nrm2, beta_slot, n2);
+}
+
 // fused-norm mode: c holds the all-reduced [V_0.r, ..., V_{j-1}.r, r.r]; turn it into the coefficients of
 // w = r / beta:  beta = sqrt(r.r), c_i /= beta, c_j = (r.r) / beta^2
 __global__ void k_fused_prepare(double* __restrict__ c, int j, double* __restrict__ beta_slot) {

@@ -244,3 +244,40 @@ def test_headline_full_size_properties():
     s2 = Lanczos(H)
     s2.execute_Lanczos(n)
     assert np.array_equal(H_eff, s2.H_eff)
+
+
+@pytest.mark.parametrize(
+    "build,n",
+    [
+        (lambda: synthetic.laplacian_2d_5pt(300, 200).to_scipy(), 200),      # nothing converges: almost no sweeps
+        (lambda: synthetic.laplacian_3d_7pt(20, 18, 16).to_scipy(), 150),    # Ritz values converge: sweeps are needed
+        (lambda: load_golden("box1d_N500_n50")[1], 50),
+        (lambda: load_golden("deuteron3d_N12_27pt_n100")[1], 100),
+    ],
+)
+def test_partial_reorthogonalisation_opt_in(build, n):
+    """LZ_FLAG_REORTH_PARTIAL (opt-in; the reference only has the full sweep): same sweep kernels, run only when the
+    omega-recurrence says semi-orthogonality (sqrt(eps)) is about to be lost.  Converged/stable Ritz values must equal
+    the full-sweep run's to 1e-10 and the basis must stay semi-orthogonal."""
+    H = build()
+    Lanczos.verbose = False
+    full = Lanczos(H)
+    full.execute_Lanczos(n)
+    part = Lanczos(H)
+    part.reorth = "partial"
+    part.execute_Lanczos(n)
+    assert full.sweeps == n and 1 <= part.sweeps < n
+    scale = np.abs(full.H_eigvals).max()
+    conv = oracle.converged_ritz(np.diag(full.H_eff), np.diag(full.H_eff, 1), tol=1e-9)
+    th_p = np.linalg.eigvalsh(part.H_eff)
+    if len(conv):
+        assert np.abs(th_p[None, :] - conv[:, None]).min(axis=1).max() <= RTOL * scale
+    a_f, b_f = np.diag(full.H_eff), np.diag(full.H_eff, 1)
+    prefix, mask = oracle.stable_masks(H, n, a_f, b_f)
+    if prefix == n:  # well-conditioned run: every Ritz value is determined
+        assert np.abs(th_p - full.H_eigvals).max() <= RTOL * scale
+    V = part.V
+    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-6  # semi-orthogonal (sqrt(eps) level), not eps like the full sweep
+    # a sweep removes components of size <= sqrt(eps) from v_j, so A V = V T + ... holds to that level (not eps)
+    R = H @ V - V @ part.H_eff
+    assert np.abs(R[:, :-1]).max() < 1e-6 * max(scale, 1.0)
