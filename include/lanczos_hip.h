@@ -45,8 +45,8 @@ enum lz_status {
 enum lz_flags {
   LZ_FLAG_NONE = 0,
   LZ_FLAG_PROFILE = 1,        /* bracket every hot kernel with hipEvents (lz_get_timings) */
-  LZ_FLAG_QTW_MFMA = 2,       /* use the MFMA (v_mfma_f64_16x16x4_f64) Q^T w kernel        */
-  LZ_FLAG_QTW_VALU = 4,       /* force the VALU/shuffle Q^T w kernel                      */
+  LZ_FLAG_QTW_MFMA = 2,       /* A/B arm: the v_mfma_f64_16x16x4_f64 Q^T w kernel (default is the 4x4x4 MFMA kernel) */
+  LZ_FLAG_QTW_VALU = 4,       /* A/B arm: the VALU + wave-shuffle Q^T w kernel                                       */
   LZ_FLAG_SPMV_SCALAR = 8,    /* force the plain one-thread-per-row CSR kernel            */
   LZ_FLAG_FUSED_NORM = 16,    /* multi-rank only: fold ||r||^2 into the Q^T r all-reduce   */
   LZ_FLAG_SPMV_STREAM = 32,   /* force the generic CSR-stream kernel (no fixed-K fast path) */

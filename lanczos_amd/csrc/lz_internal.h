@@ -54,6 +54,7 @@ struct QtwPlan {
   int G = 0;        // number of blocks
   int P = 0;        // partials per basis row (G for the VALU kernel, 4G for the MFMA kernel)
   bool mfma = false;
+  int family = 2;   // 2 = 4x4x4 MFMA (default), 1 = 16x16x4 MFMA, 0 = VALU
   int variant = 0;  // A/B knob (unroll / rows per tile)
 };
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune);

@@ -304,6 +304,72 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
   }
 }
 
+// MFMA variant 2: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction).  Lane layout measured on
+// gfx950 (tools/probes/mfma_f64_4x4x4_layout.hip): A[blk][i][k] lives in lane 16k + 4blk + i, B[blk][k][j] in lane
+// 16k + 4blk + j, D[blk][i][j] in lane 16i + 4blk + j.  Here the 4 blocks are four adjacent 64-byte chunks of the SAME
+// four basis rows, so one wave-load covers 4 rows x 256 contiguous bytes (whole 128-byte lines, like the VALU kernel)
+// instead of the 16 rows x 64 bytes the 16x16x4 shape forces.  B = the matching w entries broadcast over j; the four
+// block results of a row are added with two cross-lane steps once per tile.  No barrier in the main loop.
+template <int SCALE, int U, int T>
+__global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
+                                                   const double* __restrict__ r, const double* __restrict__ nrm2,
+                                                   double* __restrict__ beta_slot, int64_t L, int P,
+                                                   double* __restrict__ part) {
+  extern __shared__ double2 sw[];
+  const int64_t base = (int64_t)blockIdx.x * L;
+  const int cnt = (int)(len - base < L ? len - base : L);
+  double self = qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
+  self = wave_sum(self);  // this wave's share of w.w (lane 0); replaces the streamed row-j result below
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int li = lane & 3, blk = (lane >> 2) & 3, lk = lane >> 4;
+  const int sub = (int)(L >> 2);  // elements per wave (multiple of 128)
+  const int m_lo = w * sub;
+  int m_hi = m_lo + sub;
+  if (m_hi > cnt) m_hi = cnt;
+  const int nsteps = m_hi > m_lo ? (m_hi - m_lo) >> 5 : 0;  // 32 elements (256 B per row) per step
+  const int pid = blockIdx.x * (kTPB / 64) + w;
+  const int eoff = 8 * blk + 2 * lk;                          // this lane's double2 within a step
+  const double2* swl = sw + ((m_lo + eoff) >> 1);            // + 16 per step
+  for (int i0 = ((nrows - 1) / (4 * T)) * (4 * T); i0 >= 0; i0 -= 4 * T) {
+    const double2* a[T];
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      int i = i0 + 4 * t + li;
+      if (i >= nrows) i = nrows - 1;  // clamped duplicate, discarded at the store
+      if (i == j) i = j > 0 ? j - 1 : (nrows > 1 ? 1 : 0);  // row j is w itself: its coefficient comes from `self`
+      a[t] = reinterpret_cast<const double2*>(V + (int64_t)i * ldv + base + m_lo + eoff);
+      acc[t] = 0.0;
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+      double2 av[T][U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < T; ++t) av[t][u] = (s0 + u < nsteps) ? ld_stream<1>(a[t] + 16 * (s0 + u)) : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double2 bv = (s0 + u < nsteps) ? swl[16 * (s0 + u)] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].x, bv.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].y, bv.y, acc[t], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      double v = acc[t];                 // D[blk][i][jj] in lane 16 i + 4 blk + jj
+      v += __shfl_xor(v, 4, 64);         // add the four blocks (adjacent 64-byte chunks)
+      v += __shfl_xor(v, 8, 64);
+      const int row = i0 + 4 * t + lk;   // lane 16 i (+0) holds row i
+      if ((lane & 15) == 0 && row < nrows && row != j) part[(int64_t)row * P + pid] = v;
+    }
+  }
+  if (lane == 0 && j < nrows) part[(int64_t)j * P + pid] = self;  // c_j = w.w from the LDS-resident values
+}
+
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   QtwPlan p;
   int64_t target = (tune && tune[0] > 0) ? tune[0] : 0;
@@ -318,7 +384,10 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   if (L > kQtwMaxL) L = kQtwMaxL;
   p.L = L;
   p.G = (int)((len + L - 1) / L);
-  p.mfma = (flags & LZ_FLAG_QTW_MFMA) != 0 && (flags & LZ_FLAG_QTW_VALU) == 0;
+  // kernel family: 2 = 4x4x4 MFMA (default: matrix cores, line-coalesced loads), 1 = 16x16x4 MFMA (A/B arm),
+  // 0 = VALU + shuffle reductions (LZ_FLAG_QTW_VALU)
+  p.family = (flags & LZ_FLAG_QTW_VALU) ? 0 : ((flags & LZ_FLAG_QTW_MFMA) ? 1 : 2);
+  p.mfma = p.family != 0;
   p.variant = tune ? tune[1] : 0;
   p.P = (p.mfma || p.variant == 8 || p.variant == 9) ? p.G * (kTPB / 64) : p.G;
   return p;
@@ -330,12 +399,22 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
   const size_t lds = (size_t)plan.L * sizeof(double);
   const dim3 grid(plan.G), block(kTPB);
 #define LZ_QTW_ARGS V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, plan.P, part
+  if (plan.family == 2) {
+    switch (plan.variant) {
+      case 10: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 11: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 2, 8>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 13: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      default:  // measured best (profiles/r01/ab_qtw_mfma4.json): 2 tiles of 4 rows x 4 steps = 8 loads in flight per lane
+        hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS);
+        break;
+    }
+    return;
+  }
   if constexpr (SCALE != 2) {
-    if (plan.mfma) {
+    if (plan.family == 1) {
       switch (plan.variant) {
         case 1: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
         case 2: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 16, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-        case 3: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
         case 4: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
         default: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
       }

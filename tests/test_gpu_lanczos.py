@@ -52,7 +52,10 @@ def test_golden(name):
     assert s.V.shape == (int(d["M"]), n) and s.H_eigvecs.shape == (int(d["M"]), n)
     if "V" in d:
         # Lanczos vectors are only determined up to the growth of rounding differences; compare the projector
-        assert np.abs(s.V.T @ s.V - np.eye(n)).max() < 1e-12
+        # single-pass Gram-Schmidt loses orthogonality like eps/beta when beta collapses (Krylov space exhausted):
+        # hold the device basis to the reference's own level on this fixture
+        ref_orth = np.abs(d["V"] @ d["V"].T - np.eye(n)).max()
+        assert np.abs(s.V.T @ s.V - np.eye(n)).max() < max(1e-12, 100 * ref_orth)
         np.testing.assert_allclose(s.V[:, : min(prefix, 10)], d["V"][: min(prefix, 10)].T, rtol=0, atol=1e-9)
     # same checks get_H_eigs ran in the reference
     assert abs(Lanczos.test_is_normalized(s.H_eigvecs, no_assert=True) - float(d["norm_closest_to_1"])) < 1e-9
@@ -148,9 +151,10 @@ def test_error_surface_on_device():
     assert ritz_close(s.H_eigvals, d["H_eigvals"])
 
 
-@pytest.mark.parametrize("flags", [2, 16, 32, 8])
+@pytest.mark.parametrize("flags", [2, 4, 16, 4 | 16, 32, 8])
 def test_kernel_variants_agree(flags):
-    """MFMA Q^T w (2), fused-norm (16), generic CSR-stream (32) and scalar SpMV (8) arms against the default path."""
+    """16x16x4-MFMA (2) and VALU (4) Q^T w arms, fused-norm (16, also with VALU), generic CSR-stream (32) and scalar
+    SpMV (8) arms against the default path (4x4x4-MFMA Q^T w, fixed-K SpMV)."""
     from lanczos_amd import _capi
 
     A = synthetic.laplacian_2d_5pt(300, 200)
