@@ -422,7 +422,9 @@ int finish_csr(lz_handle h, const int32_t* rowptr_host, int64_t M_global, int64_
   CsrDev& A = h->csr;
   std::vector<int32_t> blk;
   int rows_cap = h->tune[2] > 0 ? h->tune[2] : 512;
-  int nnz_cap = h->tune[4] > 0 ? h->tune[4] : 4096;
+  // One batch of the CSR-stream kernel covers 2048 entries (256 lanes x 4 steps x 2): for long rows (27-point
+  // stencils) a tile of exactly one batch is fastest (profiles/r01/ab_spmv_27pt_tile.json); short ragged rows keep 4096.
+  int nnz_cap = h->tune[4] > 0 ? h->tune[4] : ((double)nnz / (double)rows_local >= 12.0 ? 2048 : 4096);
   if (nnz_cap > 16384) nnz_cap = 16384;
   build_rowblocks(rowptr_host, rows_local, rows_cap, nnz_cap, blk);
   A.blk_nnz_cap = nnz_cap;

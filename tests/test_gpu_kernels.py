@@ -51,11 +51,15 @@ def test_spmv_bit_exact(hip, name, flags):
     x = np.random.default_rng(1).uniform(-1, 1, M)
     y = h.spmv_host(x)
     ref = H * x
-    if name == "longrow_9000" and flags in (0, 32):
-        long_rows = np.diff(H.indptr) > 4096
+    # rows longer than the CSR-stream tile (2048 entries when rows average >= 12 entries, else 4096) get a block of
+    # their own with a block-wide (not sequential) reduction: tolerance instead of bit-exactness for those rows
+    cap = 2048 if H.nnz / M >= 12 else 4096
+    long_rows = np.diff(H.indptr) > cap
+    if long_rows.any() and flags in (0, 32):
         assert long_rows.sum() == 1
         assert np.array_equal(y[~long_rows], ref[~long_rows])
-        np.testing.assert_allclose(y[long_rows], ref[long_rows], rtol=0, atol=1e-13 * np.abs(H[100]).dot(np.abs(x)).max())
+        i = int(np.flatnonzero(long_rows)[0])
+        np.testing.assert_allclose(y[long_rows], ref[long_rows], rtol=0, atol=1e-13 * np.abs(H[i]).dot(np.abs(x)).max())
     else:
         assert np.array_equal(y, ref), f"max diff {np.abs(y - ref).max()}"
     h.close()

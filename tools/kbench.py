@@ -26,8 +26,25 @@ def main():
     ap.add_argument("--arms", default="valu:0:")
     ap.add_argument("--what", default="reorth,spmv,three")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--matrix", default="lap2d", help="lap2d | lap3d:N | deuteron27:N | graph:M")
     args = ap.parse_args()
-    A = synthetic.laplacian_2d_5pt(args.nx, args.ny)
+    if args.matrix.startswith("lap3d:"):
+        N = int(args.matrix.split(":")[1])
+        A = synthetic.laplacian_3d_7pt(N, N, N)
+    elif args.matrix.startswith("deuteron27:"):
+        from lanczos_amd import Hamiltonian
+
+        N = int(args.matrix.split(":")[1])
+        Hamiltonian.verbose = False
+        Hamiltonian.vectorize_potential = True
+        os.chdir("/tmp")
+        Hs = Hamiltonian(N, 25, synthetic.deuteron_potential, 197.327**2 / (2 * 469.4592) / (25.0 / N) ** 2).build_H("27")
+        A = synthetic.CSR(Hs.indptr, Hs.indices, Hs.data, Hs.shape)
+    elif args.matrix.startswith("graph:"):
+        Mg = int(args.matrix.split(":")[1])
+        A = synthetic.random_graph_laplacian(Mg, int(3.5 * Mg), seed=1234)
+    else:
+        A = synthetic.laplacian_2d_5pt(args.nx, args.ny)
     M = A.shape[0]
     rng = np.random.default_rng(0)
     arms = []
