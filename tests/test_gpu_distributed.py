@@ -29,12 +29,15 @@ WORKER = textwrap.dedent('''
     cases = [("lap2d", lambda lo, hi: synthetic.laplacian_2d_5pt(96, 80, rows=(lo, hi)), 96 * 80, "auto", 40),
              ("lap3d", lambda lo, hi: synthetic.laplacian_3d_7pt(24, 20, 18, rows=(lo, hi)), 24 * 20 * 18, "halo", 30),
              ("graph", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 30),
-             ("graph_halo", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "halo", 30)]
+             ("graph_halo", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "halo", 30),
+             ("lap3d_partial", lambda lo, hi: synthetic.laplacian_3d_7pt(20, 18, 16, rows=(lo, hi)), 20 * 18 * 16, "halo", 120)]
     for name, build, M, mode, n in cases:
         b = partition.row_bounds(M, boot.world)
         lo, hi = b[boot.rank], b[boot.rank + 1]
-        s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode, fused_norm=(name != "lap3d"))
+        opts = 64 if name.endswith("_partial") else 0  # LZ_FLAG_REORTH_PARTIAL: every rank must take the same sweep decisions
+        s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode, fused_norm=(name != "lap3d"), options=opts)
         a, bta = s.execute_Lanczos(n)
+        sweeps = s.h.last_sweeps()
         theta = s.get_H_eigs()
         V = s.V_local
         Y = s.H_eigvecs_local
@@ -46,7 +49,7 @@ WORKER = textwrap.dedent('''
         out[name] = dict(mode=s.plan.mode, da=float(np.abs(a - ao).max()), db=float(np.abs(bta - bo).max()),
                          dth=float(np.abs(theta - th_o).max() / np.abs(th_o).max()),
                          dV=float(np.abs(V[:, :8] - Vo[:8, lo:hi].T).max()), dY=float(np.abs(Y - V @ S).max()),
-                         comm_launches=s.timings()["comm"]["launches"])
+                         comm_launches=s.timings()["comm"]["launches"], sweeps=sweeps, n=n)
     res = boot.allgather_obj(out)
     if boot.rank == 0:
         print("RESULT", res)
@@ -71,8 +74,13 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
         assert per_rank["lap2d"]["mode"] == "halo" and per_rank["lap3d"]["mode"] == "halo"
         assert per_rank["graph"]["mode"] == "allgather" and per_rank["graph_halo"]["mode"] == "halo"
         for name, r in per_rank.items():
+            if name.endswith("_partial"):
+                # converging run with sweeps: Ritz values of the partial mode vs the oracle's full sweep
+                assert 1 <= r["sweeps"] < r["n"] and r["dth"] < 1e-10 and r["dY"] < 1e-12, (name, r)
+                assert r["sweeps"] == res[0][name]["sweeps"]
+                continue
             assert r["da"] < 1e-11 and r["db"] < 1e-11 and r["dth"] < 1e-10 and r["dV"] < 1e-9 and r["dY"] < 1e-12, (name, r)
-            assert r["comm_launches"] > 0
+            assert r["comm_launches"] > 0 and r["sweeps"] == r["n"]
 
 
 def test_rccl_single_rank_communicator():
