@@ -125,6 +125,7 @@ struct lz_context {
   hipEvent_t run_a = nullptr, run_b = nullptr;
   bool run_timed = false;
   int last_sweeps = 0;
+  double* h_pinned = nullptr;  // 8 pinned doubles for the per-step scalar read-back of the partial-reorth mode
   bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
   lz_timings acc;
 };
@@ -519,6 +520,7 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_send_idx);
   hipFree(h->d_sendbuf);
   hipFree(h->d_xfull);
+  if (h->h_pinned) hipHostFree(h->h_pinned);
   for (auto& e : h->events) {
     hipEventDestroy(e.a);
     hipEventDestroy(e.b);
@@ -943,6 +945,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   const double eps = 2.220446049250313e-16, thresh = 1.4901161193847656e-08;
   std::vector<double> w_prev, w_cur, w_new, ha, hb;  // omega_{j-2,:}, omega_{j-1,:}, omega_{j,:}; alpha_k; beta_k (norm forming V[k])
   if (partial) {
+    if (!h->h_pinned) LZ_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), 8 * sizeof(double), hipHostMallocDefault));
     w_prev.assign((size_t)n + 1, 0.0);
     w_cur.assign((size_t)n + 1, 0.0);
     w_new.assign((size_t)n + 1, 0.0);
@@ -998,7 +1001,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
     LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, !fused || partial));
     if (partial) {
-      double two[2] = {0.0, 0.0};
+      double* two = h->h_pinned;
       LZ_HIP(h, hipMemcpyAsync(&two[0], h->d_alpha + j, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       LZ_HIP(h, hipMemcpyAsync(&two[1], h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       LZ_HIP(h, hipStreamSynchronize(h->stream));
