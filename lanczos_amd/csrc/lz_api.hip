@@ -113,6 +113,8 @@ struct lz_context {
   int xmode = 0;  // 0 none, 1 halo, 2 allgather
   std::vector<int32_t> peers;
   std::vector<int64_t> scount, rcount, soff, roff;
+  std::vector<int64_t> sstart;  // >= 0: the peer's send list is the contiguous run x[sstart .. sstart+scount) (stencil faces)
+  bool all_contig = false;
   int64_t total_send = 0, total_recv = 0;
   int32_t* d_send_idx = nullptr;
   double* d_sendbuf = nullptr;
@@ -266,14 +268,18 @@ int comm_exchange_x(lz_handle h, int j, const double** x_out) {
   if (h->xmode == 1) {
     if (h->peers.empty()) return LZ_OK;
     Scope sc(h, LZ_K_COMM, 8.0 * (h->total_send + h->total_recv), 0);
-    launch_gather(vj, h->d_send_idx, h->total_send, h->d_sendbuf, h->stream);
-    LZ_TRY(check_launch(h, "gather"));
+    const bool direct = h->all_contig && h->comm_kind == 1;  // contiguous faces are sent straight out of V[j]
+    if (!direct) {
+      launch_gather(vj, h->d_send_idx, h->total_send, h->d_sendbuf, h->stream);
+      LZ_TRY(check_launch(h, "gather"));
+    }
     double* ghost = vj + h->rows_pad;
     if (h->comm_kind == 1) {
       LZ_NCCL(h, g_rccl.GroupStart());
       for (size_t p = 0; p < h->peers.size(); ++p) {
+        const double* src = direct ? vj + h->sstart[p] : h->d_sendbuf + h->soff[p];
         if (h->scount[p] > 0)
-          LZ_NCCL(h, g_rccl.Send(h->d_sendbuf + h->soff[p], (size_t)h->scount[p], ncclDouble, h->peers[p], h->comm, h->stream));
+          LZ_NCCL(h, g_rccl.Send(src, (size_t)h->scount[p], ncclDouble, h->peers[p], h->comm, h->stream));
         if (h->rcount[p] > 0)
           LZ_NCCL(h, g_rccl.Recv(ghost + h->roff[p], (size_t)h->rcount[p], ncclDouble, h->peers[p], h->comm, h->stream));
       }
@@ -761,6 +767,18 @@ int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* se
   LZ_TRY(dev_alloc(h, h->d_send_idx, (size_t)ts));
   LZ_TRY(dev_alloc(h, h->d_sendbuf, (size_t)ts));
   if (ts > 0) LZ_HIP(h, hipMemcpy(h->d_send_idx, send_idx, (size_t)ts * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->sstart.assign(npeers, -1);
+  h->all_contig = npeers > 0;
+  for (int p = 0; p < npeers; ++p) {
+    bool contig = true;
+    for (int64_t k = 1; k < send_counts[p]; ++k)
+      if (send_idx[h->soff[p] + k] != send_idx[h->soff[p] + k - 1] + 1) {
+        contig = false;
+        break;
+      }
+    if (contig && send_counts[p] > 0) h->sstart[p] = send_idx[h->soff[p]];
+    if (!contig) h->all_contig = false;
+  }
   h->total_send = ts;
   h->total_recv = tr;
   h->ldv = h->rows_pad + round_up(tr, kPadDoubles);

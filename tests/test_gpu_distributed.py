@@ -105,7 +105,8 @@ def test_rccl_single_rank_communicator():
     h0.close()
 
 
-def test_rccl_self_send_recv_halo():
+@pytest.mark.parametrize("faces", ["both", "one"])
+def test_rccl_self_send_recv_halo(faces):
     """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the compute stream, with a 1-rank communicator
     exchanging with itself: the vertical wrap-around neighbours of a periodic 2-D stencil are routed through the
     ghost tail (packed by k_gather, sent and received by RCCL) instead of being read in place.  Must equal the
@@ -123,6 +124,8 @@ def test_rccl_self_send_recv_halo():
     rows_pad = (M + 31) // 32 * 32
     row_of = np.repeat(np.arange(M), np.diff(A.rowptr))
     wrap = np.abs(A.colidx.astype(np.int64) - row_of) > nx  # entries that cross the periodic seam in y
+    if faces == "one":  # a single contiguous face: sent straight out of V[j] without the pack kernel
+        wrap &= A.colidx < nx
     ghost_cols = np.unique(A.colidx[wrap])
     col = A.colidx.astype(np.int64).copy()
     col[wrap] = rows_pad + np.searchsorted(ghost_cols, A.colidx[wrap])
@@ -132,7 +135,7 @@ def test_rccl_self_send_recv_halo():
     h.set_csr(M, 0, A.rowptr, col.astype(np.int32), A.vals, ncols_ext=rows_pad + len(ghost_cols))
     h.set_halo([0], [len(ghost_cols)], ghost_cols.astype(np.int32), [len(ghost_cols)])
     a1, b1 = h.run(25, v0)
-    assert len(ghost_cols) == 2 * nx
+    assert len(ghost_cols) == (2 * nx if faces == "both" else nx)
     assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
     assert np.array_equal(V0, h.get_basis())
     assert h.timings()["comm"]["launches"] >= 3 * 25
