@@ -32,8 +32,16 @@ def load_golden(name):
     if "rowptr" in d:
         H = scipy.sparse.csr_matrix((d["vals"], d["colidx"], d["rowptr"]), shape=(M, M))
     else:
-        gen = str(d["generator"]).split(";")[0].strip()
-        obj = eval(gen, {"__builtins__": {}}, {k: getattr(synthetic, k) for k in synthetic.__all__})
+        import ast
+        import re
+
+        gen = str(d["generator"]).split(";")[0].strip()  # e.g. "random_graph_laplacian(2000, 7000, seed=1234)"
+        name, argstr = re.fullmatch(r"(\w+)\((.*)\)", gen).groups()
+        call = ast.parse(f"f({argstr})", mode="eval").body
+        args = [ast.literal_eval(a) for a in call.args]
+        kwargs = {k.arg: ast.literal_eval(k.value) for k in call.keywords}
+        assert name in synthetic.__all__
+        obj = getattr(synthetic, name)(*args, **kwargs)
         H = obj.to_scipy() if hasattr(obj, "to_scipy") else scipy.sparse.csr_matrix(obj)
     return d, H
 
