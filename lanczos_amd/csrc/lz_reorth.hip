@@ -162,82 +162,6 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
   }
 }
 
-// Software-pipelined VALU variant.  The (row-tile, position) items of a block are
-// walked as ONE stream with D register buffers of R loads each: the loads of item
-// k+D-1 are issued before item k is consumed, also across tile boundaries, so a
-// lane always has (D-1)*R .. D*R 16-byte loads in flight and nothing drains at the
-// per-tile reduction.  Each wave reduces and writes its own partials (no barrier in
-// the main loop): P = 4*G partials per basis row.
-template <int SCALE, int R, int D>
-__global__ __launch_bounds__(kTPB) void k_qtw_pipe(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
-                                                  const double* __restrict__ r, const double* __restrict__ nrm2,
-                                                  double* __restrict__ beta_slot, int64_t L, int P,
-                                                  double* __restrict__ part) {
-  extern __shared__ double2 sw[];
-  const int64_t base = (int64_t)blockIdx.x * L;
-  const int cnt2 = (int)((len - base < L ? len - base : L) >> 1);
-  const int npos = (cnt2 + kTPB - 1) / kTPB;  // block-uniform
-  double self = qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt2, sw);
-  for (int t = cnt2 + threadIdx.x; t < npos * kTPB; t += kTPB) sw[t] = make_double2(0.0, 0.0);  // weights of the padding lanes
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int pid = blockIdx.x * (kTPB / 64) + w;
-  const int ntiles = (nrows + R - 1) / R;
-  const int K = ntiles * npos;
-  const double2* Vb = reinterpret_cast<const double2*>(V + base);
-  const int64_t ld2 = ldv >> 1;
-  double2 buf[D][R];
-  double acc[R];
-#pragma unroll
-  for (int q = 0; q < R; ++q) acc[q] = 0.0;
-  int ptile = 0, ppos = 0, ctile = 0, cpos = 0;
-
-  auto issue = [&](double2(&b)[R]) {
-    int t = threadIdx.x + kTPB * ppos;
-    if (t >= cnt2) t = cnt2 - 1;  // padding lane: valid address, zero weight
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      int i = ptile * R + q;
-      if (i >= nrows) i = nrows - 1;  // clamped duplicate, discarded at the store
-      b[q] = Vb[(int64_t)i * ld2 + t];
-    }
-    if (++ppos == npos) {
-      ppos = 0;
-      ++ptile;
-    }
-  };
-  auto consume = [&](const double2(&b)[R]) {
-    const double2 wv = sw[threadIdx.x + kTPB * cpos];
-#pragma unroll
-    for (int q = 0; q < R; ++q) {
-      acc[q] = fma(b[q].x, wv.x, acc[q]);
-      acc[q] = fma(b[q].y, wv.y, acc[q]);
-    }
-    if (++cpos == npos) {
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        const int row = ctile * R + q;
-        const double s = wave_sum(row == j ? self : acc[q]);  // c_j = w.w from the LDS-resident values
-        if (lane == 0 && row < nrows) part[(int64_t)row * P + pid] = s;
-        acc[q] = 0.0;
-      }
-      cpos = 0;
-      ++ctile;
-    }
-  };
-
-#pragma unroll
-  for (int d = 0; d < D - 1; ++d)
-    if (d < K) issue(buf[d]);
-  for (int k = 0; k < K; k += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      if (k + d + D - 1 < K) issue(buf[(d + D - 1) % D]);
-      if (k + d < K) consume(buf[d]);
-    }
-  }
-}
-
 // MFMA variant.  Lane l of a wave: row r = l & 15 of the current 16-row tile,
 // k-group g = l >> 4.  Step s covers 8 consecutive elements of the slice
 // (64 B per row): the lane loads the double2 at element 8*s + 2*g of its row;
@@ -389,7 +313,7 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   p.family = (flags & LZ_FLAG_QTW_VALU) ? 0 : ((flags & LZ_FLAG_QTW_MFMA) ? 1 : 2);
   p.mfma = p.family != 0;
   p.variant = tune ? tune[1] : 0;
-  p.P = (p.mfma || p.variant == 8 || p.variant == 9) ? p.G * (kTPB / 64) : p.G;
+  p.P = p.mfma ? p.G * (kTPB / 64) : p.G;
   return p;
 }
 
@@ -423,10 +347,7 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
   }
   switch (plan.variant) {
     case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-    case 6: hipLaunchKernelGGL((k_qtw_valu<SCALE, 16, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
     case 7: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 0>), grid, block, lds, s, LZ_QTW_ARGS); break;  // plain (cached) loads
-    case 8: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-    case 9: hipLaunchKernelGGL((k_qtw_pipe<SCALE, 8, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;
     default:  // measured best on MI355X (profiles/r01): 8 rows x 2 positions = 16 loads in flight per lane
       if (nrows > 4)
         hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS);
@@ -497,14 +418,6 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
   const int grid = (int)((n2 + kTPB - 1) / kTPB);
   if (!r_fused && variant == 1) {  // A/B arm: plain (cached) loads
     hipLaunchKernelGGL((k_update<false, 0, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
-    return;
-  }
-  if (!r_fused && variant == 2) {
-    hipLaunchKernelGGL((k_update<false, 0, 16>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
-    return;
-  }
-  if (!r_fused && variant == 3) {
-    hipLaunchKernelGGL((k_update<false, 1, 16>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
     return;
   }
   if (r_fused)
