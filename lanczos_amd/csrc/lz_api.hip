@@ -82,6 +82,7 @@ struct lz_context {
   int kind = 0;  // 0 none, 1 csr, 2 dense
   CsrDev csr;
   double* d_dense = nullptr;
+  int64_t dense_lda = 0;  // row stride of the device copy (even: 16-byte aligned rows)
 
   // basis and work vectors
   int n = 0;
@@ -342,7 +343,7 @@ int step_spmv(lz_handle h, int j) {
     if (h->kind == 1)
       np = launch_spmv_csr(h->csr, x, h->d_r, xown, h->d_part, h->flags, h->stream);
     else
-      np = launch_gemv_dense(h->d_dense, h->rows, x, h->d_r, h->d_part, h->stream);
+      np = launch_gemv_dense(h->d_dense, h->rows, h->dense_lda, x, h->d_r, h->d_part, h->stream);
     LZ_TRY(check_launch(h, "spmv"));
   }
   {
@@ -726,8 +727,12 @@ int lz_set_dense(lz_handle h, int64_t M, const double* A) {
   h->kind = 0;
   LZ_TRY(dev_free(h, h->d_V));
   h->n = 0;
-  LZ_TRY(dev_alloc(h, h->d_dense, (size_t)M * M));
-  LZ_HIP(h, hipMemcpy(h->d_dense, A, (size_t)M * M * sizeof(double), hipMemcpyHostToDevice));
+  const int64_t lda = (M + 1) & ~(int64_t)1;
+  LZ_TRY(dev_alloc(h, h->d_dense, (size_t)M * lda + 2));
+  if (lda != M) LZ_HIP(h, hipMemset(h->d_dense, 0, ((size_t)M * lda + 2) * sizeof(double)));
+  LZ_HIP(h, hipMemcpy2D(h->d_dense, (size_t)lda * sizeof(double), A, (size_t)M * sizeof(double), (size_t)M * sizeof(double), (size_t)M,
+                        hipMemcpyHostToDevice));
+  h->dense_lda = lda;
   h->Mg = M;
   h->row0 = 0;
   h->rows = M;
@@ -931,7 +936,7 @@ int lz_spmv_host(lz_handle h, const double* x, double* y) {
   if (h->kind == 1)
     launch_spmv_csr(h->csr, dx, dy, dx, h->d_part, h->flags, h->stream);
   else
-    launch_gemv_dense(h->d_dense, h->rows, dx, dy, h->d_part, h->stream);
+    launch_gemv_dense(h->d_dense, h->rows, h->dense_lda, dx, dy, h->d_part, h->stream);
   LZ_TRY(check_launch(h, "spmv"));
   LZ_HIP(h, hipMemcpyAsync(y, dy, (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));

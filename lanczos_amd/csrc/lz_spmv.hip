@@ -242,18 +242,43 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
   return grid;
 }
 
-// ------------------------------------------------------------------ dense GEMV (row-major A, one wave per row)
-__global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ A, int64_t M, const double* __restrict__ x,
-                                                    double* __restrict__ y, double* __restrict__ part) {
+// ------------------------------------------------------------------ dense GEMV (row-major A)
+// One wave per row, 16-byte non-temporal loads of the row (A is streamed once per matvec), x through L1/L2,
+// 4 independent accumulators per lane; wave-shuffle reduction; alpha partial per block.
+__global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ A, int64_t M, int64_t lda,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    double* __restrict__ part) {
   __shared__ double sm[kTPB / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * (kTPB / 64) + w;
   double d = 0.0;
   if (row < M) {
-    const double* a = A + row * M;
-    double acc = 0.0;
-    for (int64_t c = lane; c < M; c += 64) acc = fma(a[c], x[c], acc);
-    acc = wave_sum(acc);
+    const double* a = A + row * lda;  // lda is even: every row is 16-byte aligned
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int64_t c = 0;
+    {
+      const double2* a2 = reinterpret_cast<const double2*>(a);
+      const double2* x2 = reinterpret_cast<const double2*>(x);
+      const int64_t m2 = M >> 1;
+      int64_t p = lane;
+      for (; p + 64 < m2; p += 128) {
+        const double2 u = ld_stream<1>(a2 + p), v = ld_stream<1>(a2 + p + 64);
+        const double2 xu = x2[p], xv = x2[p + 64];
+        acc0 = fma(u.x, xu.x, acc0);
+        acc1 = fma(u.y, xu.y, acc1);
+        acc2 = fma(v.x, xv.x, acc2);
+        acc3 = fma(v.y, xv.y, acc3);
+      }
+      for (; p < m2; p += 64) {
+        const double2 u = ld_stream<1>(a2 + p);
+        const double2 xu = x2[p];
+        acc0 = fma(u.x, xu.x, acc0);
+        acc1 = fma(u.y, xu.y, acc1);
+      }
+      c = 2 * m2;
+    }
+    for (c += lane; c < M; c += 64) acc0 = fma(a[c], x[c], acc0);  // odd M: the last column
+    const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
     if (lane == 0) {
       y[row] = acc;
       d = x[row] * acc;
@@ -263,9 +288,9 @@ __global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ 
   if (threadIdx.x == 0) part[blockIdx.x] = d;
 }
 
-int launch_gemv_dense(const double* A, int64_t M, const double* x, double* y, double* part, hipStream_t s) {
+int launch_gemv_dense(const double* A, int64_t M, int64_t lda, const double* x, double* y, double* part, hipStream_t s) {
   const int grid = (int)((M + kTPB / 64 - 1) / (kTPB / 64));
-  hipLaunchKernelGGL(k_gemv_dense, dim3(grid), dim3(kTPB), 0, s, A, M, x, y, part);
+  hipLaunchKernelGGL(k_gemv_dense, dim3(grid), dim3(kTPB), 0, s, A, M, lda, x, y, part);
   return grid;
 }
 
