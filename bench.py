@@ -286,7 +286,7 @@ def main():
             except Exception:
                 pass
         line = {
-            "metric": "Lanczos iterations/sec (+ SpMV GB/s vs HBM roofline), n=1e7 5-pt Laplacian k=200",
+            "metric": "Lanczos iterations/sec + SpMV GB/s vs HBM roofline, n=1e7 5-pt Laplacian k=200",  # BASELINE.json
             "value": round(iters / elapsed, 3),
             "unit": "iterations/s",
             "n_gpus": world,
