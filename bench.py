@@ -187,7 +187,7 @@ def main():
         print(f"[rank {rank}] RCCL setup failed ({e}); falling back to host-staged collectives", file=sys.stderr)
         ok = False
     if world > 1 and not all(boot.allgather_obj(ok)):
-        comm_used = "host-gloo (RCCL init failed)"
+        comm_used = "host-staged (RCCL init failed)"
         solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend="host", mode=args.mode,
                                                 options=args.options | prof)
     v0 = solver.start_vector(99)[lo:hi].copy()

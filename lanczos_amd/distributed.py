@@ -265,8 +265,15 @@ class DistributedLanczos:
         self.backend = backend
         if self.world > 1:
             if backend == "rccl":
-                uid = self.h.unique_id() if self.rank == 0 else None
+                uid = None
+                if self.rank == 0:
+                    try:
+                        uid = self.h.unique_id()
+                    except _capi.LanczosHipError as e:  # keep the ranks in step: everyone learns about the failure
+                        uid = ("error", str(e))
                 uid = self.boot.broadcast_bytes(uid, root=0)
+                if isinstance(uid, tuple):
+                    raise _capi.LanczosHipError(-3, f"rank 0 could not create the RCCL unique id: {uid[1]}")
                 self.h.comm_init_rccl(self.world, self.rank, uid)
             elif backend == "host":
                 self.h.comm_init_host(self.world, self.rank, self.boot.allreduce_sum, self.boot.exchange, self.boot.allgather_array)
