@@ -255,6 +255,8 @@ def main():
             "iterations_per_s": round(2 * k / tp, 1), "ms_per_solve": round(1e3 * tp / 2, 3), "sweeps": solver.h.last_sweeps(), "of": k,
             "max_rel_ritz_diff_vs_full": float(np.abs(theta_part - theta_full).max() / np.abs(theta_full).max()),
             "spmv_share_of_device_time": round(tmp["spmv"]["ms"] * tmp["spmv"]["launches"] / max(tmp["spmv"]["timed_launches"], 1) / max(tmp["total_ms"], 1e-9), 3),
+            "whole_iteration_gbps": round(sum(tmp[c]["bytes"] for c in ("spmv", "qtw", "update", "three_term")) / max(tmp["total_ms"], 1e-9) / 1e6, 1),
+            "whole_iteration_frac_hbm_peak": round(sum(tmp[c]["bytes"] for c in ("spmv", "qtw", "update", "three_term")) / max(tmp["total_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
             "note": "opt-in LZ_FLAG_REORTH_PARTIAL (Simon 1984): the reference's sweep kernels run only when semi-orthogonality "
                     "is about to be lost; basis orthogonal to sqrt(eps), Ritz values to O(eps||A||)",
         }
