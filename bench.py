@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--profile-stride", type=int, default=8, help="bracket only every n-th iteration with hipEvents (each event costs ~3 us)")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed runtime pre-warm (used under rocprofv3 --pmc)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index (default: LOCAL_RANK); lets several ranks share one GPU with --backend host")
+    ap.add_argument("--overlap", action="store_true", help="N > 1: exchange the halo on a second stream behind the interior re-orthogonalisation update (LZ_FLAG_OVERLAP_HALO)")
     ap.add_argument("--bootstrap", default="socket", choices=["socket", "torch"])
     ap.add_argument("--backend", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--mode", default="auto", choices=["auto", "halo", "allgather"])
@@ -176,6 +177,8 @@ def main():
     t_build = time.perf_counter() - t0
 
     prof = 0 if args.no_profile else _capi.FLAG_PROFILE
+    if args.overlap:
+        prof |= _capi.FLAG_OVERLAP_HALO
     comm_used = "none" if world == 1 else args.backend
     try:
         solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend=args.backend, mode=args.mode,
@@ -303,6 +306,7 @@ def main():
             "config": {"workload": args.workload, "matrix": kind, "dims": list(dims), "M": M, "k": k, "reorth": "full (reference CGS, 2 passes)",
                        "partition": f"row-block x{world}", "exchange": solver.plan.mode, "comm": comm_used,
                        "fused_norm_allreduce": bool(solver.options & _capi.FLAG_FUSED_NORM), "profile_stride": stride,
+                       "halo_overlap": bool(solver.options & _capi.FLAG_OVERLAP_HALO),
                        "step": "one full k-iteration Lanczos solve"},
             "roofline": dict(per_class[dominant], kernel=dominant) if dominant else None,
             "roofline_all": per_class,

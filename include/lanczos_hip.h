@@ -50,6 +50,8 @@ enum lz_flags {
   LZ_FLAG_SPMV_SCALAR = 8,    /* force the plain one-thread-per-row CSR kernel            */
   LZ_FLAG_FUSED_NORM = 16,    /* multi-rank only: fold ||r||^2 into the Q^T r all-reduce   */
   LZ_FLAG_SPMV_STREAM = 32,   /* force the generic CSR-stream kernel (no fixed-K fast path) */
+  LZ_FLAG_OVERLAP_HALO = 128, /* multi-rank, contiguous (stencil) halos: update the faces of V[j] first, exchange them on a
+                                 second stream while the interior is updated; the SpMV waits on an event (opt-in)    */
   LZ_FLAG_REORTH_PARTIAL = 64 /* opt-in: partial re-orthogonalisation (Simon 1984).  The reference sweeps the whole basis
                                  every step; with this flag the sweep (same kernels, same arithmetic) runs only when the
                                  omega-recurrence estimate of the loss of orthogonality exceeds sqrt(eps), on that and the

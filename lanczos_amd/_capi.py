@@ -25,6 +25,7 @@ FLAG_SPMV_SCALAR = 8
 FLAG_FUSED_NORM = 16
 FLAG_SPMV_STREAM = 32
 FLAG_REORTH_PARTIAL = 64
+FLAG_OVERLAP_HALO = 128
 
 KERNEL_CLASSES = ("spmv", "qtw", "update", "three_term", "final", "comm", "ritz")
 K_COUNT = len(KERNEL_CLASSES)

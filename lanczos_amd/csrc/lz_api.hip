@@ -116,6 +116,12 @@ struct lz_context {
   std::vector<int64_t> scount, rcount, soff, roff;
   std::vector<int64_t> sstart;  // >= 0: the peer's send list is the contiguous run x[sstart .. sstart+scount) (stencil faces)
   bool all_contig = false;
+  // LZ_FLAG_OVERLAP_HALO: the boundary positions of V[j] are updated first, their halo exchange runs on `cstream`
+  // while the compute stream updates the interior; the SpMV waits for `e_halo`.
+  hipStream_t cstream = nullptr;
+  hipEvent_t e_bnd = nullptr, e_halo = nullptr;
+  int halo_inflight_j = -1;
+  std::vector<std::pair<int64_t, int64_t>> bnd_ranges, int_ranges;  // double2 position ranges of a basis row
   int64_t total_send = 0, total_recv = 0;
   int32_t* d_send_idx = nullptr;
   double* d_sendbuf = nullptr;
@@ -335,7 +341,13 @@ double spmv_flops(lz_handle h) { return h->kind == 1 ? 2.0 * h->csr.nnz : 2.0 * 
 // r = A V[j]; d_alpha[j] = sum over ranks of V[j] . r
 int step_spmv(lz_handle h, int j) {
   const double* x = nullptr;
-  LZ_TRY(comm_exchange_x(h, j, &x));
+  if (h->halo_inflight_j == j) {  // exchange already issued on the comm stream behind the boundary update
+    LZ_HIP(h, hipStreamWaitEvent(h->stream, h->e_halo, 0));
+    x = h->d_V + (int64_t)j * h->ldv;
+    h->halo_inflight_j = -1;
+  } else {
+    LZ_TRY(comm_exchange_x(h, j, &x));
+  }
   const double* xown = h->d_V + (int64_t)j * h->ldv;
   int np = 0;
   {
@@ -355,7 +367,7 @@ int step_spmv(lz_handle h, int j) {
 }
 
 // V[j] = r / sqrt(nrm2) (if scale), then c = V[0:nrows] . V[j]; V[j] = 2 V[j] - c^T V[0:nrows]
-int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx) {
+int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in_run_loop = false) {
   const double M = (double)h->rows;
   // fused-norm mode (multi-rank): one all-reduce carries [V_i . r (i < j), r . r]; beta and the scaling by
   // 1/beta are applied afterwards.  Only valid for the in-loop call shape (row j is the newest row).
@@ -377,11 +389,41 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx) {
     launch_fused_prepare(h->d_c, j, h->d_beta + beta_idx, h->stream);
     LZ_TRY(check_launch(h, "fused_prepare"));
   }
-  {
-    Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + (fused ? 16.0 : 16.0) * M, 2.0 * nrows * M);
+  const bool overlap = in_run_loop && (h->flags & LZ_FLAG_OVERLAP_HALO) && h->xmode == 1 && h->all_contig && h->comm_kind == 1 &&
+                       !h->peers.empty() && (h->world > 1 || h->tune[6]);
+  if (!overlap) {
+    Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + 16.0 * M, 2.0 * nrows * M);
     launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream);
     LZ_TRY(check_launch(h, "update"));
+    return LZ_OK;
   }
+  // 1. boundary positions (the faces the neighbours need), 2. their exchange on the comm stream, 3. interior
+  double* vj = h->d_V + (int64_t)j * h->ldv;
+  {
+    Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + 16.0 * M, 2.0 * nrows * M);
+    for (auto& rg : h->bnd_ranges)
+      launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream,
+                    rg.first, rg.second);
+    LZ_TRY(check_launch(h, "update(boundary)"));
+    LZ_HIP(h, hipEventRecord(h->e_bnd, h->stream));
+    for (auto& rg : h->int_ranges)
+      launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream,
+                    rg.first, rg.second);
+    LZ_TRY(check_launch(h, "update(interior)"));
+  }
+  LZ_HIP(h, hipStreamWaitEvent(h->cstream, h->e_bnd, 0));
+  h->acc.bytes[LZ_K_COMM] += 8.0 * (h->total_send + h->total_recv);
+  h->acc.launches[LZ_K_COMM] += 1;
+  LZ_NCCL(h, g_rccl.GroupStart());
+  for (size_t p = 0; p < h->peers.size(); ++p) {
+    if (h->scount[p] > 0)
+      LZ_NCCL(h, g_rccl.Send(vj + h->sstart[p], (size_t)h->scount[p], ncclDouble, h->peers[p], h->comm, h->cstream));
+    if (h->rcount[p] > 0)
+      LZ_NCCL(h, g_rccl.Recv(vj + h->rows_pad + h->roff[p], (size_t)h->rcount[p], ncclDouble, h->peers[p], h->comm, h->cstream));
+  }
+  LZ_NCCL(h, g_rccl.GroupEnd());
+  LZ_HIP(h, hipEventRecord(h->e_halo, h->cstream));
+  h->halo_inflight_j = j;
   return LZ_OK;
 }
 
@@ -528,6 +570,12 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_sendbuf);
   hipFree(h->d_xfull);
   if (h->h_pinned) hipHostFree(h->h_pinned);
+  if (h->cstream) {
+    hipStreamSynchronize(h->cstream);
+    hipStreamDestroy(h->cstream);
+    hipEventDestroy(h->e_bnd);
+    hipEventDestroy(h->e_halo);
+  }
   for (auto& e : h->events) {
     hipEventDestroy(e.a);
     hipEventDestroy(e.b);
@@ -784,6 +832,32 @@ int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* se
     if (contig && send_counts[p] > 0) h->sstart[p] = send_idx[h->soff[p]];
     if (!contig) h->all_contig = false;
   }
+  h->bnd_ranges.clear();
+  h->int_ranges.clear();
+  if (h->all_contig) {
+    std::vector<std::pair<int64_t, int64_t>> rg;
+    for (int p = 0; p < npeers; ++p)
+      if (send_counts[p] > 0) rg.push_back({h->sstart[p] / 2, (h->sstart[p] + send_counts[p] + 1) / 2});  // double2 positions
+    std::sort(rg.begin(), rg.end());
+    for (auto& r : rg) {
+      if (!h->bnd_ranges.empty() && r.first <= h->bnd_ranges.back().second)
+        h->bnd_ranges.back().second = std::max(h->bnd_ranges.back().second, r.second);
+      else
+        h->bnd_ranges.push_back(r);
+    }
+    int64_t cur = 0;
+    const int64_t n2 = h->rows_pad / 2;
+    for (auto& r : h->bnd_ranges) {
+      if (r.first > cur) h->int_ranges.push_back({cur, r.first});
+      cur = r.second;
+    }
+    if (cur < n2) h->int_ranges.push_back({cur, n2});
+    if (!h->cstream) {
+      LZ_HIP(h, hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+      LZ_HIP(h, hipEventCreateWithFlags(&h->e_bnd, hipEventDisableTiming));
+      LZ_HIP(h, hipEventCreateWithFlags(&h->e_halo, hipEventDisableTiming));
+    }
+  }
   h->total_send = ts;
   h->total_recv = tr;
   h->ldv = h->rows_pad + round_up(tr, kPadDoubles);
@@ -953,6 +1027,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   LZ_TRY(lz_basis_alloc(h, n));
+  h->halo_inflight_j = -1;
   const double t1 = now();
   LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const double t2 = now();
@@ -1014,7 +1089,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     }
     if (sweep) {
       ++sweeps;
-      LZ_TRY(step_reorth(h, j, j + 1, true, bidx));
+      LZ_TRY(step_reorth(h, j, j + 1, true, bidx, true));
     } else {
       Scope sc(h, LZ_K_QTW, 16.0 * (double)h->rows, (double)h->rows);
       launch_scale_store(h->d_V + (int64_t)j * h->ldv, h->d_r, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream);

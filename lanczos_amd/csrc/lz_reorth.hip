@@ -374,10 +374,10 @@ void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const dou
 // rounded separately.  One double2 column position per lane; the row loop is
 // unrolled so 8 independent 16-byte loads are in flight per lane.
 template <bool FUSED, int VAR = 0, int UN = 8>
-__global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t ldv, int64_t n2, int nrows, int j,
+__global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t ldv, int64_t p0, int64_t n2, int nrows, int j,
                                                 const double* __restrict__ c, const double* __restrict__ r,
                                                 const double* __restrict__ beta) {
-  const int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  const int64_t i = p0 + (int64_t)blockIdx.x * kTPB + threadIdx.x;  // double2 positions [p0, n2)
   if (i >= n2) return;
   const double2* col = reinterpret_cast<const double2*>(V) + i;
   const int64_t ld2 = ldv >> 1;
@@ -413,17 +413,20 @@ __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
-                   const double* beta, int variant, hipStream_t s) {
-  const int64_t n2 = len >> 1;
-  const int grid = (int)((n2 + kTPB - 1) / kTPB);
+                   const double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi) {
+  // double2 positions [pos_lo, pos_hi) of the row (default: the whole row)
+  const int64_t n2 = pos_hi >= 0 ? pos_hi : (len >> 1);
+  const int64_t p0 = pos_lo > 0 ? pos_lo : 0;
+  if (n2 <= p0) return;
+  const int grid = (int)((n2 - p0 + kTPB - 1) / kTPB);
   if (!r_fused && variant == 1) {  // A/B arm: plain (cached) loads
-    hipLaunchKernelGGL((k_update<false, 0, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+    hipLaunchKernelGGL((k_update<false, 0, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
     return;
   }
   if (r_fused)
-    hipLaunchKernelGGL((k_update<true, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+    hipLaunchKernelGGL((k_update<true, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
   else
-    hipLaunchKernelGGL((k_update<false, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, n2, nrows, j, c, r_fused, beta);
+    hipLaunchKernelGGL((k_update<false, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
 }
 
 // partial re-orthogonalisation mode, steps without a sweep: V[j] = r / sqrt(nrm2) and nothing else

@@ -105,8 +105,9 @@ def test_rccl_single_rank_communicator():
     h0.close()
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("faces", ["both", "one"])
-def test_rccl_self_send_recv_halo(faces):
+def test_rccl_self_send_recv_halo(faces, overlap):
     """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on the compute stream, with a 1-rank communicator
     exchanging with itself: the vertical wrap-around neighbours of a periodic 2-D stencil are routed through the
     ghost tail (packed by k_gather, sent and received by RCCL) instead of being read in place.  Must equal the
@@ -132,8 +133,13 @@ def test_rccl_self_send_recv_halo(faces):
     h = _capi.Handle(0)
     h.comm_init_rccl(1, 0, h.unique_id())
     h.set_tuning(6, 1)
+    if overlap:  # LZ_FLAG_OVERLAP_HALO: faces updated first, exchanged on a second stream behind the interior update
+        h.set_options(_capi.FLAG_OVERLAP_HALO)
     h.set_csr(M, 0, A.rowptr, col.astype(np.int32), A.vals, ncols_ext=rows_pad + len(ghost_cols))
-    h.set_halo([0], [len(ghost_cols)], ghost_cols.astype(np.int32), [len(ghost_cols)])
+    if faces == "both":  # two contiguous faces, like the two slab neighbours of a rank: two (self) peer entries
+        h.set_halo([0, 0], [nx, nx], ghost_cols.astype(np.int32), [nx, nx])
+    else:
+        h.set_halo([0], [len(ghost_cols)], ghost_cols.astype(np.int32), [len(ghost_cols)])
     a1, b1 = h.run(25, v0)
     assert len(ghost_cols) == (2 * nx if faces == "both" else nx)
     assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
