@@ -39,6 +39,8 @@ WORKLOADS = {
     "lap2d_5pt_M1e7_k500": ("lap2d", (4000, 2500), 500),   # configs[4] (8 GPUs)
     "graph_M1e7_k200": ("graph", (10_000_000, 35_000_000), 200),  # configs[2]
     "lap2d_5pt_M1.25e6_k200": ("lap2d", (4000, 313), 200),  # one rank's share of the headline at N = 8 (compute floor)
+    "lap2d_5pt_M2.5e6_k200": ("lap2d", (4000, 625), 200),   # ... at N = 4
+    "lap2d_5pt_M5e6_k200": ("lap2d", (4000, 1250), 200),    # ... at N = 2
     "deuteron3d_N160_27pt_k400": ("deuteron27", (160,), 400),  # the reference's largest configured run (3Ddeuteron.py:63-95)
     "tiny": ("lap2d", (256, 128), 24),
 }
