@@ -285,3 +285,15 @@ def test_partial_reorthogonalisation_opt_in(build, n):
     # a sweep removes components of size <= sqrt(eps) from v_j, so A V = V T + ... holds to that level (not eps)
     R = H @ V - V @ part.H_eff
     assert np.abs(R[:, :-1]).max() < 1e-6 * max(scale, 1.0)
+
+
+def test_randomised_shapes_against_oracle():
+    """30 random symmetric matrices of awkward shapes (M = 5 ... 12345 incl. non-multiples of every tile size, n up to
+    M, dense / banded / ragged sparse): recurrence coefficients and Ritz values vs the CPU oracle, Y = V S."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(seed=1, trials=30, quiet=True) == 0
