@@ -131,3 +131,34 @@ def test_host_side_diagnostics_match_reference_semantics():
     Lanczos.test_is_Hermitian(A)
     with pytest.raises(AssertionError):
         Lanczos.test_is_Hermitian(np.triu(A))
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "c_abi_example")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_example.c"),
+           "-L" + os.path.join(ROOT, "lanczos_amd"), "-llanczos_hip", "-Wl,-rpath," + os.path.join(ROOT, "lanczos_amd"), "-lm", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return exe
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_header_is_plain_c_and_client_links(tmp_path):
+    """include/lanczos_hip.h compiles as C99 and a plain-C client links against the shared library; without a GPU the
+    client gets LZ_ERR_NODEVICE from lz_create (exit code 3) - no CPU fallback."""
+    import subprocess
+
+    exe = _build_c_example(tmp_path)
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 3 and "no HIP device" in p.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_client_runs(tmp_path):
+    import subprocess
+
+    exe = _build_c_example(tmp_path)
+    p = subprocess.run([exe, "64", "48", "24"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "sweeps=24" in p.stdout
