@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU box): HIP path vs the CPU oracle on random symmetric matrices of odd shapes
-(tiny, n == M, dense, banded, ragged).  `run()` is also called from tests/test_gpu_lanczos.py."""
+(tiny, n == M, dense, banded, ragged).  Test infrastructure (it uses the oracle): `run()` is called from
+tests/test_gpu_lanczos.py; `python tests/stress_parity.py SEED TRIALS` runs a longer sweep by hand."""
 import os
 import sys
 

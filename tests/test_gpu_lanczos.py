@@ -293,7 +293,7 @@ def test_randomised_shapes_against_oracle():
     import importlib.util
     import os
 
-    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_parity.py"))
+    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(seed=1, trials=30, quiet=True) == 0
