@@ -159,6 +159,12 @@ class LanczosBase:
         else:
             h.set_dense(packed[1])
         alpha, beta = h.run(n, v0)
+        if not (np.isfinite(alpha).all() and np.isfinite(beta).all()):
+            # The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov space gives inf/NaN there too.
+            import warnings
+
+            warnings.warn("Lanczos breakdown: a residual norm beta reached zero (invariant subspace); H_eff contains "
+                          "non-finite entries, exactly as the reference's would", RuntimeWarning, stacklevel=3)
         self._timings = h.timings()
         self.sweeps = h.last_sweeps()  # steps that ran the re-orthogonalisation sweep (== n for reorth="full")
 

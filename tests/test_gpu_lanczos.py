@@ -297,3 +297,21 @@ def test_randomised_shapes_against_oracle():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(seed=1, trials=30, quiet=True) == 0
+
+
+def test_breakdown_behaves_like_the_reference():
+    """Invariant subspace (H = I: the first residual is exactly zero): the reference divides by beta = 0 and carries
+    NaNs forward (Lanczos.py:113, no breakdown test); the device path must do the same - and says so with a warning."""
+    import scipy.sparse
+
+    H = scipy.sparse.identity(64, format="csr")
+    a, b, V = None, None, None
+    with np.errstate(all="ignore"):
+        a, b, V = oracle.execute_lanczos(H, 5)
+    assert not np.isfinite(a).all()
+    Lanczos.verbose = False
+    s = Lanczos(H)
+    with pytest.warns(RuntimeWarning, match="breakdown"):
+        s.execute_Lanczos(5)
+    assert not np.isfinite(s.H_eff).all()
+    assert np.array_equal(np.isfinite(np.diag(s.H_eff)), np.isfinite(a))
