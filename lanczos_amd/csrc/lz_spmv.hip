@@ -107,7 +107,15 @@ __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict_
 #pragma unroll
         for (int k = 0; k < FIXED_K; ++k) sum += prod[a + k];
       } else {
-        for (int k = a; k < b; ++k) sum += prod[k];
+        int k = a;
+        for (; k + 4 <= b; k += 4) {  // four LDS reads in flight; the adds stay in CSR order
+          const double p0 = prod[k], p1 = prod[k + 1], p2 = prod[k + 2], p3 = prod[k + 3];
+          sum += p0;
+          sum += p1;
+          sum += p2;
+          sum += p3;
+        }
+        for (; k < b; ++k) sum += prod[k];
       }
       if (!(ABL & 8)) y[row] = sum;
       d += xown[row] * sum;
