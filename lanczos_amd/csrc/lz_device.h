@@ -48,6 +48,19 @@ __device__ __forceinline__ double2 ld_stream(const double2* p) {
   }
   return *p;
 }
+// Non-temporal 16-byte store: results that are not re-read soon (the new basis row) should not sit dirty in L2 while the
+// other rows stream through it (tools/probes/hbm_read_peak.hip: a trailing plain store costs 17 % of the pass, an nt one 9 %).
+template <int VAR>
+__device__ __forceinline__ void st_stream(double2* p, double2 v) {
+  if (VAR == 1) {
+    d2v_t t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<d2v_t*>(p));
+  } else {
+    *p = v;
+  }
+}
 template <int VAR>
 __device__ __forceinline__ int2 ld_stream(const int2* p) {
   if (VAR == 1) {

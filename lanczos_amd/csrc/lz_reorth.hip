@@ -91,7 +91,7 @@ __device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ld
       double2 v = rr[t];
       v.x = v.x / beta;
       v.y = v.y / beta;
-      vj[t] = v;
+      st_stream<1>(vj + t, v);  // next read of V[j] is a whole pass away: keep it out of L2
       sw[t] = v;
       self = fma(v.x, v.x, self);
       self = fma(v.y, v.y, self);
@@ -402,14 +402,92 @@ __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t
       ty = ty + ck * q[u].y;
     }
   }
-  for (; k < nrows; ++k) {
-    const double2 q = (FUSED && k == j) ? w : col[(int64_t)k * ld2];
-    const double ck = c[k];
-    tx = tx + ck * q.x;
-    ty = ty + ck * q.y;
+  if (k < nrows) {  // tail (< UN rows): still one batch of independent loads, not one round trip per row
+    const int rem = nrows - k;  // block-uniform
+    double2 q[UN];
+#pragma unroll
+    for (int u = 0; u < UN - 1; ++u)
+      if (u < rem) q[u] = (FUSED && k + u == j) ? w : ld_stream<VAR>(col + (int64_t)(k + u) * ld2);
+#pragma unroll
+    for (int u = 0; u < UN - 1; ++u)
+      if (u < rem) {
+        const double ck = c[k + u];
+        tx = tx + ck * q[u].x;
+        ty = ty + ck * q[u].y;
+      }
   }
-  const double2 v = FUSED ? w : *out;
-  *out = make_double2(2.0 * v.x - tx, 2.0 * v.y - ty);
+  const double2 v = FUSED ? w : ld_stream<VAR>(out);
+  st_stream<VAR>(out, make_double2(2.0 * v.x - tx, 2.0 * v.y - ty));
+}
+
+// Default pass-2 kernel: "slice owner".  A block owns 256*P consecutive double2 positions of the row and keeps their
+// running sums in registers while it walks ALL basis rows, RU rows x P positions = RU*P independent 16-byte loads in
+// flight per lane.  Same per-element arithmetic and order as k_update; the difference is WHEN V[j] is written: every
+// block of a residency round finishes at about the same time, so the 8M bytes of stores arrive as a few bursts at the
+// end instead of trickling in between the reads for the whole launch.  A 1 % trickle of writes costs ~15 % of HBM read
+// throughput on MI355X (tools/probes/hbm_read_peak.hip: 6.8 -> 5.8 TB/s), presumably read<->write bus turnarounds.
+template <bool FUSED, int P, int RU>
+__global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, int64_t ldv, int64_t p0, int64_t n2, int nrows,
+                                                      int j, const double* __restrict__ c, const double* __restrict__ r,
+                                                      const double* __restrict__ beta) {
+  const int64_t base = p0 + (int64_t)blockIdx.x * (kTPB * P) + threadIdx.x;
+  const int64_t ld2 = ldv >> 1;
+  const double2* V2 = reinterpret_cast<const double2*>(V);
+  int64_t pos[P];
+  bool ok[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    pos[p] = base + (int64_t)p * kTPB;
+    ok[p] = pos[p] < n2;
+    if (!ok[p]) pos[p] = n2 - 1;  // valid address, result discarded
+  }
+  double2 w[P];
+  if (FUSED) {
+    const double b = beta[0];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      w[p] = reinterpret_cast<const double2*>(r)[pos[p]];
+      w[p].x = w[p].x / b;
+      w[p].y = w[p].y / b;
+    }
+  }
+  double tx[P], ty[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) tx[p] = ty[p] = 0.0;
+  for (int k = 0; k < nrows; k += RU) {
+    double2 q[RU][P];
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (k + u < nrows) {  // block-uniform
+        const double2* row = V2 + (int64_t)(k + u) * ld2;
+#pragma unroll
+        for (int p = 0; p < P; ++p) q[u][p] = (FUSED && k + u == j) ? w[p] : ld_stream<1>(row + pos[p]);
+      }
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (k + u < nrows) {
+        const double ck = c[k + u];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          tx[p] = tx[p] + ck * q[u][p].x;
+          ty[p] = ty[p] + ck * q[u][p].y;
+        }
+      }
+  }
+  double2* out = reinterpret_cast<double2*>(V) + (int64_t)j * ld2;
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+    if (ok[p]) {
+      const double2 v = FUSED ? w[p] : ld_stream<1>(out + pos[p]);
+      st_stream<1>(out + pos[p], make_double2(2.0 * v.x - tx[p], 2.0 * v.y - ty[p]));
+    }
+}
+
+template <bool FUSED, int P, int RU>
+static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, int nrows, int j, const double* c, const double* r,
+                                const double* beta, hipStream_t s) {
+  const int grid = (int)((n2 - p0 + kTPB * P - 1) / (kTPB * P));
+  hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r, beta);
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
@@ -423,10 +501,25 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
     hipLaunchKernelGGL((k_update<false, 0, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
     return;
   }
-  if (r_fused)
-    hipLaunchKernelGGL((k_update<true, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
-  else
-    hipLaunchKernelGGL((k_update<false, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
+  if (variant == 2) {  // A/B arm: one position per lane, non-temporal loads (stores trickle through the whole launch)
+    if (r_fused)
+      hipLaunchKernelGGL((k_update<true, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
+    else
+      hipLaunchKernelGGL((k_update<false, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
+    return;
+  }
+  // default: slice-owner kernel; pick P so that small vectors still fill the chip
+  const int64_t span = n2 - p0;
+  if (variant == 3 || (variant == 0 && span >= (int64_t)kTPB * 8 * 1024)) {
+    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+    else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+  } else if (variant == 4 || (variant == 0 && span >= (int64_t)kTPB * 4 * 512)) {
+    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+    else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+  } else {
+    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+    else launch_update_slice<false, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+  }
 }
 
 // partial re-orthogonalisation mode, steps without a sweep: V[j] = r / sqrt(nrm2) and nothing else
@@ -489,7 +582,7 @@ __global__ __launch_bounds__(kTPB) void k_three_term(double* __restrict__ r, con
       x.x = x.x - m.x * b;
       x.y = x.y - m.y * b;
     }
-    r2[i] = x;
+    r2[i] = x;  // plain store: r is re-read by the very next kernel (an nt store measured no different)
     acc = fma(x.x, x.x, acc);
     acc = fma(x.y, x.y, acc);
   }
