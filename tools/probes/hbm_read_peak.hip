@@ -90,11 +90,14 @@ __global__ __launch_bounds__(256) void k_update_like(d2* __restrict__ p, size_t 
   } else if (tx + ty == 1.2345e300) out[0] = tx;
 }
 // ... and like Q^T w: a block owns a 40 KB slice of every row and walks the rows 8 at a time
-template <int R, int U>
-__global__ __launch_bounds__(256) void k_read_slices(const d2* __restrict__ p, size_t ld2, int nrows, int cnt2, double* out) {
+template <int R, int U, int PART = 0>  // PART 1: per-wave 8-byte partial store after every tile ([row][wave] layout), 2: one burst at the end
+__global__ __launch_bounds__(256) void k_read_slices(const d2* __restrict__ p, size_t ld2, int nrows, int cnt2, double* out, double* part = nullptr) {
   const size_t base = (size_t)blockIdx.x * cnt2;
   double acc = 0;
+  const int pid = blockIdx.x * 4 + (threadIdx.x >> 6), P = gridDim.x * 4;
+  __shared__ double keep[4][512];
   for (int i0 = 0; i0 + R <= nrows; i0 += R) {
+    if (PART) acc = 0;
     for (int t = threadIdx.x; t < cnt2; t += 256 * U) {
       d2 v[R][U];
 #pragma unroll
@@ -106,8 +109,13 @@ __global__ __launch_bounds__(256) void k_read_slices(const d2* __restrict__ p, s
 #pragma unroll
         for (int q = 0; q < R; ++q) acc += v[q][u].x + v[q][u].y;
     }
+    if (PART == 1 && (threadIdx.x & 63) < R) part[(size_t)(i0 + (threadIdx.x & 63)) * P + pid] = acc;
+    if (PART == 2 && (threadIdx.x & 63) < R) keep[threadIdx.x >> 6][i0 + (threadIdx.x & 63)] = acc;
   }
-  if (acc == 1.2345e300) out[0] = acc;
+  if (PART == 2) {
+    for (int i = threadIdx.x & 63; i < nrows; i += 64) __builtin_nontemporal_store(keep[threadIdx.x >> 6][i], part + (size_t)pid * 512 + i);
+  }
+  if (!PART && acc == 1.2345e300) out[0] = acc;
 }
 int main() {
   const size_t bytes = (size_t)8 << 30, n2 = bytes / 16;
@@ -152,6 +160,9 @@ int main() {
     time([&] { hipLaunchKernelGGL((k_read_slices<8, 2>), dim3(G), dim3(256), 0, 0, a, ld2, nrows, cnt2, out); }, 16.0 * ld2 * (nrows / 8 * 8), "slices R8 U2 (qtw-like)");
     time([&] { hipLaunchKernelGGL((k_read_slices<4, 2>), dim3(G), dim3(256), 0, 0, a, ld2, nrows, cnt2, out); }, 16.0 * ld2 * nrows, "slices R4 U2");
     time([&] { hipLaunchKernelGGL((k_read_slices<4, 5>), dim3(G), dim3(256), 0, 0, a, ld2, nrows, cnt2, out); }, 16.0 * ld2 * nrows, "slices R4 U5");
+    double* part; hipMalloc(&part, (size_t)G * 4 * 512 * 8);
+    time([&] { hipLaunchKernelGGL((k_read_slices<8, 2, 1>), dim3(G), dim3(256), 0, 0, a, ld2, nrows, cnt2, out, part); }, 16.0 * ld2 * (nrows / 8 * 8), "slices R8 U2 + partial store per tile");
+    time([&] { hipLaunchKernelGGL((k_read_slices<8, 2, 2>), dim3(G), dim3(256), 0, 0, a, ld2, nrows, cnt2, out, part); }, 16.0 * ld2 * (nrows / 8 * 8), "slices R8 U2 + partials in one nt burst");
   }
   return 0;
 }
