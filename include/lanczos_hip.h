@@ -200,6 +200,25 @@ int lz_step_three_term(lz_handle h, int j, int jm1, double alpha, double beta, d
 /* y = A x on host vectors (length rows_local / ncols_ext handled internally; single rank) */
 int lz_spmv_host(lz_handle h, const double* x, double* y);
 
+/* ---- two-sided (bi-orthogonal) Lanczos: the Irregular copy's execute_Lanczos --------------------------------
+ * Replaces Python/Irregular/IrrLanczos.py:77-187 (driver loop) and :408-441 (bireorthogonalize, default branch).
+ * Single rank, CSR only.  Four (n, rows) bases live on the device: 0 = q (published as V: lz_get_basis /
+ * lz_ritz_vectors read it), 1 = p, 2 = q_basis, 3 = p_basis (the orthonormalised copies the reference projects on). */
+
+/* HT = csr_matrix(H.transpose()) (IrrLanczos.py:92/96) as sorted CSR of the same square shape as lz_set_csr's matrix.
+ * rowptr == NULL: H is symmetric, H^T x runs on H itself. */
+int lz_set_csr_transpose(lz_handle h, int64_t nnz, const int32_t* rowptr, const int32_t* colidx, const double* vals);
+/* The whole run: q0, p0 are the start pair already scaled so that q0 . p0 = +-1 (IrrLanczos.py:104-106, host side).
+ * alpha_out[n], beta_out[n-1], gamma_out[n-1] (IrrLanczos.py:119-121).  n >= 2. */
+int lz_run_two_sided(lz_handle h, int n, const double* q0, const double* p0, double* alpha_out, double* beta_out,
+                     double* gamma_out);
+/* Step API for unit parity tests and for the static IrrLanczos.bireorthogonalize(V1, V2, q_basis, p_basis, j):
+ * allocate the four bases (zeroed), move rows, run the default branch of bireorthogonalize on row j (j >= 1). */
+int lz_bi_alloc(lz_handle h, int n);
+int lz_bi_set_row(lz_handle h, int which, int j, const double* row);
+int lz_bi_get_row(lz_handle h, int which, int j, double* row);
+int lz_step_bireorth(lz_handle h, int j);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,12 @@ SIGNATURES = {
     "lz_step_reorth": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _D, _D]),
     "lz_step_three_term": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, _D]),
     "lz_spmv_host": (C.c_int, [_P, _D, _D]),
+    "lz_set_csr_transpose": (C.c_int, [_P, C.c_int64, _I32, _I32, _D]),
+    "lz_run_two_sided": (C.c_int, [_P, C.c_int, _D, _D, _D, _D, _D]),
+    "lz_bi_alloc": (C.c_int, [_P, C.c_int]),
+    "lz_bi_set_row": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "lz_bi_get_row": (C.c_int, [_P, C.c_int, C.c_int, _D]),
+    "lz_step_bireorth": (C.c_int, [_P, C.c_int]),
 }
 
 
@@ -398,6 +404,43 @@ class Handle:
         d = C.c_double()
         self.check(self.lib.lz_step_three_term(self._h, int(j), int(jm1), float(alpha), float(beta), C.byref(d)))
         return d.value
+
+    # ---- two-sided (bi-orthogonal) Lanczos ----
+    def set_csr_transpose(self, rowptr=None, colidx=None, vals=None):
+        """``None``: H is symmetric (H^T x runs on H)."""
+        if rowptr is None:
+            self.check(self.lib.lz_set_csr_transpose(self._h, 0, None, None, None))
+            return
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+        colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+        vals = f64(vals)
+        self.check(self.lib.lz_set_csr_transpose(self._h, int(rowptr[-1]), i32ptr(rowptr), i32ptr(colidx), dptr(vals)))
+
+    def run_two_sided(self, n, q0, p0):
+        q0, p0 = f64(q0), f64(p0)
+        if q0.shape != (self.rows,) or p0.shape != (self.rows,):
+            raise ValueError("start pair has the wrong length")
+        alpha, beta, gamma = np.zeros(n), np.zeros(max(n - 1, 1)), np.zeros(max(n - 1, 1))
+        self.check(self.lib.lz_run_two_sided(self._h, int(n), dptr(q0), dptr(p0), dptr(alpha), dptr(beta), dptr(gamma)))
+        self.n = n
+        return alpha, beta[: n - 1], gamma[: n - 1]
+
+    def bi_alloc(self, n):
+        self.check(self.lib.lz_bi_alloc(self._h, int(n)))
+        self.n = n
+
+    def bi_set_row(self, which, j, row):
+        row = f64(row)
+        assert row.shape == (self.rows,)
+        self.check(self.lib.lz_bi_set_row(self._h, int(which), int(j), dptr(row)))
+
+    def bi_get_row(self, which, j):
+        out = np.empty(self.rows)
+        self.check(self.lib.lz_bi_get_row(self._h, int(which), int(j), dptr(out)))
+        return out
+
+    def step_bireorth(self, j):
+        self.check(self.lib.lz_step_bireorth(self._h, int(j)))
 
     def spmv_host(self, x, ncols=None):
         x = f64(x)

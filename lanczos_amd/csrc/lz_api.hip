@@ -97,6 +97,16 @@ struct lz_context {
   double* d_xtmp = nullptr;   // lz_spmv_host scratch
   QtwPlan qplan;
 
+  // two-sided Lanczos (IrrLanczos.py:77-187): H^T, the three extra bases P / Qb / Pb (Q is d_V), s, gamma, scalars
+  CsrDev csrT;
+  bool has_T = false;      // false: H declared symmetric, H^T x runs on csr
+  bool T_declared = false; // lz_set_csr_transpose was called for the current matrix
+  double* d_B3 = nullptr;  // 3 * n * ldv
+  int bi_n = 0;
+  double* d_s = nullptr;
+  double* d_gamma = nullptr;  // n + 1
+  double* d_bi = nullptr;     // [0..3] raw sums S, [4..6] factors f
+
   // Ritz vectors
   double* d_Y = nullptr;
   int64_t y_rows = 0;
@@ -467,9 +477,28 @@ void build_rowblocks(const int32_t* rowptr, int64_t rows, int rows_cap, int nnz_
 }
 
 // shared tail of lz_set_csr / lz_build_stencil3d: row blocks for the CSR-stream kernel + bookkeeping
+int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t rows_local, int64_t ncols_ext, int64_t nnz, int fixed_k,
+                  int max_nnz);
+
 int finish_csr(lz_handle h, const int32_t* rowptr_host, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext,
                int64_t nnz, int fixed_k, int max_nnz) {
-  CsrDev& A = h->csr;
+  LZ_TRY(fill_csr_meta(h, h->csr, rowptr_host, rows_local, ncols_ext, nnz, fixed_k, max_nnz));
+  h->T_declared = false;  // a new H invalidates H^T and the two-sided bases
+  h->has_T = false;
+  h->bi_n = 0;
+  h->Mg = M_global;
+  h->row0 = row0;
+  h->rows = rows_local;
+  h->ncols_ext = ncols_ext;
+  h->rows_pad = round_up(rows_local, kPadDoubles);
+  h->ldv = h->rows_pad;
+  h->xmode = 0;
+  h->kind = 1;
+  return LZ_OK;
+}
+
+int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t rows_local, int64_t ncols_ext, int64_t nnz, int fixed_k,
+                  int max_nnz) {
   std::vector<int32_t> blk;
   int rows_cap = h->tune[2] > 0 ? h->tune[2] : 512;
   // One batch of the CSR-stream kernel covers 2048 entries (256 lanes x 4 steps x 2): for long rows (27-point
@@ -489,14 +518,36 @@ int finish_csr(lz_handle h, const int32_t* rowptr_host, int64_t M_global, int64_
   A.fixed_k = fixed_k;
   A.max_row_nnz = max_nnz;
   A.avg_row_nnz = (double)nnz / (double)rows_local;
-  h->Mg = M_global;
-  h->row0 = row0;
-  h->rows = rows_local;
-  h->ncols_ext = ncols_ext;
-  h->rows_pad = round_up(rows_local, kPadDoubles);
-  h->ldv = h->rows_pad;
-  h->xmode = 0;
-  h->kind = 1;
+  return LZ_OK;
+}
+
+// validate + upload one CSR matrix into A (arrays padded by 2 entries: the kernels read pairs)
+int upload_csr(lz_handle h, CsrDev& A, const char* who, int64_t rows, int64_t ncols, int64_t nnz, const int32_t* rowptr,
+               const int32_t* colidx, const double* vals, int* fixed_k_out, int* max_nnz_out) {
+  if (rowptr[0] != 0 || rowptr[rows] != nnz) return fail(h, LZ_ERR_ARG, std::string(who) + ": rowptr[0] != 0 or rowptr[rows] != nnz");
+  int max_nnz = 0;
+  int fixed_k = (int)(rows > 0 ? rowptr[1] - rowptr[0] : 0);
+  for (int64_t i = 0; i < rows; ++i) {
+    const int64_t d = (int64_t)rowptr[i + 1] - rowptr[i];
+    if (d < 0) return fail(h, LZ_ERR_ARG, std::string(who) + ": rowptr not monotone");
+    if (d > max_nnz) max_nnz = (int)d;
+    if (d != fixed_k) fixed_k = 0;
+  }
+  for (int64_t k = 0; k < nnz; ++k)
+    if (colidx[k] < 0 || colidx[k] >= ncols) return fail(h, LZ_ERR_ARG, std::string(who) + ": column index out of range");
+  if (fixed_k > 64) fixed_k = 0;
+  LZ_TRY(dev_alloc(h, A.rowptr, (size_t)rows + 1));
+  LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
+  LZ_TRY(dev_alloc(h, A.vals, (size_t)nnz + 2));
+  LZ_HIP(h, hipMemset(A.colidx, 0, ((size_t)nnz + 2) * sizeof(int32_t)));
+  LZ_HIP(h, hipMemset(A.vals, 0, ((size_t)nnz + 2) * sizeof(double)));
+  LZ_HIP(h, hipMemcpy(A.rowptr, rowptr, ((size_t)rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    LZ_HIP(h, hipMemcpy(A.colidx, colidx, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+    LZ_HIP(h, hipMemcpy(A.vals, vals, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+  }
+  *fixed_k_out = fixed_k;
+  *max_nnz_out = max_nnz;
   return LZ_OK;
 }
 
@@ -564,6 +615,14 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_c);
   hipFree(h->d_nrm2);
   hipFree(h->d_part);
+  hipFree(h->csrT.rowptr);
+  hipFree(h->csrT.colidx);
+  hipFree(h->csrT.vals);
+  hipFree(h->csrT.rowblk);
+  hipFree(h->d_B3);
+  hipFree(h->d_s);
+  hipFree(h->d_gamma);
+  hipFree(h->d_bi);
   hipFree(h->d_xtmp);
   hipFree(h->d_Y);
   hipFree(h->d_send_idx);
@@ -679,36 +738,14 @@ int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, 
   if (rows_local >= (int64_t)1 << 31 || nnz >= (int64_t)1 << 31 || ncols_ext >= (int64_t)1 << 31)
     return fail(h, LZ_ERR_ARG, "lz_set_csr: sizes exceed int32 CSR indexing");
   if (ncols_ext < rows_local) return fail(h, LZ_ERR_ARG, "lz_set_csr: ncols_ext < rows_local");
-  if (rowptr[0] != 0 || rowptr[rows_local] != nnz) return fail(h, LZ_ERR_ARG, "lz_set_csr: rowptr[0] != 0 or rowptr[rows] != nnz");
-  int max_nnz = 0;
-  int fixed_k = (int)(rows_local > 0 ? rowptr[1] - rowptr[0] : 0);
-  for (int64_t i = 0; i < rows_local; ++i) {
-    const int64_t d = (int64_t)rowptr[i + 1] - rowptr[i];
-    if (d < 0) return fail(h, LZ_ERR_ARG, "lz_set_csr: rowptr not monotone");
-    if (d > max_nnz) max_nnz = (int)d;
-    if (d != fixed_k) fixed_k = 0;
-  }
-  for (int64_t k = 0; k < nnz; ++k)
-    if (colidx[k] < 0 || colidx[k] >= ncols_ext) return fail(h, LZ_ERR_ARG, "lz_set_csr: column index out of range");
-  if (fixed_k > 64) fixed_k = 0;
-
   LZ_HIP(h, hipSetDevice(h->dev));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
   h->kind = 0;
   LZ_TRY(dev_free(h, h->d_dense));
   LZ_TRY(dev_free(h, h->d_V));  // a new matrix invalidates the basis
   h->n = 0;
-  CsrDev& A = h->csr;
-  LZ_TRY(dev_alloc(h, A.rowptr, (size_t)rows_local + 1));
-  LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
-  LZ_TRY(dev_alloc(h, A.vals, (size_t)nnz + 2));
-  LZ_HIP(h, hipMemset(A.colidx, 0, ((size_t)nnz + 2) * sizeof(int32_t)));
-  LZ_HIP(h, hipMemset(A.vals, 0, ((size_t)nnz + 2) * sizeof(double)));
-  LZ_HIP(h, hipMemcpy(A.rowptr, rowptr, ((size_t)rows_local + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (nnz > 0) {
-    LZ_HIP(h, hipMemcpy(A.colidx, colidx, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-    LZ_HIP(h, hipMemcpy(A.vals, vals, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
-  }
+  int fixed_k = 0, max_nnz = 0;
+  LZ_TRY(upload_csr(h, h->csr, "lz_set_csr", rows_local, ncols_ext, nnz, rowptr, colidx, vals, &fixed_k, &max_nnz));
   return finish_csr(h, rowptr, M_global, row0, rows_local, ncols_ext, nnz, fixed_k, max_nnz);
 }
 
@@ -1131,6 +1168,209 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     h->acc.total_ms += ms;
     h->run_timed = false;
   }
+  return LZ_OK;
+}
+
+// ---- two-sided (bi-orthogonal) Lanczos ------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+double* bi_base(lz_handle h, int which) {  // 0 = Q (the published basis), 1 = P, 2 = Qb, 3 = Pb
+  return which == 0 ? h->d_V : h->d_B3 + (size_t)(which - 1) * (size_t)h->n * (size_t)h->ldv;
+}
+double* bi_row(lz_handle h, int which, int j) { return bi_base(h, which) + (int64_t)j * h->ldv; }
+
+int bi_alloc(lz_handle h, int n, int zero_rows) {
+  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "two-sided Lanczos needs a CSR matrix (lz_set_csr)");
+  if (h->world > 1) return fail(h, LZ_ERR_STATE, "two-sided Lanczos is single-rank only");
+  if (h->rows != h->ncols_ext || h->rows != h->Mg) return fail(h, LZ_ERR_STATE, "two-sided Lanczos needs the whole square matrix on this rank");
+  LZ_TRY(basis_alloc(h, n, zero_rows));
+  const size_t one = (size_t)n * (size_t)h->ldv;
+  if (!h->d_B3 || h->bi_n != n) {
+    LZ_TRY(dev_alloc(h, h->d_B3, 3 * one));
+    LZ_TRY(dev_alloc(h, h->d_s, (size_t)h->ldv));
+    LZ_TRY(dev_alloc(h, h->d_gamma, (size_t)n + 1));
+    LZ_TRY(dev_alloc(h, h->d_bi, 8));
+    h->bi_n = n;
+  }
+  LZ_TRY(ensure_part(h, (size_t)bi_partials_needed()));
+  const size_t zr = (size_t)std::min(zero_rows, n) * (size_t)h->ldv * sizeof(double);
+  for (int w = 1; w < 4; ++w) LZ_HIP(h, hipMemsetAsync(bi_base(h, w), 0, zr, h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_s, 0, (size_t)h->ldv * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_gamma, 0, ((size_t)n + 1) * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_bi, 0, 8 * sizeof(double), h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+// IrrLanczos.py:408-441 on row jj (>= 1).  from_rs: the pair is formed here as (r / beta, s / gamma) with the factors the
+// two-term kernel left in f (driver loop :136-137); otherwise rows jj of Q and P are taken as stored (step API).
+int bi_reorth(lz_handle h, int jj, bool from_rs) {
+  const int64_t len = h->rows_pad;
+  double* S = h->d_bi;
+  double* f = h->d_bi + 4;
+  double *q = bi_row(h, 0, jj), *p = bi_row(h, 1, jj), *qb = bi_row(h, 2, jj), *pb = bi_row(h, 3, jj);
+  const double M = (double)h->rows;
+  Scope sc(h, LZ_K_QTW, (2.0 * jj * 64.0 + 5.0 * 32.0) * M, (2.0 * jj * 12.0) * M);
+  // project q on the orthonormalised p's and p on the orthonormalised q's, one vector at a time (:409-416)
+  for (int i = 0; i < jj; ++i) {
+    const double *a = bi_row(h, 3, i), *b = bi_row(h, 2, i);
+    if (i == 0)
+      launch_bi(from_rs ? 1 : 0, 0, 0, q, p, h->d_r, h->d_s, f, nullptr, nullptr, nullptr, a, b, len, h->d_part, 0, S, f, nullptr, nullptr,
+                h->stream);
+    else
+      launch_bi(0, 1, 0, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, i - 1), bi_row(h, 2, i - 1), S, a, b, len, h->d_part, 0, S, f,
+                nullptr, nullptr, h->stream);
+  }
+  // last axpy + q.p  ->  f = {sqrt|q.p|, sqrt|q.p|, sign(q.p)}; rescale so that q.p = +-1 (:418-420) + the two norms
+  launch_bi(0, 1, 1, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, jj - 1), bi_row(h, 2, jj - 1), S, nullptr, nullptr, len, h->d_part, 1, S,
+            f, nullptr, nullptr, h->stream);
+  launch_bi(1, 0, 2, q, p, q, p, f, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S, f, nullptr, nullptr, h->stream);
+  // q_basis[jj] = q / |q|, p_basis[jj] = p / |p| (:423-424), made orthogonal to the earlier basis vectors (:427-434)
+  for (int i = 0; i < jj; ++i) {
+    const double *a = bi_row(h, 2, i), *b = bi_row(h, 3, i);
+    if (i == 0)
+      launch_bi(1, 0, 0, qb, pb, q, p, f, nullptr, nullptr, nullptr, a, b, len, h->d_part, 0, S, f, nullptr, nullptr, h->stream);
+    else
+      launch_bi(0, 1, 0, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, i - 1), bi_row(h, 3, i - 1), S, a, b, len, h->d_part, 0, S, f,
+                nullptr, nullptr, h->stream);
+  }
+  launch_bi(0, 1, 2, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, jj - 1), bi_row(h, 3, jj - 1), S, nullptr, nullptr, len, h->d_part, 2, S,
+            f, nullptr, nullptr, h->stream);
+  launch_bi(1, 0, 3, qb, pb, qb, pb, f, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S, f, nullptr, nullptr, h->stream);  // :437-438
+  return check_launch(h, "bireorthogonalize");
+}
+
+}  // namespace
+
+extern "C" {
+
+int lz_set_csr_transpose(lz_handle h, int64_t nnz, const int32_t* rowptr, const int32_t* colidx, const double* vals) {
+  if (!h) return LZ_ERR_ARG;
+  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_set_csr_transpose: call lz_set_csr first");
+  if (h->world > 1 || h->rows != h->Mg || h->ncols_ext != h->rows)
+    return fail(h, LZ_ERR_STATE, "lz_set_csr_transpose: needs the whole square matrix on one rank");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  if (!rowptr) {
+    h->has_T = false;
+    h->T_declared = true;
+    return LZ_OK;
+  }
+  if (nnz < 0 || nnz >= (int64_t)1 << 31 || (nnz > 0 && (!colidx || !vals))) return fail(h, LZ_ERR_ARG, "lz_set_csr_transpose: bad nnz or NULL arrays");
+  int fixed_k = 0, max_nnz = 0;
+  h->has_T = false;
+  h->T_declared = false;
+  LZ_TRY(upload_csr(h, h->csrT, "lz_set_csr_transpose", h->rows, h->rows, nnz, rowptr, colidx, vals, &fixed_k, &max_nnz));
+  LZ_TRY(fill_csr_meta(h, h->csrT, rowptr, h->rows, h->rows, nnz, fixed_k, max_nnz));
+  h->has_T = true;
+  h->T_declared = true;
+  return LZ_OK;
+}
+
+int lz_bi_alloc(lz_handle h, int n) {
+  if (!h) return LZ_ERR_ARG;
+  if (n < 1) return fail(h, LZ_ERR_ARG, "n must be >= 1");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  return bi_alloc(h, n, n);
+}
+
+static int bi_check_row(lz_handle h, int which, int j) {
+  if (!h->d_V || !h->d_B3 || h->bi_n != h->n) return fail(h, LZ_ERR_STATE, "no two-sided bases allocated (lz_bi_alloc / lz_run_two_sided)");
+  if (which < 0 || which > 3 || j < 0 || j >= h->n) return fail(h, LZ_ERR_ARG, "basis selector or row index out of range");
+  return LZ_OK;
+}
+
+int lz_bi_set_row(lz_handle h, int which, int j, const double* row) {
+  if (!h || !row) return LZ_ERR_ARG;
+  LZ_TRY(bi_check_row(h, which, j));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpyAsync(bi_row(h, which, j), row, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_bi_get_row(lz_handle h, int which, int j, double* row) {
+  if (!h || !row) return LZ_ERR_ARG;
+  LZ_TRY(bi_check_row(h, which, j));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpyAsync(row, bi_row(h, which, j), (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_step_bireorth(lz_handle h, int j) {
+  if (!h) return LZ_ERR_ARG;
+  LZ_TRY(bi_check_row(h, 0, j));
+  if (j < 1) return fail(h, LZ_ERR_ARG, "lz_step_bireorth: j must be >= 1");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_TRY(bi_reorth(h, j, false));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_run_two_sided(lz_handle h, int n, const double* q0, const double* p0, double* alpha_out, double* beta_out, double* gamma_out) {
+  if (!h) return LZ_ERR_ARG;
+  if (!q0 || !p0 || !alpha_out || !beta_out || !gamma_out) return fail(h, LZ_ERR_ARG, "lz_run_two_sided: NULL buffer");
+  if (n < 2) return fail(h, LZ_ERR_ARG, "lz_run_two_sided: n must be >= 2 (H_eff[0,1] and beta[-1] exist only then)");
+  if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run_two_sided: n cannot be larger than M");
+  if (h->kind == 1 && !h->T_declared)
+    return fail(h, LZ_ERR_STATE, "lz_run_two_sided: call lz_set_csr_transpose first (NULL arrays if H is symmetric)");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_TRY(bi_alloc(h, n, 1));
+  const int64_t len = h->rows_pad;
+  const size_t rowb = (size_t)h->rows * sizeof(double);
+  double* S = h->d_bi;
+  double* f = h->d_bi + 4;
+  LZ_HIP(h, hipMemcpyAsync(bi_row(h, 0, 0), q0, rowb, hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(bi_row(h, 1, 0), p0, rowb, hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+  // q_basis[0] = q0 / |q0|, p_basis[0] = p0 / |p0|  (IrrLanczos.py:113-118)
+  launch_bi(0, 0, 2, bi_row(h, 0, 0), bi_row(h, 1, 0), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S,
+            f, nullptr, nullptr, h->stream);
+  launch_bi(1, 0, 3, bi_row(h, 2, 0), bi_row(h, 3, 0), bi_row(h, 0, 0), bi_row(h, 1, 0), f, nullptr, nullptr, nullptr, nullptr, nullptr, len,
+            h->d_part, 2, S, f, nullptr, nullptr, h->stream);
+  LZ_TRY(check_launch(h, "two-sided start"));
+  const CsrDev& AT = h->has_T ? h->csrT : h->csr;
+  const double M = (double)h->rows;
+  for (int j = 0; j + 1 < n; ++j) {
+    double *qj = bi_row(h, 0, j), *pj = bi_row(h, 1, j);
+    {
+      Scope sc(h, LZ_K_SPMV, 2.0 * spmv_bytes(h), 2.0 * spmv_flops(h));
+      launch_spmv_csr(h->csr, qj, h->d_r, qj, h->d_part, h->flags, h->stream);  // r = H q_j   (:124)
+      launch_spmv_csr(AT, pj, h->d_s, pj, h->d_part, h->flags, h->stream);      // s = HT p_j  (:125)
+      LZ_TRY(check_launch(h, "two-sided spmv"));
+    }
+    {
+      Scope sc(h, LZ_K_THREE, (j > 0 ? 112.0 : 64.0) * M, 12.0 * M);
+      // r -= gamma[j-1] q[j-1]; s -= beta[j-1] p[j-1] (at j = 0 both are the reference's zero rows: skipped);
+      // alpha[j] = (p_j . r + q_j . s) / 2  (:128-132)
+      if (j > 0)
+        launch_bi_two_term(1, 0, h->d_r, h->d_s, bi_row(h, 0, j - 1), bi_row(h, 1, j - 1), h->d_gamma + (j - 1), h->d_beta + (j - 1), pj, qj, len,
+                           h->d_part, f, h->d_alpha + j, nullptr, h->stream);
+      else
+        launch_bi_two_term(0, 0, h->d_r, h->d_s, nullptr, nullptr, nullptr, nullptr, pj, qj, len, h->d_part, f, h->d_alpha + j, nullptr, h->stream);
+      // r -= alpha q_j; s -= alpha p_j; w = r . s; beta[j] = sqrt|w|; gamma[j] = w / beta[j]  (:134-141)
+      launch_bi_two_term(1, 1, h->d_r, h->d_s, qj, pj, h->d_alpha + j, h->d_alpha + j, nullptr, nullptr, len, h->d_part, f, h->d_beta + j,
+                         h->d_gamma + j, h->stream);
+      LZ_TRY(check_launch(h, "two-sided recurrence"));
+    }
+    LZ_TRY(bi_reorth(h, j + 1, true));  // q[j+1] = r / beta, p[j+1] = s / gamma, then bireorthogonalize (:142-161)
+  }
+  // alpha[n-1] = q[n-1] . r with the LAST iteration's residual (:163)
+  launch_bi_two_term(0, 2, h->d_r, nullptr, nullptr, nullptr, nullptr, nullptr, bi_row(h, 0, n - 1), nullptr, len, h->d_part, f, h->d_alpha + (n - 1),
+                     nullptr, h->stream);
+  LZ_TRY(check_launch(h, "two-sided last alpha"));
+  LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(gamma_out, h->d_gamma, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
+  h->acc.total_ms += ms;
+  h->last_sweeps = n - 1;
   return LZ_OK;
 }
 

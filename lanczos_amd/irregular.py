@@ -1,13 +1,11 @@
-"""``IrrLanczos`` - drop-in for the symmetric half of the reference's
-Python/Irregular/IrrLanczos.py (``execute_LanczosOld`` and friends)."""
+"""``IrrLanczos`` - drop-in for the reference's Python/Irregular/IrrLanczos.py: the symmetric solver
+(``execute_LanczosOld`` and friends) and the two-sided (bi-orthogonal) variant ``execute_Lanczos`` /
+``bireorthogonalize`` (IrrLanczos.py:77-187, 390-443), both executed by liblanczos_hip.so."""
 import numpy as np
+import scipy.sparse
 
-from ._solver import LanczosBase
-
-_TWO_SIDED = (
-    "the two-sided (bi-orthogonal) Lanczos of IrrLanczos.py:77-187/390-443 is outside this build's hot path "
-    "(SURVEY.md section 2 #3: broken at the reference snapshot, no valid oracle); use execute_LanczosOld"
-)
+from . import _capi
+from ._solver import LanczosBase, _CPU_MSG, _pack_matrix
 
 
 class IrrLanczos(LanczosBase):
@@ -21,10 +19,75 @@ class IrrLanczos(LanczosBase):
         self._execute(n, seed, use_cuda, v0)
 
     def execute_Lanczos(self, n, seed=99, use_cuda=True, v0=None, dtype=np.float64):
+        """Two-sided Lanczos (IrrLanczos.py:77-187): right/left Krylov bases ``q``/``p`` of ``H`` and ``H^T`` with
+        ``q_i . p_j = +-delta_ij``, every new pair bi-orthogonalised against orthonormalised copies of the bases
+        (``bireorthogonalize``).  Publishes the non-symmetric tridiagonal ``H_eff`` (sub-diagonal ``beta``,
+        super-diagonal ``gamma``, laid out as :165-174 does) and ``V = q.T``.
+
+        Reference behaviour kept: only ``v0=None`` works (the second start vector exists only on that branch, :98-102);
+        the start pair comes from the global legacy RNG (two draws) and is scaled to ``q0 . p0 = +-1``; no breakdown
+        check.  ``dtype`` other than float64 is not supported by the device path."""
         if n > self.M:
             raise ValueError("n cannot be larger than M!")
         assert np.shape(self.H)[0] == np.shape(self.H)[1]
-        raise NotImplementedError(_TWO_SIDED)
+        self._say("+++ Executing Lanczos algorithm")
+        self.n = n
+        if not use_cuda:
+            raise NotImplementedError(_CPU_MSG)
+        if np.dtype(dtype) != np.float64:
+            raise NotImplementedError("the device path computes in float64 only")
+        M = self.M
+        H = scipy.sparse.csr_matrix(self.H, dtype=np.float64)          # :91
+        HT = scipy.sparse.csr_matrix(H.transpose(), dtype=np.float64)  # :92
+        np.random.seed(seed)
+        if v0 is None:
+            v0 = np.random.uniform(-1, 1, size=(M))
+            v1 = np.random.uniform(-1, 1, size=(M))
+        else:
+            v0 = np.array(v0)
+            # :104 reads v1, which the reference assigns only when v0 is None
+            raise UnboundLocalError("local variable 'v1' referenced before assignment")
+        dot = np.sqrt(np.abs(np.dot(v0, v1)))
+        v0 = v0 / dot
+        v1 = v1 / dot * np.sign(np.dot(v0, v1))
+        if n < 2:
+            # with n == 1 the loop body never runs and :163 reads an unassigned residual
+            raise UnboundLocalError("local variable 'r' referenced before assignment")
+
+        kind, rowptr, colidx, vals = _pack_matrix(H)
+        _, t_rowptr, t_colidx, t_vals = _pack_matrix(HT)
+        if self._handle is None:
+            self._handle = _capi.Handle(self.device_id)
+        h = self._handle
+        h.set_options(self.options)
+        h.set_csr(M, 0, rowptr, colidx, vals)
+        symmetric = (len(t_colidx) == len(colidx) and np.array_equal(t_rowptr, rowptr) and np.array_equal(t_colidx, colidx)
+                     and np.array_equal(t_vals, vals))
+        if symmetric:
+            h.set_csr_transpose()  # H^T x runs on H: one matrix resident
+        else:
+            h.set_csr_transpose(t_rowptr, t_colidx, t_vals)
+        alpha, beta, gamma = h.run_two_sided(n, v0, v1)
+        self._timings = h.timings()
+        self.sweeps = n - 1
+
+        # H_eff exactly as :165-174 lays it out (row i >= 1 carries gamma[i-1], not gamma[i], right of the diagonal)
+        H_eff = np.zeros((n, n))
+        H_eff[0, 0] = alpha[0]
+        H_eff[0, 1] = gamma[0]
+        H_eff[-1, -2] = beta[-1]
+        H_eff[-1, -1] = alpha[-1]
+        for i in range(1, n - 1):
+            H_eff[i, i - 1] = beta[i - 1]
+            H_eff[i, i] = alpha[i]
+            H_eff[i, i + 1] = gamma[i - 1]
+        self._alpha, self._beta, self._gamma = alpha, beta, gamma
+        self._H_eff = H_eff
+        self._V = None
+        self.H = H  # the reference's GPU branch leaves a SciPy CSR in self.H (:183)
+        self.H_eigs_have_been_found = False
+        self._say("+++ Lanczos executed successfully.")
+        self.Lanczos_has_been_executed = True
 
     def get_H_eigsOld(self):
         self._ritz(("normalized",))
@@ -56,4 +119,28 @@ class IrrLanczos(LanczosBase):
 
     @staticmethod
     def bireorthogonalize(V1, V2, q_basis, p_basis, j, use_cuda=True, mem_safe=False):
-        raise NotImplementedError(_TWO_SIDED)
+        """In place on row ``j`` of the four (n, M) arrays, the reference's default branch (IrrLanczos.py:408-441):
+        project ``V1[j]`` on ``p_basis[:j]`` and ``V2[j]`` on ``q_basis[:j]`` (sequential Gram-Schmidt), rescale the
+        pair to ``V1[j] . V2[j] = +-1``, then extend the two orthonormal bases by row ``j``.  Runs on the device."""
+        if not use_cuda:
+            raise NotImplementedError(_CPU_MSG)
+        if mem_safe:
+            raise NotImplementedError("mem_safe=True (IrrLanczos.py:397-407) is a different, unused arithmetic; "
+                                      "only the default branch is implemented")
+        if j < 1:
+            raise ValueError("bireorthogonalize needs j >= 1")
+        arrs = [np.asarray(a) for a in (V1, V2, q_basis, p_basis)]
+        n, M = arrs[0].shape
+        h = _capi.Handle(LanczosBase.device_id)
+        try:
+            eye_ptr = np.arange(M + 1, dtype=np.int32)
+            h.set_csr(M, 0, eye_ptr, eye_ptr[:-1], np.ones(M))  # length carrier only; no matvec is run
+            h.bi_alloc(n)
+            for which, a in enumerate(arrs):
+                for i in ([j] if which < 2 else range(j)):  # the step reads row j of the pair and rows < j of the bases
+                    h.bi_set_row(which, i, a[i])
+            h.step_bireorth(j)
+            for which, a in enumerate(arrs):
+                a[j] = h.bi_get_row(which, j)
+        finally:
+            h.close()

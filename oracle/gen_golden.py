@@ -42,6 +42,7 @@ import IrrLanczos as ref_irregular  # noqa: E402
 import Hamiltonian as ref_hamiltonian  # noqa: E402
 
 from oracle import lanczos_ref as oracle  # noqa: E402
+from oracle import two_sided_ref  # noqa: E402
 from lanczos_amd import synthetic  # noqa: E402
 
 
@@ -106,6 +107,44 @@ def case(name, H, n, seed=99, v0=None, store_matrix=True, gen=None, keep_V=None)
     print(f"{name:28s} M={M:6d} n={n:5d} ref-vs-oracle max|diff|={diff:.3e} eig[:3]={reg.H_eigvals[:3]}")
 
 
+def two_sided_case(name, H, n, seed=99, gen=None, store_matrix=False):
+    """IrrLanczos.execute_Lanczos (two-sided, IrrLanczos.py:77-187) on the reference's CPU branch; v0=None is the only
+    start the reference supports there."""
+    H = scipy.sparse.csr_matrix(H, dtype=np.float64)
+    H.sort_indices()
+    M = H.shape[0]
+    obj = ref_irregular.IrrLanczos(H)
+    quiet(obj.execute_Lanczos, n, seed=seed, use_cuda=False, v0=None)
+    quiet(obj.get_H_eigs)
+    a, b, g, Q, P, Qb, Pb = two_sided_ref.execute_two_sided(H, n, seed=seed, return_all=True)
+    T = two_sided_ref.build_h_eff(a, b, g)
+    diff = max(np.abs(T - obj._H_eff).max(), np.abs(Q.T - obj._V).max())
+    q0, p0 = two_sided_ref.start_pair(M, seed)
+    data = dict(
+        name=name, M=M, n=n, seed=seed, alpha=a, beta=b, gamma=g, H_eff=obj._H_eff.copy(), H_eigvals=obj.H_eigvals.copy(),
+        q0=q0, p0=p0, ref_vs_oracle_maxabs=diff, numpy_version=np.__version__, scipy_version=scipy.__version__,
+    )
+    if M * n <= 200_000:
+        data["V"] = np.ascontiguousarray(obj._V.T)  # (n, M)
+    if store_matrix:
+        data.update(rowptr=H.indptr.astype(np.int32), colidx=H.indices.astype(np.int32), vals=H.data)
+    if gen is not None:
+        data["generator"] = gen
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
+    print(f"{name:28s} M={M:6d} n={n:5d} ref-vs-oracle max|diff|={diff:.3e} alpha[:3]={a[:3]} eig[:2]={obj.H_eigvals[:2]}")
+
+
+def two_sided_main():
+    two_sided_case("two_sided_lap2d_16x16_n12", synthetic.laplacian_2d_5pt(16, 16).to_scipy(), 12, gen="laplacian_2d_5pt(16, 16)")
+    two_sided_case("two_sided_graph_M2000_n20", synthetic.random_graph_laplacian(2000, 7000, seed=1234).to_scipy(), 20,
+                   gen="random_graph_laplacian(2000, 7000, seed=1234)")
+    rng = np.random.default_rng(11)
+    N = scipy.sparse.random(300, 300, density=0.03, random_state=rng, format="csr") + scipy.sparse.diags(np.linspace(1, 4, 300))
+    two_sided_case("two_sided_nonsym_M300_n10", N, 10, seed=5, store_matrix=True)
+    two_sided_case("two_sided_lap2d_8x8_n2", synthetic.laplacian_2d_5pt(8, 8).to_scipy(), 2, gen="laplacian_2d_5pt(8, 8)")
+
+
 def deuteron_potential(x, y, z):
     # same functional form/constants the reference's driver uses (3Ddeuteron.py:51-61); data, not code of the path
     r = np.sqrt(x**2 + y**2 + z**2)
@@ -115,6 +154,8 @@ def deuteron_potential(x, y, z):
 
 def main():
     os.chdir(os.environ.get("TMPDIR", "/tmp"))  # the reference's Hamiltonian creates ./T_matrices
+    if "--two-sided-only" in sys.argv:
+        return two_sided_main()
 
     # (i) C1: dense 512 x 512 random symmetric, n = 20, explicit v0
     A = synthetic.dense_symmetric(512, seed=0)
@@ -190,6 +231,8 @@ def main():
     case("ragged_M700_n25", R.tocsr(), 25, seed=3)
     # n = 2: smallest n the reference survives (beta has one entry)
     case("lap2d_8x8_n2", synthetic.laplacian_2d_5pt(8, 8).to_scipy(), 2, store_matrix=False, gen="laplacian_2d_5pt(8, 8)")
+    # the Irregular copy's two-sided variant (IrrLanczos.py:77-187)
+    two_sided_main()
 
 
 if __name__ == "__main__":

@@ -26,7 +26,12 @@ def pytest_configure(config):
 
 def golden_names():
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith("hamiltonian")]  # builder fixtures: tests/test_hamiltonian.py
+    # builder fixtures: tests/test_hamiltonian.py; two-sided variant: two_sided_names()
+    return [n for n in names if not n.startswith(("hamiltonian", "two_sided"))]
+
+
+def two_sided_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "two_sided_*.npz")))
 
 
 def load_golden(name):

@@ -6,6 +6,8 @@ import inspect
 import os
 import re
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -103,8 +105,19 @@ def test_error_behaviour_before_any_device_work():
     with pytest.raises(IndexError):
         s.execute_Lanczos(1)
     t = IrrLanczos(H)
-    with pytest.raises(NotImplementedError, match="two-sided"):
-        t.execute_Lanczos(10)
+    # two-sided variant: argument errors come first (as in IrrLanczos.py:78-104), then - with no GPU here - the
+    # device path fails loudly instead of falling back to a CPU implementation
+    with pytest.raises(ValueError, match="n cannot be larger than M!"):
+        t.execute_Lanczos(65)
+    with pytest.raises(UnboundLocalError):
+        t.execute_Lanczos(10, v0=np.ones(64))
+    with pytest.raises(NotImplementedError, match="device path only"):
+        t.execute_Lanczos(10, use_cuda=False)
+    import lanczos_amd._capi as capi
+    ndev = C.c_int(-1)
+    if capi.load_library().lz_device_count(C.byref(ndev)) != 0 or ndev.value == 0:
+        with pytest.raises(capi.LanczosHipError, match="LZ_ERR_NODEVICE"):
+            t.execute_Lanczos(10)
     with pytest.raises(ValueError, match="n cannot be larger than M!"):
         t.execute_LanczosOld(100)
 

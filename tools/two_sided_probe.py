@@ -1,0 +1,37 @@
+"""Timing + accuracy probe of the two-sided (bi-orthogonal) Lanczos path (GPU box only; the oracle is the checker)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lanczos_amd import IrrLanczos, _capi, synthetic  # noqa: E402
+from oracle import two_sided_ref as ts  # noqa: E402
+
+out = {}
+IrrLanczos.verbose = False
+# accuracy vs the oracle on a mid-size case
+A = synthetic.laplacian_2d_5pt(200, 150).to_scipy()
+s = IrrLanczos(A)
+s.execute_Lanczos(16, seed=3)
+a, b, g, Q = ts.execute_two_sided(A, 16, seed=3)
+sc = np.abs(a).max()
+out["accuracy_M3e4_n16"] = {"alpha": (np.abs(s._alpha - a) / sc).tolist(), "gamma": (np.abs(s._gamma - g) / sc).tolist()}
+
+for (nx, ny, n) in [(1000, 1000, 50), (4000, 2500, 24)]:
+    A = synthetic.laplacian_2d_5pt(nx, ny).to_scipy()
+    s = IrrLanczos(A)
+    s.options = _capi.FLAG_PROFILE
+    s.execute_Lanczos(4, seed=1)  # warm-up (code objects)
+    s._handle.timings()
+    t0 = time.perf_counter()
+    s.execute_Lanczos(n, seed=1)
+    wall = time.perf_counter() - t0
+    tm = s._timings
+    M = nx * ny
+    q = tm["qtw"]
+    out[f"M{M}_n{n}"] = {"wall_s": wall, "device_ms": tm["total_ms"], "biorth_ms": q["ms"], "biorth_GBps": q["timed_bytes"] / q["ms"] / 1e6 if q["ms"] else None,
+                         "spmv_ms": tm["spmv"]["ms"], "two_term_ms": tm["three_term"]["ms"], "finite": bool(np.isfinite(s.H_eff).all())}
+print(json.dumps(out))
