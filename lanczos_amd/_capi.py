@@ -119,6 +119,9 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # The host driver of this pool only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails with
+    # "hipIpcGetMemHandle: invalid argument".  Must be in the environment before the HIP runtime initialises.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not os.path.isfile(p):
         raise LanczosHipError(-6, f"HIP extension not built: {p} is missing (run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C lanczos_amd/csrc`)")
     try:

@@ -1180,6 +1180,11 @@ double* bi_base(lz_handle h, int which) {  // 0 = Q (the published basis), 1 = P
   return which == 0 ? h->d_V : h->d_B3 + (size_t)(which - 1) * (size_t)h->n * (size_t)h->ldv;
 }
 double* bi_row(lz_handle h, int which, int j) { return bi_base(h, which) + (int64_t)j * h->ldv; }
+// d_bi[7] doubles as the ticket counter of the single-launch A/B arm (tune[11] == 2: the last block folds the partials
+// behind a __threadfence()).  Measured (tools/two_sided_probe.py, profiles/r01/ab_two_sided_links.json): the agent-scope
+// release has to write back the L2 lines the kernel just dirtied, which costs far more than the launch it saves - 157
+// vs 41 ms at M = 2.6e5, 250 vs 98 ms at M = 1e6, 178 vs 75 ms at M = 1e7, a tie at M = 9e4.  Default: two launches.
+unsigned* bi_ticket(lz_handle h) { return h->tune[11] == 2 ? reinterpret_cast<unsigned*>(h->d_bi + 7) : nullptr; }
 
 int bi_alloc(lz_handle h, int n, int zero_rows) {
   if (h->kind != 1) return fail(h, LZ_ERR_STATE, "two-sided Lanczos needs a CSR matrix (lz_set_csr)");
@@ -1210,6 +1215,7 @@ int bi_reorth(lz_handle h, int jj, bool from_rs) {
   const int64_t len = h->rows_pad;
   double* S = h->d_bi;
   double* f = h->d_bi + 4;
+  unsigned* tk = bi_ticket(h);
   double *q = bi_row(h, 0, jj), *p = bi_row(h, 1, jj), *qb = bi_row(h, 2, jj), *pb = bi_row(h, 3, jj);
   const double M = (double)h->rows;
   Scope sc(h, LZ_K_QTW, (2.0 * jj * 64.0 + 5.0 * 32.0) * M, (2.0 * jj * 12.0) * M);
@@ -1218,27 +1224,27 @@ int bi_reorth(lz_handle h, int jj, bool from_rs) {
     const double *a = bi_row(h, 3, i), *b = bi_row(h, 2, i);
     if (i == 0)
       launch_bi(from_rs ? 1 : 0, 0, 0, q, p, h->d_r, h->d_s, f, nullptr, nullptr, nullptr, a, b, len, h->d_part, 0, S, f, nullptr, nullptr,
-                h->stream);
+                tk, h->stream);
     else
       launch_bi(0, 1, 0, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, i - 1), bi_row(h, 2, i - 1), S, a, b, len, h->d_part, 0, S, f,
-                nullptr, nullptr, h->stream);
+                nullptr, nullptr, tk, h->stream);
   }
   // last axpy + q.p  ->  f = {sqrt|q.p|, sqrt|q.p|, sign(q.p)}; rescale so that q.p = +-1 (:418-420) + the two norms
   launch_bi(0, 1, 1, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, jj - 1), bi_row(h, 2, jj - 1), S, nullptr, nullptr, len, h->d_part, 1, S,
-            f, nullptr, nullptr, h->stream);
-  launch_bi(1, 0, 2, q, p, q, p, f, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S, f, nullptr, nullptr, h->stream);
+            f, nullptr, nullptr, tk, h->stream);
+  launch_bi(1, 0, 2, q, p, q, p, f, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S, f, nullptr, nullptr, tk, h->stream);
   // q_basis[jj] = q / |q|, p_basis[jj] = p / |p| (:423-424), made orthogonal to the earlier basis vectors (:427-434)
   for (int i = 0; i < jj; ++i) {
     const double *a = bi_row(h, 2, i), *b = bi_row(h, 3, i);
     if (i == 0)
-      launch_bi(1, 0, 0, qb, pb, q, p, f, nullptr, nullptr, nullptr, a, b, len, h->d_part, 0, S, f, nullptr, nullptr, h->stream);
+      launch_bi(1, 0, 0, qb, pb, q, p, f, nullptr, nullptr, nullptr, a, b, len, h->d_part, 0, S, f, nullptr, nullptr, tk, h->stream);
     else
       launch_bi(0, 1, 0, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, i - 1), bi_row(h, 3, i - 1), S, a, b, len, h->d_part, 0, S, f,
-                nullptr, nullptr, h->stream);
+                nullptr, nullptr, tk, h->stream);
   }
   launch_bi(0, 1, 2, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, jj - 1), bi_row(h, 3, jj - 1), S, nullptr, nullptr, len, h->d_part, 2, S,
-            f, nullptr, nullptr, h->stream);
-  launch_bi(1, 0, 3, qb, pb, qb, pb, f, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S, f, nullptr, nullptr, h->stream);  // :437-438
+            f, nullptr, nullptr, tk, h->stream);
+  launch_bi(1, 0, 3, qb, pb, qb, pb, f, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S, f, nullptr, nullptr, tk, h->stream);  // :437-438
   return check_launch(h, "bireorthogonalize");
 }
 
@@ -1323,14 +1329,15 @@ int lz_run_two_sided(lz_handle h, int n, const double* q0, const double* p0, dou
   const size_t rowb = (size_t)h->rows * sizeof(double);
   double* S = h->d_bi;
   double* f = h->d_bi + 4;
+  unsigned* tk = bi_ticket(h);
   LZ_HIP(h, hipMemcpyAsync(bi_row(h, 0, 0), q0, rowb, hipMemcpyHostToDevice, h->stream));
   LZ_HIP(h, hipMemcpyAsync(bi_row(h, 1, 0), p0, rowb, hipMemcpyHostToDevice, h->stream));
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
   // q_basis[0] = q0 / |q0|, p_basis[0] = p0 / |p0|  (IrrLanczos.py:113-118)
   launch_bi(0, 0, 2, bi_row(h, 0, 0), bi_row(h, 1, 0), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S,
-            f, nullptr, nullptr, h->stream);
+            f, nullptr, nullptr, tk, h->stream);
   launch_bi(1, 0, 3, bi_row(h, 2, 0), bi_row(h, 3, 0), bi_row(h, 0, 0), bi_row(h, 1, 0), f, nullptr, nullptr, nullptr, nullptr, nullptr, len,
-            h->d_part, 2, S, f, nullptr, nullptr, h->stream);
+            h->d_part, 2, S, f, nullptr, nullptr, tk, h->stream);
   LZ_TRY(check_launch(h, "two-sided start"));
   const CsrDev& AT = h->has_T ? h->csrT : h->csr;
   const double M = (double)h->rows;
@@ -1348,19 +1355,19 @@ int lz_run_two_sided(lz_handle h, int n, const double* q0, const double* p0, dou
       // alpha[j] = (p_j . r + q_j . s) / 2  (:128-132)
       if (j > 0)
         launch_bi_two_term(1, 0, h->d_r, h->d_s, bi_row(h, 0, j - 1), bi_row(h, 1, j - 1), h->d_gamma + (j - 1), h->d_beta + (j - 1), pj, qj, len,
-                           h->d_part, f, h->d_alpha + j, nullptr, h->stream);
+                           h->d_part, f, h->d_alpha + j, nullptr, tk, h->stream);
       else
-        launch_bi_two_term(0, 0, h->d_r, h->d_s, nullptr, nullptr, nullptr, nullptr, pj, qj, len, h->d_part, f, h->d_alpha + j, nullptr, h->stream);
+        launch_bi_two_term(0, 0, h->d_r, h->d_s, nullptr, nullptr, nullptr, nullptr, pj, qj, len, h->d_part, f, h->d_alpha + j, nullptr, tk, h->stream);
       // r -= alpha q_j; s -= alpha p_j; w = r . s; beta[j] = sqrt|w|; gamma[j] = w / beta[j]  (:134-141)
       launch_bi_two_term(1, 1, h->d_r, h->d_s, qj, pj, h->d_alpha + j, h->d_alpha + j, nullptr, nullptr, len, h->d_part, f, h->d_beta + j,
-                         h->d_gamma + j, h->stream);
+                         h->d_gamma + j, tk, h->stream);
       LZ_TRY(check_launch(h, "two-sided recurrence"));
     }
     LZ_TRY(bi_reorth(h, j + 1, true));  // q[j+1] = r / beta, p[j+1] = s / gamma, then bireorthogonalize (:142-161)
   }
   // alpha[n-1] = q[n-1] . r with the LAST iteration's residual (:163)
   launch_bi_two_term(0, 2, h->d_r, nullptr, nullptr, nullptr, nullptr, nullptr, bi_row(h, 0, n - 1), nullptr, len, h->d_part, f, h->d_alpha + (n - 1),
-                     nullptr, h->stream);
+                     nullptr, tk, h->stream);
   LZ_TRY(check_launch(h, "two-sided last alpha"));
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
   LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -22,10 +22,70 @@ namespace lz {
 
 constexpr int kBiMaxBlocks = 1024;
 
+// EPI 0: S[0..K) = sums.                       1: f = {sqrt|S0|, sqrt|S0|, sign(S0)}       2: f = {sqrt S0, sqrt S1, 1}
+//     3: o0[0] = (S0 + S1) / 2  (alpha_j)       4: o0[0] = beta = sqrt|S0|, o1[0] = gamma = S0 / beta, f = {beta, gamma, 1}
+//     5: o0[0] = S0
+template <int EPI>
+__device__ __forceinline__ void bi_epilogue(const double* tot, int K, double* S, double* f, double* o0, double* o1) {
+  if (EPI == 0) {
+    for (int k = 0; k < K; ++k) S[k] = tot[k];
+  } else if (EPI == 1) {
+    const double sc = sqrt(fabs(tot[0]));
+    f[0] = sc;
+    f[1] = sc;
+    f[2] = tot[0] > 0.0 ? 1.0 : (tot[0] < 0.0 ? -1.0 : 0.0);  // np.sign
+  } else if (EPI == 2) {
+    f[0] = sqrt(tot[0]);
+    f[1] = sqrt(tot[1]);
+    f[2] = 1.0;
+  } else if (EPI == 3) {
+    o0[0] = (tot[0] + tot[1]) / 2;
+  } else if (EPI == 4) {
+    const double be = sqrt(fabs(tot[0]));
+    const double ga = tot[0] / be;
+    o0[0] = be;
+    o1[0] = ga;
+    f[0] = be;
+    f[1] = ga;
+    f[2] = 1.0;
+  } else {
+    o0[0] = tot[0];
+  }
+}
+
+// Single-launch links (ticket != nullptr): every block publishes its partials, takes a ticket, and the block that draws
+// the last one folds all partials - in index order, so the result does not depend on which block that is - and runs the
+// epilogue.  __threadfence() is the agent-scope release/acquire pair that makes the partials written on other XCDs
+// (separate, non-coherent L2s) visible.  Saves the second dependent launch of every link of the chain, but the release
+// writes back every L2 line the kernel dirtied, which measured 2-4x slower than the extra launch: A/B arm only (see
+// bi_ticket() in lz_api.hip); the same result kept the main path's second-stage reductions as separate kernels.
+template <int EPI>
+__device__ __forceinline__ void bi_last_block_final(unsigned* ticket, const double* part, int NB, int K, double* S, double* f,
+                                                    double* o0, double* o1, double* sm) {
+  __shared__ int is_last;
+  __shared__ double tot[4];
+  __threadfence();
+  if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == (unsigned)gridDim.x - 1u;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  for (int k = 0; k < K; ++k) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < NB; i += kTPB) acc += __builtin_nontemporal_load(part + (int64_t)k * NB + i);
+    const double t = block_sum(acc, sm);
+    if (threadIdx.x == 0) tot[k] = t;
+  }
+  if (threadIdx.x == 0) {
+    bi_epilogue<EPI>(tot, K, S, f, o0, o1);
+    *ticket = 0u;  // ready for the next launch (stream order)
+  }
+}
+
 template <int FIRST, int PEND, int DOTS>
 __global__ __launch_bounds__(kTPB) void k_bi(double* x, double* y, const double* xs, const double* ys, const double* f,
                                             const double* ap, const double* bp, const double* Sp, const double* a,
-                                            const double* b, int64_t n2, int NB, double* __restrict__ part) {
+                                            const double* b, int64_t n2, int NB, double* __restrict__ part, unsigned* ticket,
+                                            double* S, double* fo) {
   __shared__ double sm[kTPB / 64];
   double fx = 1.0, fy = 1.0, sg = 1.0, cx = 0.0, cy = 0.0;
   if (FIRST) {
@@ -98,13 +158,14 @@ __global__ __launch_bounds__(kTPB) void k_bi(double* x, double* y, const double*
     const double t = block_sum(v[k], sm);
     if (threadIdx.x == 0) part[(int64_t)k * NB + blockIdx.x] = t;
   }
+  if (ticket) bi_last_block_final<DOTS>(ticket, part, NB, K, S, fo, nullptr, nullptr, sm);  // DOTS d pairs with epilogue d
 }
 
 // r = r - c0 * u ; s = s - c1 * v  (SUB), then DOTS 0: [da . r, db . s]   1: [r . s]   2: [da . r]
 template <int SUB, int DOTS>
 __global__ __launch_bounds__(kTPB) void k_bi_two_term(double* r, double* s, const double* u, const double* v, const double* c0p,
                                                      const double* c1p, const double* da, const double* db, int64_t n2, int NB,
-                                                     double* __restrict__ part) {
+                                                     double* __restrict__ part, unsigned* ticket, double* fo, double* o0, double* o1) {
   __shared__ double sm[kTPB / 64];
   const double c0 = SUB ? c0p[0] : 0.0, c1 = SUB ? c1p[0] : 0.0;
   double2* r2 = reinterpret_cast<double2*>(r);
@@ -147,11 +208,10 @@ __global__ __launch_bounds__(kTPB) void k_bi_two_term(double* r, double* s, cons
     t = block_sum(a1, sm);
     if (threadIdx.x == 0) part[(int64_t)NB + blockIdx.x] = t;
   }
+  if (ticket) bi_last_block_final<DOTS + 3>(ticket, part, NB, DOTS == 0 ? 2 : 1, nullptr, fo, o0, o1, sm);
 }
 
-// EPI 0: S[0..K) = sums.                       1: f = {sqrt|S0|, sqrt|S0|, sign(S0)}       2: f = {sqrt S0, sqrt S1, 1}
-//     3: o0[0] = (S0 + S1) / 2  (alpha_j)       4: o0[0] = beta = sqrt|S0|, o1[0] = gamma = S0 / beta, f = {beta, gamma, 1}
-//     5: o0[0] = S0
+// Two-launch variant of the fold (ticket == nullptr; A/B arm): one block, same epilogues.
 constexpr int kBiFinalThreads = 1024;
 template <int EPI>
 __global__ __launch_bounds__(kBiFinalThreads) void k_bi_final(const double* __restrict__ part, int NB, int K, double* __restrict__ S,
@@ -174,31 +234,7 @@ __global__ __launch_bounds__(kBiFinalThreads) void k_bi_final(const double* __re
     }
     __syncthreads();
   }
-  if (threadIdx.x != 0) return;
-  if (EPI == 0) {
-    for (int k = 0; k < K; ++k) S[k] = tot[k];
-  } else if (EPI == 1) {
-    const double sc = sqrt(fabs(tot[0]));
-    f[0] = sc;
-    f[1] = sc;
-    f[2] = tot[0] > 0.0 ? 1.0 : (tot[0] < 0.0 ? -1.0 : 0.0);  // np.sign
-  } else if (EPI == 2) {
-    f[0] = sqrt(tot[0]);
-    f[1] = sqrt(tot[1]);
-    f[2] = 1.0;
-  } else if (EPI == 3) {
-    o0[0] = (tot[0] + tot[1]) / 2;
-  } else if (EPI == 4) {
-    const double be = sqrt(fabs(tot[0]));
-    const double ga = tot[0] / be;
-    o0[0] = be;
-    o1[0] = ga;
-    f[0] = be;
-    f[1] = ga;
-    f[2] = 1.0;
-  } else {
-    o0[0] = tot[0];
-  }
+  if (threadIdx.x == 0) bi_epilogue<EPI>(tot, K, S, f, o0, o1);
 }
 
 static int bi_grid(int64_t n2) {
@@ -211,11 +247,11 @@ int bi_partials_needed() { return 4 * kBiMaxBlocks; }
 
 void launch_bi(int first, int pend, int dots, double* x, double* y, const double* xs, const double* ys, const double* f,
                const double* ap, const double* bp, const double* Sp, const double* a, const double* b, int64_t len, double* part,
-               int epi, double* S, double* fo, double* o0, double* o1, hipStream_t s) {
+               int epi, double* S, double* fo, double* o0, double* o1, unsigned* ticket, hipStream_t s) {
   const int64_t n2 = len >> 1;
   const int NB = bi_grid(n2);
   const dim3 g(NB), t(kTPB);
-#define LZ_BI(F, P, D) hipLaunchKernelGGL((k_bi<F, P, D>), g, t, 0, s, x, y, xs, ys, f, ap, bp, Sp, a, b, n2, NB, part)
+#define LZ_BI(F, P, D) hipLaunchKernelGGL((k_bi<F, P, D>), g, t, 0, s, x, y, xs, ys, f, ap, bp, Sp, a, b, n2, NB, part, ticket, S, fo)
   const int key = first * 100 + pend * 10 + dots;
   switch (key) {
     case 100: LZ_BI(1, 0, 0); break;  // first link of a Gram-Schmidt chain, pair formed from a scaled source
@@ -229,7 +265,7 @@ void launch_bi(int first, int pend, int dots, double* x, double* y, const double
     default: break;
   }
 #undef LZ_BI
-  if (dots == 3) return;
+  if (dots == 3 || ticket) return;
   const int K = dots == 0 ? 4 : (dots == 1 ? 1 : 2);
   const dim3 g1(1), t1(kBiFinalThreads);
   switch (epi) {
@@ -241,20 +277,20 @@ void launch_bi(int first, int pend, int dots, double* x, double* y, const double
 
 void launch_bi_two_term(int sub, int dots, double* r, double* sv, const double* u, const double* v, const double* c0, const double* c1,
                         const double* da, const double* db, int64_t len, double* part, double* fo, double* o0, double* o1,
-                        hipStream_t s) {
+                        unsigned* ticket, hipStream_t s) {
   const int64_t n2 = len >> 1;
   const int NB = bi_grid(n2);
   const dim3 g(NB), t(kTPB), g1(1), t1(kBiFinalThreads);
-#define LZ_TT(S_, D_) hipLaunchKernelGGL((k_bi_two_term<S_, D_>), g, t, 0, s, r, sv, u, v, c0, c1, da, db, n2, NB, part)
+#define LZ_TT(S_, D_) hipLaunchKernelGGL((k_bi_two_term<S_, D_>), g, t, 0, s, r, sv, u, v, c0, c1, da, db, n2, NB, part, ticket, fo, o0, o1)
   if (dots == 0) {
     if (sub) LZ_TT(1, 0); else LZ_TT(0, 0);
-    hipLaunchKernelGGL((k_bi_final<3>), g1, t1, 0, s, part, NB, 2, nullptr, fo, o0, o1);
+    if (!ticket) hipLaunchKernelGGL((k_bi_final<3>), g1, t1, 0, s, part, NB, 2, nullptr, fo, o0, o1);
   } else if (dots == 1) {
     LZ_TT(1, 1);
-    hipLaunchKernelGGL((k_bi_final<4>), g1, t1, 0, s, part, NB, 1, nullptr, fo, o0, o1);
+    if (!ticket) hipLaunchKernelGGL((k_bi_final<4>), g1, t1, 0, s, part, NB, 1, nullptr, fo, o0, o1);
   } else {
     LZ_TT(0, 2);
-    hipLaunchKernelGGL((k_bi_final<5>), g1, t1, 0, s, part, NB, 1, nullptr, fo, o0, o1);
+    if (!ticket) hipLaunchKernelGGL((k_bi_final<5>), g1, t1, 0, s, part, NB, 1, nullptr, fo, o0, o1);
   }
 #undef LZ_TT
 }
