@@ -42,8 +42,17 @@ WORKLOADS = {
     "lap2d_5pt_M2.5e6_k200": ("lap2d", (4000, 625), 200),   # ... at N = 4
     "lap2d_5pt_M5e6_k200": ("lap2d", (4000, 1250), 200),    # ... at N = 2
     "deuteron3d_N160_27pt_k400": ("deuteron27", (160,), 400),  # the reference's largest configured run (3Ddeuteron.py:63-95)
+    "dense_M512_k20": ("dense_c1", (512,), 20),             # configs[0]: 512 x 512 random symmetric
+    "dense_M32768_k100": ("dense", (32768,), 100),          # synthetic dense, 8.6 GB matrix (GEMV-bound)
+    "dense_M131072_k100": ("dense", (131072,), 100),        # 137 GB matrix: 8 GPUs (17 GB block per rank)
     "tiny": ("lap2d", (256, 128), 24),
 }
+
+
+def workload_rows(kind, dims):
+    if kind == "graph" or kind.startswith("dense"):
+        return dims[0]
+    return dims[0] ** 3 if kind == "deuteron27" else int(np.prod(dims))
 
 
 def build_local(kind, dims, lo, hi):
@@ -56,6 +65,10 @@ def build_local(kind, dims, lo, hi):
     if kind == "graph":
         full = synthetic.random_graph_laplacian(dims[0], dims[1], seed=1234)
         return full.row_slice(lo, hi)
+    if kind == "dense":  # counter-based symmetric entries: each rank generates only its row block
+        return synthetic.dense_symmetric_hashed(dims[0], rows=(lo, hi))
+    if kind == "dense_c1":  # default_rng(0).standard_normal, (A + A^T) / 2
+        return np.ascontiguousarray(synthetic.dense_symmetric(dims[0], seed=0)[lo:hi])
     if kind == "deuteron27":  # H = -T + V of 3Ddeuteron.py, assembled on the device by the Hamiltonian mirror
         from lanczos_amd import Hamiltonian
 
@@ -77,12 +90,13 @@ def cpu_baseline(kind, dims, k, budget_s=40.0):
     from lanczos_amd import synthetic
     from oracle import lanczos_ref as oracle
 
-    M = dims[0] if kind == "graph" else (dims[0] ** 3 if kind == "deuteron27" else int(np.prod(dims)))
+    M = workload_rows(kind, dims)
     avail = psutil.virtual_memory().available
     n_cpu = k
     while 3.3 * 8 * n_cpu * M > 0.6 * avail and n_cpu > 8:
         n_cpu //= 2
-    H = build_local(kind, dims, 0, M).to_scipy()
+    H = build_local(kind, dims, 0, M)
+    H = H.to_scipy() if hasattr(H, "to_scipy") else oracle.as_operator(H)  # dense: CSR, as the reference's GPU branch converts it
     v0 = oracle.start_vector(M, 99)
     V = np.zeros((n_cpu, M))
     V[0] = v0
@@ -170,7 +184,7 @@ def main():
     kind, dims, k = WORKLOADS[args.workload]
     if args.k:
         k = args.k
-    M = dims[0] if kind == "graph" else (dims[0] ** 3 if kind == "deuteron27" else int(np.prod(dims)))
+    M = workload_rows(kind, dims)
     bounds = partition.row_bounds(M, world)
     lo, hi = bounds[rank], bounds[rank + 1]
 

@@ -135,6 +135,11 @@ int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, 
  * conversion the reference's GPU path performs for ndarray input
  * (1Dbox.py:27 -> Lanczos.py:88) with a real dense GEMV. */
 int lz_set_dense(lz_handle h, int64_t M, const double* A);
+/* Row block [row0, row0 + rows_local) of a dense symmetric A split over ranks (the north star's dense multi-GPU case;
+ * nothing to mirror in the single-process reference).  A is rows_local x ncols_ext row-major with the columns laid out
+ * like the all-gathered vector: rank q's entries at [q * chunk, q * chunk + rows_q), zero columns in the padding
+ * (ncols_ext = world * chunk; follow with lz_set_allgather(h, chunk)).  One rank: rows_local = ncols_ext = M_global. */
+int lz_set_dense_block(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext, const double* A);
 /* Assemble the reference's regular-grid Hamiltonian directly in device CSR (replaces the
  * Python-loop COO build of Python/Regular/Hamiltonian.py:45-128 plus `H = -T + V; H.sort_indices()` of
  * 3Ddeuteron.py:80-81): periodic N^3 grid, flat index x + y N + z N^2, `points` = 7 or 27, weights4 =

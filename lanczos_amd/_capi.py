@@ -72,6 +72,7 @@ SIGNATURES = {
     "lz_comm_init_host": (C.c_int, [_P, C.c_int, C.c_int, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN, HOST_ALLGATHER_FN, _P]),
     "lz_set_csr": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _I32, _I32, _D]),
     "lz_set_dense": (C.c_int, [_P, C.c_int64, _D]),
+    "lz_set_dense_block": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _D]),
     "lz_build_stencil3d": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _D, _D, C.c_int]),
     "lz_csr_info": (C.c_int, [_P, _I64, _I64]),
     "lz_get_csr": (C.c_int, [_P, _I32, _I32, _D]),
@@ -287,6 +288,13 @@ class Handle:
             raise ValueError("dense H must be square")
         self.check(self.lib.lz_set_dense(self._h, A.shape[0], dptr(A)))
         self.rows = A.shape[0]
+
+    def set_dense_block(self, M_global, row0, A_block):
+        """Row block of a dense matrix split over ranks; columns already in the all-gather layout (see the header)."""
+        A_block = f64(A_block)
+        rows, ncols_ext = A_block.shape
+        self.check(self.lib.lz_set_dense_block(self._h, int(M_global), int(row0), rows, ncols_ext, dptr(A_block)))
+        self.rows = rows
 
     def build_stencil3d(self, N, points, T_factor, weights4, potential=None, negate_T=False):
         w = f64(weights4)

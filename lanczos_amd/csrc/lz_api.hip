@@ -344,9 +344,9 @@ int ensure_part(lz_handle h, size_t need) {
 
 double spmv_bytes(lz_handle h) {
   if (h->kind == 1) return 12.0 * h->csr.nnz + 4.0 * (h->rows + 1) + 16.0 * h->rows;
-  return 8.0 * (double)h->rows * h->rows + 16.0 * h->rows;
+  return 8.0 * (double)h->rows * (double)h->Mg + 8.0 * (double)h->Mg + 8.0 * h->rows;  // A block, x once, y
 }
-double spmv_flops(lz_handle h) { return h->kind == 1 ? 2.0 * h->csr.nnz : 2.0 * (double)h->rows * h->rows; }
+double spmv_flops(lz_handle h) { return h->kind == 1 ? 2.0 * h->csr.nnz : 2.0 * (double)h->rows * (double)h->Mg; }
 
 // r = A V[j]; d_alpha[j] = sum over ranks of V[j] . r
 int step_spmv(lz_handle h, int j) {
@@ -365,7 +365,7 @@ int step_spmv(lz_handle h, int j) {
     if (h->kind == 1)
       np = launch_spmv_csr(h->csr, x, h->d_r, xown, h->d_part, h->flags, h->stream);
     else
-      np = launch_gemv_dense(h->d_dense, h->rows, h->dense_lda, x, h->d_r, h->d_part, h->stream);
+      np = launch_gemv_dense(h->d_dense, h->rows, h->ncols_ext, h->dense_lda, x, xown, h->d_r, h->d_part, h->stream);
     LZ_TRY(check_launch(h, "spmv"));
   }
   {
@@ -803,30 +803,40 @@ int lz_get_csr(lz_handle h, int32_t* rowptr, int32_t* colidx, double* vals) {
   return LZ_OK;
 }
 
-int lz_set_dense(lz_handle h, int64_t M, const double* A) {
+int lz_set_dense_block(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext, const double* A) {
   if (!h) return LZ_ERR_ARG;
-  if (M <= 0 || !A) return fail(h, LZ_ERR_ARG, "lz_set_dense: bad size or NULL matrix");
-  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_set_dense: dense matrices are single-rank only");
+  if (M_global <= 0 || rows_local <= 0 || row0 < 0 || row0 + rows_local > M_global || ncols_ext < M_global || !A)
+    return fail(h, LZ_ERR_ARG, "lz_set_dense_block: bad sizes or NULL matrix");
+  if (h->world == 1 && (rows_local != M_global || ncols_ext != M_global))
+    return fail(h, LZ_ERR_ARG, "lz_set_dense_block: a single rank owns the whole square matrix");
   LZ_HIP(h, hipSetDevice(h->dev));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
   h->kind = 0;
   LZ_TRY(dev_free(h, h->d_V));
   h->n = 0;
-  const int64_t lda = (M + 1) & ~(int64_t)1;
-  LZ_TRY(dev_alloc(h, h->d_dense, (size_t)M * lda + 2));
-  if (lda != M) LZ_HIP(h, hipMemset(h->d_dense, 0, ((size_t)M * lda + 2) * sizeof(double)));
-  LZ_HIP(h, hipMemcpy2D(h->d_dense, (size_t)lda * sizeof(double), A, (size_t)M * sizeof(double), (size_t)M * sizeof(double), (size_t)M,
-                        hipMemcpyHostToDevice));
+  const int64_t lda = (ncols_ext + 1) & ~(int64_t)1;
+  LZ_TRY(dev_alloc(h, h->d_dense, (size_t)rows_local * lda + 2));
+  if (lda != ncols_ext) LZ_HIP(h, hipMemset(h->d_dense, 0, ((size_t)rows_local * lda + 2) * sizeof(double)));
+  LZ_HIP(h, hipMemcpy2D(h->d_dense, (size_t)lda * sizeof(double), A, (size_t)ncols_ext * sizeof(double), (size_t)ncols_ext * sizeof(double),
+                        (size_t)rows_local, hipMemcpyHostToDevice));
   h->dense_lda = lda;
-  h->Mg = M;
-  h->row0 = 0;
-  h->rows = M;
-  h->ncols_ext = M;
-  h->rows_pad = round_up(M, kPadDoubles);
+  h->Mg = M_global;
+  h->row0 = row0;
+  h->rows = rows_local;
+  h->ncols_ext = ncols_ext;
+  h->rows_pad = round_up(rows_local, kPadDoubles);
   h->ldv = h->rows_pad;
   h->xmode = 0;
   h->kind = 2;
+  h->T_declared = false;
+  h->bi_n = 0;
   return LZ_OK;
+}
+
+int lz_set_dense(lz_handle h, int64_t M, const double* A) {
+  if (!h) return LZ_ERR_ARG;
+  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_set_dense: one rank, whole matrix; use lz_set_dense_block + lz_set_allgather for a row partition");
+  return lz_set_dense_block(h, M, 0, M, M, A);
 }
 
 int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* send_counts, const int32_t* send_idx,
@@ -906,7 +916,7 @@ int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* se
 
 int lz_set_allgather(lz_handle h, int64_t chunk) {
   if (!h) return LZ_ERR_ARG;
-  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_set_allgather: call lz_set_csr first");
+  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "lz_set_allgather: call lz_set_csr / lz_set_dense_block first");
   if (chunk < h->rows_pad || chunk % kPadDoubles != 0 || chunk * h->world != h->ncols_ext)
     return fail(h, LZ_ERR_ARG, "lz_set_allgather: chunk must be a multiple of 32, >= padded rows, and world*chunk == ncols_ext");
   LZ_HIP(h, hipSetDevice(h->dev));
@@ -1053,7 +1063,7 @@ int lz_spmv_host(lz_handle h, const double* x, double* y) {
   if (h->kind == 1)
     launch_spmv_csr(h->csr, dx, dy, dx, h->d_part, h->flags, h->stream);
   else
-    launch_gemv_dense(h->d_dense, h->rows, h->dense_lda, dx, dy, h->d_part, h->stream);
+    launch_gemv_dense(h->d_dense, h->rows, h->ncols_ext, h->dense_lda, dx, dx, dy, h->d_part, h->stream);
   LZ_TRY(check_launch(h, "spmv"));
   LZ_HIP(h, hipMemcpyAsync(y, dy, (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));

@@ -42,7 +42,8 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
                     hipStream_t s);
 void launch_build_stencil3d(int N, int points, double tf, const double* w, int negate, const double* pot, int32_t* rowptr,
                             int32_t* colidx, double* vals, hipStream_t s);
-int launch_gemv_dense(const double* A, int64_t M, int64_t lda, const double* x, double* y, double* part, hipStream_t s);
+int launch_gemv_dense(const double* A, int64_t M, int64_t cols, int64_t lda, const double* x, const double* x_own, double* y,
+                      double* part, hipStream_t s);
 
 // out[0] = sum(part[0..n)) (fixed order)
 void launch_final_sum(const double* part, int n, double* out, hipStream_t s);

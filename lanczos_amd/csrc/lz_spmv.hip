@@ -253,9 +253,11 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
 // ------------------------------------------------------------------ dense GEMV (row-major A)
 // One wave per row, 16-byte non-temporal loads of the row (A is streamed once per matvec), x through L1/L2,
 // 4 independent accumulators per lane; wave-shuffle reduction; alpha partial per block.
-__global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ A, int64_t M, int64_t lda,
-                                                    const double* __restrict__ x, double* __restrict__ y,
-                                                    double* __restrict__ part) {
+// rows x cols block of a row-partitioned matrix: x has `cols` entries (the whole vector, or the all-gathered padded
+// layout when the matrix is split over ranks), x_own the `rows` entries this rank owns (for the alpha partial).
+__global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ A, int64_t M, int64_t cols, int64_t lda,
+                                                    const double* __restrict__ x, const double* __restrict__ x_own,
+                                                    double* __restrict__ y, double* __restrict__ part) {
   __shared__ double sm[kTPB / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * (kTPB / 64) + w;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ 
     {
       const double2* a2 = reinterpret_cast<const double2*>(a);
       const double2* x2 = reinterpret_cast<const double2*>(x);
-      const int64_t m2 = M >> 1;
+      const int64_t m2 = cols >> 1;
       int64_t p = lane;
       for (; p + 64 < m2; p += 128) {
         const double2 u = ld_stream<1>(a2 + p), v = ld_stream<1>(a2 + p + 64);
@@ -285,20 +287,21 @@ __global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ 
       }
       c = 2 * m2;
     }
-    for (c += lane; c < M; c += 64) acc0 = fma(a[c], x[c], acc0);  // odd M: the last column
+    for (c += lane; c < cols; c += 64) acc0 = fma(a[c], x[c], acc0);  // odd column count: the last column
     const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
     if (lane == 0) {
       y[row] = acc;
-      d = x[row] * acc;
+      d = x_own[row] * acc;
     }
   }
   d = block_sum(d, sm);
   if (threadIdx.x == 0) part[blockIdx.x] = d;
 }
 
-int launch_gemv_dense(const double* A, int64_t M, int64_t lda, const double* x, double* y, double* part, hipStream_t s) {
+int launch_gemv_dense(const double* A, int64_t M, int64_t cols, int64_t lda, const double* x, const double* x_own, double* y,
+                      double* part, hipStream_t s) {
   const int grid = (int)((M + kTPB / 64 - 1) / (kTPB / 64));
-  hipLaunchKernelGGL(k_gemv_dense, dim3(grid), dim3(kTPB), 0, s, A, M, lda, x, y, part);
+  hipLaunchKernelGGL(k_gemv_dense, dim3(grid), dim3(kTPB), 0, s, A, M, cols, lda, x, x_own, y, part);
   return grid;
 }
 

@@ -236,7 +236,8 @@ class DistributedLanczos:
 
     ``local`` is this rank's row block as a ``synthetic.CSR``-like object (``rowptr``,
     ``colidx`` with GLOBAL column ids, ``vals``) for the rows ``partition.row_bounds(M, world)``
-    assigns to ``boot.rank``.  Results: ``alpha``, ``beta``, ``H_eff`` replicated; ``V_local``
+    assigns to ``boot.rank`` - or, for a dense ``H``, the ``(rows_local, M)`` ndarray block of those rows (the SpMV input is
+    then all-gathered).  Results: ``alpha``, ``beta``, ``H_eff`` replicated; ``V_local``
     / ``H_eigvecs_local`` hold this rank's rows.
     """
 
@@ -247,6 +248,12 @@ class DistributedLanczos:
         bounds = partition.row_bounds(self.M, self.world)
         self.lo, self.hi = bounds[self.rank], bounds[self.rank + 1]
         rows = self.hi - self.lo
+        self.dense = isinstance(local, np.ndarray)
+        if self.dense:
+            if local.shape != (rows, self.M):
+                raise ValueError(f"rank {self.rank} must own the dense block of rows [{self.lo}, {self.hi}) x {self.M} columns")
+            self._init_dense(local, device_id, backend, options, fused_norm)
+            return
         if len(local.rowptr) != rows + 1:
             raise ValueError(f"rank {self.rank} must own rows [{self.lo}, {self.hi})")
         modes = self.boot.allgather_obj(partition.plan_exchange(local.rowptr, local.colidx, self.M, self.world, self.rank, mode).mode)
@@ -263,6 +270,39 @@ class DistributedLanczos:
         self.h = _capi.Handle(device_id)
         self.h.set_options(options)
         self.backend = backend
+        self._init_comm(backend)
+        self.h.set_csr(self.M, self.lo, local.rowptr, self.plan.colidx, local.vals, ncols_ext=self.plan.ncols_ext)
+        if self.plan.mode == "halo":
+            self.h.set_halo(self.plan.peers, self.plan.send_counts, self.plan.send_idx, self.plan.recv_counts)
+        elif self.plan.mode == "allgather":
+            self.h.set_allgather(self.plan.chunk)
+        self.executed = False
+
+    def _init_dense(self, block, device_id, backend, options, fused_norm):
+        """Dense row block: columns keep their global index (every rank starts at rank * chunk, so the all-gathered
+        padded vector is the global numbering followed by zero padding up to world * chunk)."""
+        from types import SimpleNamespace
+
+        if fused_norm and self.world > 1:
+            options |= _capi.FLAG_FUSED_NORM
+        self.options = options
+        self.h = _capi.Handle(device_id)
+        self.h.set_options(options)
+        self.backend = backend
+        self._init_comm(backend)
+        chunk = partition.chunk_size(self.M, self.world)
+        if self.world == 1:
+            self.h.set_dense(block)
+            self.plan = SimpleNamespace(mode="none", chunk=chunk, ncols_ext=self.M)
+        else:
+            ext = np.zeros((block.shape[0], chunk * self.world))
+            ext[:, : self.M] = block
+            self.h.set_dense_block(self.M, self.lo, ext)
+            self.h.set_allgather(chunk)
+            self.plan = SimpleNamespace(mode="allgather", chunk=chunk, ncols_ext=chunk * self.world)
+        self.executed = False
+
+    def _init_comm(self, backend):
         if self.world > 1:
             if backend == "rccl":
                 uid = None
@@ -279,12 +319,6 @@ class DistributedLanczos:
                 self.h.comm_init_host(self.world, self.rank, self.boot.allreduce_sum, self.boot.exchange, self.boot.allgather_array)
             else:
                 raise ValueError(f"unknown backend {backend!r}")
-        self.h.set_csr(self.M, self.lo, local.rowptr, self.plan.colidx, local.vals, ncols_ext=self.plan.ncols_ext)
-        if self.plan.mode == "halo":
-            self.h.set_halo(self.plan.peers, self.plan.send_counts, self.plan.send_idx, self.plan.recv_counts)
-        elif self.plan.mode == "allgather":
-            self.h.set_allgather(self.plan.chunk)
-        self.executed = False
 
     def start_vector(self, seed=99, v0=None):
         """The reference's start vector (Lanczos.py:93-100), generated identically on every rank."""

@@ -20,6 +20,7 @@ __all__ = [
     "laplacian_3d_7pt",
     "random_graph_laplacian",
     "dense_symmetric",
+    "dense_symmetric_hashed",
     "deuteron_potential",
     "reference_start_vector",
 ]
@@ -120,6 +121,26 @@ def dense_symmetric(M, seed=0):
     """Config C1: ``A = standard_normal((M, M)); (A + A.T) / 2`` with ``default_rng(seed)``."""
     A = np.random.default_rng(seed).standard_normal((M, M))
     return (A + A.T) / 2
+
+
+def dense_symmetric_hashed(M, rows=None, seed=0):
+    """Rows ``[lo, hi)`` of a dense symmetric ``M x M`` matrix whose entry (i, j) is a counter-based hash of
+    (min(i, j), max(i, j), seed) mapped to [-1, 1): every rank of a row partition generates exactly its block, no rank
+    ever holds the whole matrix (the large synthetic dense workloads of bench.py; C1 keeps ``dense_symmetric``)."""
+    lo, hi = (0, M) if rows is None else rows
+    out = np.empty((hi - lo, M))
+    j = np.arange(M, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        for r0 in range(lo, hi, 2048):
+            r1 = min(hi, r0 + 2048)
+            i = np.arange(r0, r1, dtype=np.uint64)[:, None]
+            a, b = np.minimum(i, j), np.maximum(i, j)
+            h = (a * np.uint64(0x9E3779B97F4A7C15)) ^ (b * np.uint64(0xC2B2AE3D27D4EB4F)) ^ np.uint64(seed * 2 + 1)
+            h ^= h >> np.uint64(29)
+            h *= np.uint64(0xBF58476D1CE4E5B9)
+            h ^= h >> np.uint64(32)
+            out[r0 - lo : r1 - lo] = (h >> np.uint64(11)).astype(np.float64) * (2.0 / 2**53) - 1.0
+    return out
 
 
 def deuteron_potential(x, y, z):

@@ -30,7 +30,8 @@ WORKER = textwrap.dedent('''
              ("lap3d", lambda lo, hi: synthetic.laplacian_3d_7pt(24, 20, 18, rows=(lo, hi)), 24 * 20 * 18, "halo", 30),
              ("graph", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 30),
              ("graph_halo", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "halo", 30),
-             ("lap3d_partial", lambda lo, hi: synthetic.laplacian_3d_7pt(20, 18, 16, rows=(lo, hi)), 20 * 18 * 16, "halo", 120)]
+             ("lap3d_partial", lambda lo, hi: synthetic.laplacian_3d_7pt(20, 18, 16, rows=(lo, hi)), 20 * 18 * 16, "halo", 120),
+             ("dense", lambda lo, hi: synthetic.dense_symmetric_hashed(701, rows=(lo, hi), seed=3), 701, "auto", 25)]
     for name, build, M, mode, n in cases:
         b = partition.row_bounds(M, boot.world)
         lo, hi = b[boot.rank], b[boot.rank + 1]
@@ -42,7 +43,8 @@ WORKER = textwrap.dedent('''
         V = s.V_local
         Y = s.H_eigvecs_local
         # single-rank oracle on the full matrix
-        full = build(0, M).to_scipy()
+        full = build(0, M)
+        full = full.to_scipy() if hasattr(full, "to_scipy") else __import__("scipy.sparse").sparse.csr_matrix(full)
         ao, bo, Vo = oracle.execute_lanczos(full, n, economy=True)
         th_o = np.linalg.eigvalsh(oracle.build_h_eff(ao, bo))
         S = np.linalg.eigh(s.H_eff)[1]
@@ -73,6 +75,7 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
     for per_rank in res:
         assert per_rank["lap2d"]["mode"] == "halo" and per_rank["lap3d"]["mode"] == "halo"
         assert per_rank["graph"]["mode"] == "allgather" and per_rank["graph_halo"]["mode"] == "halo"
+        assert per_rank["dense"]["mode"] == "allgather"
         for name, r in per_rank.items():
             if name.endswith("_partial"):
                 # converging run with sweeps: Ritz values of the partial mode vs the oracle's full sweep

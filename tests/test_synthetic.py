@@ -68,3 +68,12 @@ def test_dense_and_start_vector_conventions():
     assert np.array_equal(A, (B + B.T) / 2)
     np.random.seed(99)
     assert np.array_equal(synthetic.reference_start_vector(1000, 99), np.random.uniform(-1, 1, size=1000))
+
+
+def test_dense_symmetric_hashed_is_symmetric_and_row_sliceable():
+    A = synthetic.dense_symmetric_hashed(300, seed=2)
+    assert A.shape == (300, 300) and np.array_equal(A, A.T)
+    assert A.min() >= -1 and A.max() < 1 and abs(A.mean()) < 0.02 and 0.5 < A.std() < 0.65  # ~uniform(-1, 1)
+    B = synthetic.dense_symmetric_hashed(300, rows=(117, 260), seed=2)
+    assert np.array_equal(B, A[117:260])
+    assert not np.array_equal(A, synthetic.dense_symmetric_hashed(300, seed=3))
