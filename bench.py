@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--k", type=int, default=0, help="override the number of Lanczos iterations")
     ap.add_argument("--options", type=int, default=0, help="extra lz_flags (A/B arms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap-arm", action="store_true", help="N > 1: skip the extra halo-overlap measurement")
+    ap.add_argument("--arm-timeout", type=float, default=240.0, help="seconds after which stalled extra arms are abandoned (main line still printed)")
     ap.add_argument("--no-partial", action="store_true", help="skip the extra (untimed-in-value) partial re-orthogonalisation measurement")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents (roofline fields become null)")
     ap.add_argument("--profile-stride", type=int, default=8, help="bracket only every n-th iteration with hipEvents (each event costs ~3 us)")
@@ -250,37 +252,6 @@ def main():
         tr = {"ms": 0.0, "flops": 0.0}
     assert np.isfinite(theta).all()
 
-    # Extra, separately reported: the opt-in partial re-orthogonalisation mode (the north star's "selective" arm).  NOT
-    # part of `value`: the headline reproduces the reference's full sweep at every step.
-    partial = None
-    if not args.no_partial:
-        theta_full = np.linalg.eigvalsh(solver.H_eff)
-        solver.h.set_options(solver.options | _capi.FLAG_REORTH_PARTIAL)
-        solver.execute_Lanczos(k, v0_normalized_local=v0)
-        solver.timings()
-        boot.barrier()
-        solver.h.synchronize()
-        tp = time.perf_counter()
-        for _ in range(2):
-            solver.execute_Lanczos(k, v0_normalized_local=v0)
-        solver.h.synchronize()
-        boot.barrier()
-        tp = time.perf_counter() - tp
-        if world > 1:
-            tp = max(boot.allgather_obj(tp))
-        tmp = solver.timings()
-        theta_part = np.linalg.eigvalsh(solver.H_eff)
-        partial = {
-            "iterations_per_s": round(2 * k / tp, 1), "ms_per_solve": round(1e3 * tp / 2, 3), "sweeps": solver.h.last_sweeps(), "of": k,
-            "max_rel_ritz_diff_vs_full": float(np.abs(theta_part - theta_full).max() / np.abs(theta_full).max()),
-            "spmv_share_of_device_time": round(tmp["spmv"]["ms"] * tmp["spmv"]["launches"] / max(tmp["spmv"]["timed_launches"], 1) / max(tmp["total_ms"], 1e-9), 3),
-            "whole_iteration_gbps": round(sum(tmp[c]["bytes"] for c in ("spmv", "qtw", "update", "three_term")) / max(tmp["total_ms"], 1e-9) / 1e6, 1),
-            "whole_iteration_frac_hbm_peak": round(sum(tmp[c]["bytes"] for c in ("spmv", "qtw", "update", "three_term")) / max(tmp["total_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
-            "note": "opt-in LZ_FLAG_REORTH_PARTIAL (Simon 1984): the reference's sweep kernels run only when semi-orthogonality "
-                    "is about to be lost; basis orthogonal to sqrt(eps), Ritz values to O(eps||A||)",
-        }
-        solver.h.set_options(solver.options)
-
     if rank == 0:
         iters = args.steps * k
         per_class = {}
@@ -335,12 +306,86 @@ def main():
             "setup_s": {"matrix_build": round(t_build, 2)},
             "device": solver.h.device_name(),
             "ritz_min_max": [float(theta.min()), float(theta.max())],
-            "partial_reorth": partial,
+            "partial_reorth": None,
             "ritz_backtransform": {"ms": round(tr["ms"], 3), "tflops": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9, 2),
                                    "bound": "mfma", "peak_tflops": FP64_MFMA_PEAK_TFLOPS,
                                    "frac": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 4),
                                    "note": "Y = V^T-layout x S (M x k x k) FP64 MFMA GEMM, outside the timed steps"},
         }
+    else:
+        line = None
+
+    # ---- extra arms, reported separately and NEVER part of `value`.  They contain collectives; a watchdog prints the
+    # main line and ends every rank if an arm stalls, so the headline result cannot be lost to an experiment.
+    import threading
+
+    def bail():  # pragma: no cover
+        if rank == 0:
+            line["arms"] = "timed out; main result unaffected"
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(args.arm_timeout, bail)
+    watchdog.daemon = True
+    watchdog.start()
+    alpha_main, beta_main = alpha.copy(), beta.copy()
+
+    # (1) the opt-in partial re-orthogonalisation mode (the north star's "selective" arm); the headline reproduces the
+    # reference's full sweep at every step.
+    partial = None
+    if not args.no_partial:
+        theta_full = np.linalg.eigvalsh(solver.H_eff)
+        solver.h.set_options(solver.options | _capi.FLAG_REORTH_PARTIAL)
+        solver.execute_Lanczos(k, v0_normalized_local=v0)
+        solver.timings()
+        boot.barrier()
+        solver.h.synchronize()
+        tp = time.perf_counter()
+        for _ in range(2):
+            solver.execute_Lanczos(k, v0_normalized_local=v0)
+        solver.h.synchronize()
+        boot.barrier()
+        tp = time.perf_counter() - tp
+        if world > 1:
+            tp = max(boot.allgather_obj(tp))
+        tmp = solver.timings()
+        theta_part = np.linalg.eigvalsh(solver.H_eff)
+        partial = {
+            "iterations_per_s": round(2 * k / tp, 1), "ms_per_solve": round(1e3 * tp / 2, 3), "sweeps": solver.h.last_sweeps(), "of": k,
+            "max_rel_ritz_diff_vs_full": float(np.abs(theta_part - theta_full).max() / np.abs(theta_full).max()),
+            "spmv_share_of_device_time": round(tmp["spmv"]["ms"] * tmp["spmv"]["launches"] / max(tmp["spmv"]["timed_launches"], 1) / max(tmp["total_ms"], 1e-9), 3),
+            "whole_iteration_gbps": round(sum(tmp[c]["bytes"] for c in ("spmv", "qtw", "update", "three_term")) / max(tmp["total_ms"], 1e-9) / 1e6, 1),
+            "whole_iteration_frac_hbm_peak": round(sum(tmp[c]["bytes"] for c in ("spmv", "qtw", "update", "three_term")) / max(tmp["total_ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+            "note": "opt-in LZ_FLAG_REORTH_PARTIAL (Simon 1984): the reference's sweep kernels run only when semi-orthogonality "
+                    "is about to be lost; basis orthogonal to sqrt(eps), Ritz values to O(eps||A||)",
+        }
+        solver.h.set_options(solver.options)
+
+
+    # (2) N > 1, stencil halos over RCCL: the same solve with LZ_FLAG_OVERLAP_HALO (faces of V[j] updated first and
+    # exchanged on a second stream behind the interior update).  Off by default until measured on a multi-GPU node -
+    # this arm is that measurement.
+    overlap_arm = None
+    if world > 1 and not args.no_overlap_arm and not args.overlap and solver.plan.mode == "halo" and comm_used == "rccl":
+        solver.h.set_options(solver.options | _capi.FLAG_OVERLAP_HALO)
+        solver.execute_Lanczos(k, v0_normalized_local=v0)
+        boot.barrier()
+        solver.h.synchronize()
+        to = time.perf_counter()
+        for _ in range(2):
+            a_o, b_o = solver.execute_Lanczos(k, v0_normalized_local=v0)
+        solver.h.synchronize()
+        boot.barrier()
+        to = max(boot.allgather_obj(time.perf_counter() - to))
+        solver.timings()
+        overlap_arm = {"iterations_per_s": round(2 * k / to, 1), "ms_per_solve": round(1e3 * to / 2, 3),
+                       "max_abs_coeff_diff_vs_default": float(max(np.abs(a_o - alpha_main).max(), np.abs(b_o - beta_main).max()))}
+        solver.h.set_options(solver.options)
+    watchdog.cancel()
+
+    if rank == 0:
+        line["partial_reorth"] = partial
+        line["halo_overlap_arm"] = overlap_arm
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(kind, dims, k)
