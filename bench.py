@@ -301,8 +301,10 @@ def main():
             "spmv_frac_hbm_peak": per_class.get("spmv", {}).get("frac"),
             "whole_iteration_gbps": round(whole_bytes / (tm["total_ms"] * 1e-3) / 1e9, 1) if tm["total_ms"] > 0 else None,
             "device_ms_per_step": round(tm["total_ms"] / args.steps, 3),
-            "comm_ms_per_step": round(tm["comm"]["ms"] / args.steps, 3),
-            "final_ms_per_step": round(tm["final"]["ms"] / args.steps, 3),
+            "comm_ms_per_step": round(tm["comm"]["ms"] * tm["comm"]["launches"] / max(tm["comm"]["timed_launches"], 1) / args.steps, 3),
+            "comm_avg_us_per_call": round(1e3 * tm["comm"]["ms"] / max(tm["comm"]["timed_launches"], 1), 2),
+            "comm_calls_per_step": tm["comm"]["launches"] // max(args.steps, 1),
+            "final_ms_per_step": round(tm["final"]["ms"] * tm["final"]["launches"] / max(tm["final"]["timed_launches"], 1) / args.steps, 3),
             "setup_s": {"matrix_build": round(t_build, 2)},
             "device": solver.h.device_name(),
             "ritz_min_max": [float(theta.min()), float(theta.max())],
