@@ -382,6 +382,7 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in
   // fused-norm mode (multi-rank): one all-reduce carries [V_i . r (i < j), r . r]; beta and the scaling by
   // 1/beta are applied afterwards.  Only valid for the in-loop call shape (row j is the newest row).
   const bool fused = scale && (h->flags & LZ_FLAG_FUSED_NORM) && !(h->flags & LZ_FLAG_REORTH_PARTIAL) && nrows == j + 1;
+  h->qplan.variant = h->tune[1];  // A/B knob may change between launches on one handle (same allocation for every arm)
   {
     Scope sc(h, LZ_K_QTW, 8.0 * (nrows - 1) * M + (scale && !fused ? 16.0 : 8.0) * M, 2.0 * nrows * M);
     launch_qtw(h->d_V, h->ldv, h->rows_pad, nrows, j, scale ? h->d_r : nullptr, h->d_nrm2, h->d_beta + beta_idx, h->qplan,
@@ -945,6 +946,7 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
   const size_t vsz = (size_t)n * (size_t)h->ldv;
   if (!h->d_V || h->n != n) {
     LZ_TRY(dev_alloc(h, h->d_V, vsz));
+    if (getenv("LZ_DEBUG_PTR")) fprintf(stderr, "[lz] basis %p (%zu bytes, ld %lld)\n", (void*)h->d_V, vsz * sizeof(double), (long long)h->ldv);
     LZ_TRY(dev_alloc(h, h->d_r, (size_t)h->ldv));
     LZ_TRY(dev_alloc(h, h->d_alpha, (size_t)n + 1));
     LZ_TRY(dev_alloc(h, h->d_beta, (size_t)n + 1));

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
 // four basis rows, so one wave-load covers 4 rows x 256 contiguous bytes (whole 128-byte lines, like the VALU kernel)
 // instead of the 16 rows x 64 bytes the 16x16x4 shape forces.  B = the matching w entries broadcast over j; the four
 // block results of a row are added with two cross-lane steps once per tile.  No barrier in the main loop.
-template <int SCALE, int U, int T>
+template <int SCALE, int U, int T, int ABL = 0>  // ABL: timing-only ablation arms (tools/kbench.py), wrong results
 __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                    const double* __restrict__ r, const double* __restrict__ nrm2,
                                                    double* __restrict__ beta_slot, int64_t L, int P,
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   extern __shared__ double2 sw[];
   const int64_t base = (int64_t)blockIdx.x * L;
   const int cnt = (int)(len - base < L ? len - base : L);
-  double self = qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
+  double self = ABL == 4 ? 0.0 : qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
   self = wave_sum(self);  // this wave's share of w.w (lane 0); replaces the streamed row-j result below
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -255,7 +255,9 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   const int pid = blockIdx.x * (kTPB / 64) + w;
   const int eoff = 8 * blk + 2 * lk;                          // this lane's double2 within a step
   const double2* swl = sw + ((m_lo + eoff) >> 1);            // + 16 per step
-  for (int i0 = ((nrows - 1) / (4 * T)) * (4 * T); i0 >= 0; i0 -= 4 * T) {
+  const int i_top = ((nrows - 1) / (4 * T)) * (4 * T);
+  for (int ii = i_top; ii >= 0; ii -= 4 * T) {
+    const int i0 = ABL == 3 ? i_top - ii : ii;  // ABL 3: ascending rows
     const double2* a[T];
     double acc[T];
 #pragma unroll
@@ -274,11 +276,15 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
         for (int t = 0; t < T; ++t) av[t][u] = (s0 + u < nsteps) ? ld_stream<1>(a[t] + 16 * (s0 + u)) : make_double2(0.0, 0.0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const double2 bv = (s0 + u < nsteps) ? swl[16 * (s0 + u)] : make_double2(0.0, 0.0);
+        const double2 bv = ABL == 1 ? make_double2(1.0, 2.0) : ((s0 + u < nsteps) ? swl[16 * (s0 + u)] : make_double2(0.0, 0.0));
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].x, bv.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].y, bv.y, acc[t], 0, 0, 0);
+          if (ABL == 2) {
+            acc[t] += av[t][u].x * bv.x + av[t][u].y * bv.y;
+          } else {
+            acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].x, bv.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].y, bv.y, acc[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -328,6 +334,10 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
       case 10: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
       case 11: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 2, 8>), grid, block, lds, s, LZ_QTW_ARGS); break;
       case 13: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
+      case 21: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no LDS read of w
+      case 22: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;  // VALU instead of MFMA
+      case 23: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;  // ascending rows
+      case 24: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no staging of w
       default:  // measured best (profiles/r01/ab_qtw_mfma4.json): 2 tiles of 4 rows x 4 steps = 8 loads in flight per lane
         hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS);
         break;

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--arms", default="valu:0:")
     ap.add_argument("--what", default="reorth,spmv,three")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--one-handle", action="store_true", help="all arms share ONE handle/allocation (only per-launch knobs: tune 1, 8); "
+                    "separate allocations differ by +-3 % on their own")
     ap.add_argument("--matrix", default="lap2d", help="lap2d | lap3d:N | deuteron27:N | graph:M")
     args = ap.parse_args()
     if args.matrix.startswith("lap3d:"):
@@ -58,6 +60,9 @@ def main():
     n = args.rows
     rows = [rng.standard_normal(M) / np.sqrt(M) for _ in range(3)]
     for name, flags, tune in arms:
+        if args.one_handle and handles:
+            handles.append(handles[0])
+            continue
         h = _capi.Handle(0)
         h.set_options(flags | _capi.FLAG_PROFILE)
         for idx, val in tune:
@@ -73,6 +78,10 @@ def main():
     cref = None
     for rep in range(args.reps + 1):
         for (name, flags, tune), h in zip(arms, handles):
+            if args.one_handle:
+                for idx in (1, 8):
+                    h.set_tuning(idx, dict(tune).get(idx, 0))
+                h.timings()
             if "reorth" in args.what:
                 _, c = h.step_reorth(n - 1, n, scale=False)
                 if args.check:
