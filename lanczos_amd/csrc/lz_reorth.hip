@@ -108,7 +108,7 @@ __device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ld
   return self;
 }
 
-template <int SCALE, int R, int U, int NT = 1>
+template <int SCALE, int R, int U, int NT = 1, int ABL = 0>  // ABL: timing-only ablation arms, wrong results
 __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                   const double* __restrict__ r, const double* __restrict__ nrm2,
                                                   double* __restrict__ beta_slot, int64_t L, int G,
@@ -123,7 +123,10 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
   // Tiles are walked from the newest rows down to row 0: pass 2 (k_update) must add rows in ascending
   // order, so the last ~256 MB this pass reads (rows 0, 1, ...) are the first pass 2 needs - they are still in
   // the Infinity Cache.
-  for (int i0 = ((nrows - 1) / R) * R; i0 >= 0; i0 -= R) {
+  const int i_top = ((nrows - 1) / R) * R;
+  double sink = 0.0;
+  for (int ii = i_top; ii >= 0; ii -= R) {
+    const int i0 = (ABL & 2) ? i_top - ii : ii;  // ABL 2: ascending rows
     const double2* row[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -137,13 +140,18 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
     for (int q = 0; q < R; ++q) acc[q] = 0.0;
 #pragma unroll U
     for (int t = threadIdx.x; t < cnt2; t += kTPB) {
-      const double2 wv = sw[t];
+      const double2 wv = (ABL & 4) ? make_double2(1.0, 2.0) : sw[t];  // ABL 4: no LDS read
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         const double2 v = ld_stream<NT>(row[q] + t);
         acc[q] = fma(v.x, wv.x, acc[q]);
         acc[q] = fma(v.y, wv.y, acc[q]);
       }
+    }
+    if (ABL & 1) {  // ABL 1: no per-tile reduction / barriers / partial stores
+#pragma unroll
+      for (int q = 0; q < R; ++q) sink += acc[q];
+      continue;
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -160,6 +168,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
     }
     __syncthreads();
   }
+  if ((ABL & 1) && sink == 1.2345e300) part[0] = sink;
 }
 
 // MFMA variant.  Lane l of a wave: row r = l & 15 of the current 16-row tile,
@@ -358,6 +367,11 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
   switch (plan.variant) {
     case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
     case 7: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 0>), grid, block, lds, s, LZ_QTW_ARGS); break;  // plain (cached) loads
+    case 31: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no reductions/stores
+    case 32: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;  // ascending
+    case 33: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;  // both
+    case 35: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 5>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no reductions, no LDS
+    case 37: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 7>), grid, block, lds, s, LZ_QTW_ARGS); break;  // all three
     default:  // measured best on MI355X (profiles/r01): 8 rows x 2 positions = 16 loads in flight per lane
       if (nrows > 4)
         hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS);
@@ -452,6 +466,8 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
     if (!ok[p]) pos[p] = n2 - 1;  // valid address, result discarded
   }
   double2 w[P];
+#pragma unroll
+  for (int p = 0; p < P; ++p) w[p] = make_double2(0.0, 0.0);
   if (FUSED) {
     const double b = beta[0];
 #pragma unroll
@@ -477,6 +493,10 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
     for (int u = 0; u < RU; ++u)
       if (k + u < nrows) {
         const double ck = c[k + u];
+        if (!FUSED && k + u == j) {  // row j is V[j] itself (j < nrows): keep it for the final 2 v - t instead of re-reading it
+#pragma unroll
+          for (int p = 0; p < P; ++p) w[p] = q[u][p];
+        }
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           tx[p] = tx[p] + ck * q[u][p].x;
@@ -487,10 +507,7 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
   double2* out = reinterpret_cast<double2*>(V) + (int64_t)j * ld2;
 #pragma unroll
   for (int p = 0; p < P; ++p)
-    if (ok[p]) {
-      const double2 v = FUSED ? w[p] : ld_stream<1>(out + pos[p]);
-      st_stream<1>(out + pos[p], make_double2(2.0 * v.x - tx[p], 2.0 * v.y - ty[p]));
-    }
+    if (ok[p]) st_stream<1>(out + pos[p], make_double2(2.0 * w[p].x - tx[p], 2.0 * w[p].y - ty[p]));
 }
 
 template <bool FUSED, int P, int RU>

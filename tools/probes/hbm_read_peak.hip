@@ -117,6 +117,14 @@ __global__ __launch_bounds__(256) void k_read_slices(const d2* __restrict__ p, s
   }
   if (!PART && acc == 1.2345e300) out[0] = acc;
 }
+__global__ void k_fill_random(double* p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long h = i * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    p[i] = (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  }
+}
+
 int main() {
   const size_t bytes = (size_t)8 << 30, n2 = bytes / 16;
   d2 *a, *b; double* out;
@@ -163,6 +171,23 @@ int main() {
     double* part; hipMalloc(&part, (size_t)G * 4 * 512 * 8);
     time([&] { hipLaunchKernelGGL((k_read_slices<8, 2, 1>), dim3(G), dim3(256), 0, 0, a, ld2, nrows, cnt2, out, part); }, 16.0 * ld2 * (nrows / 8 * 8), "slices R8 U2 + partial store per tile");
     time([&] { hipLaunchKernelGGL((k_read_slices<8, 2, 2>), dim3(G), dim3(256), 0, 0, a, ld2, nrows, cnt2, out, part); }, 16.0 * ld2 * (nrows / 8 * 8), "slices R8 U2 + partials in one nt burst");
+    // occupancy: the real Q.w kernel holds a 40 KB slice of w in LDS (4 blocks per CU); same stream with that much LDS reserved
+    for (int kb : {0, 20, 32, 40, 64}) {
+      char nm[64]; snprintf(nm, 64, "slices R8 U2, %d KB LDS reserved", kb);
+      time([&] { hipLaunchKernelGGL((k_read_slices<8, 2>), dim3(G), dim3(256), (size_t)kb * 1024, 0, a, ld2, nrows, cnt2, out); }, 16.0 * ld2 * (nrows / 8 * 8), nm);
+    }
+    // Sustained rate: the headline solve streams for 0.5 s at a time and carries random mantissas, while the numbers
+    // above are best-of-5 of ~1 ms launches over a constant byte pattern.  3 x 600 back-to-back launches per pattern.
+    for (int pattern = 0; pattern < 2; ++pattern) {
+      if (pattern == 1) { hipLaunchKernelGGL(k_fill_random, dim3(8192), dim3(256), 0, 0, reinterpret_cast<double*>(a), bytes / 8); hipDeviceSynchronize(); }
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        for (int it = 0; it < 600; ++it) hipLaunchKernelGGL((k_read_slices<8, 2>), dim3(G), dim3(256), 0, 0, a, ld2, nrows, cnt2, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("sustained slices R8 U2, %s data, 600 launches: %8.1f ms  %7.1f GB/s\n", pattern ? "random" : "constant", ms, 600.0 * 16.0 * ld2 * (nrows / 8 * 8) / ms / 1e6);
+      }
+    }
   }
   return 0;
 }
