@@ -130,3 +130,17 @@ def test_error_behaviour():
         s.execute_Lanczos(4, use_cuda=False)
     with pytest.raises(ValueError, match="Lanczos Algorithm has not been called."):
         s.H_eff
+
+
+def test_run_to_run_bit_reproducibility_and_handle_reuse():
+    """Fixed-order reductions: two runs give identical bits; the same object can switch between the two-sided and the
+    symmetric solver (the bases are re-planned per run)."""
+    A = synthetic.random_graph_laplacian(5000, 17000, seed=2).to_scipy()
+    IrrLanczos.verbose = False
+    s = IrrLanczos(A)
+    s.execute_Lanczos(12, seed=4)
+    H1, V1 = s.H_eff.copy(), s.V.copy()
+    s.execute_LanczosOld(10, seed=4)
+    assert s.H_eff.shape == (10, 10) and np.array_equal(s.H_eff, s.H_eff.T)
+    s.execute_Lanczos(12, seed=4)
+    assert np.array_equal(H1, s.H_eff) and np.array_equal(V1, s.V)
