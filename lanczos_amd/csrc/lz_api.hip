@@ -179,6 +179,15 @@ int fail(lz_handle h, int code, const std::string& msg) {
     if (rc_ != LZ_OK) return rc_; \
   } while (0)
 
+// Row stride of the basis.  Every streaming kernel has several rows in flight at the SAME column offset, so a stride
+// that is a multiple of a large power of two (M = 2^20, 160^3 = 2^15 * 125, ...) lands them on the same HBM channels.
+// Making stride / 256 B odd spreads consecutive rows over the channel interleave; costs at most 256 B per row.
+// tune[12] = 1 disables the skew (A/B).
+int64_t skew_stride(lz_handle h, int64_t ld) {
+  if (h->tune[12] == 1) return ld;
+  return ((ld / kPadDoubles) & 1) ? ld : ld + kPadDoubles;
+}
+
 int check_launch(lz_handle h, const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -492,7 +501,7 @@ int finish_csr(lz_handle h, const int32_t* rowptr_host, int64_t M_global, int64_
   h->rows = rows_local;
   h->ncols_ext = ncols_ext;
   h->rows_pad = round_up(rows_local, kPadDoubles);
-  h->ldv = h->rows_pad;
+  h->ldv = skew_stride(h, h->rows_pad);
   h->xmode = 0;
   h->kind = 1;
   return LZ_OK;
@@ -826,7 +835,7 @@ int lz_set_dense_block(lz_handle h, int64_t M_global, int64_t row0, int64_t rows
   h->rows = rows_local;
   h->ncols_ext = ncols_ext;
   h->rows_pad = round_up(rows_local, kPadDoubles);
-  h->ldv = h->rows_pad;
+  h->ldv = skew_stride(h, h->rows_pad);
   h->xmode = 0;
   h->kind = 2;
   h->T_declared = false;
@@ -908,7 +917,7 @@ int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* se
   }
   h->total_send = ts;
   h->total_recv = tr;
-  h->ldv = h->rows_pad + round_up(tr, kPadDoubles);
+  h->ldv = skew_stride(h, h->rows_pad + round_up(tr, kPadDoubles));
   h->xmode = 1;
   LZ_TRY(dev_free(h, h->d_V));
   h->n = 0;
@@ -924,7 +933,7 @@ int lz_set_allgather(lz_handle h, int64_t chunk) {
   LZ_TRY(dev_alloc(h, h->d_xfull, (size_t)(chunk * h->world)));
   LZ_HIP(h, hipMemset(h->d_xfull, 0, (size_t)(chunk * h->world) * sizeof(double)));
   h->ag_chunk = chunk;
-  h->ldv = chunk;
+  h->ldv = skew_stride(h, chunk);
   h->xmode = 2;
   LZ_TRY(dev_free(h, h->d_V));
   h->n = 0;

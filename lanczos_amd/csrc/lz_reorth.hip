@@ -12,6 +12,9 @@
 // (compiled with -ffp-contract=off), so SpMV row sums, the re-orthogonalisation
 // update and the three-term recurrence are bit-identical to NumPy/SciPy given
 // the same scalar inputs; only the inner products differ (summation order).
+#include <algorithm>
+#include <cmath>
+
 #include "lz_device.h"
 
 namespace lz {
@@ -312,14 +315,30 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   QtwPlan p;
   int64_t target = (tune && tune[0] > 0) ? tune[0] : 0;
-  // Measured on MI355X (profiles/r01/ab_qtw_slice_small.json): long slices amortise the per-tile reduction, as long
-  // as there are still a few blocks per CU: 5120 (40 KiB LDS, 4 blocks/CU) for >= 1024 blocks, else 2560, 1024, 512.
-  int64_t L;
-  if (target > 0) L = round_up(target, 512);
-  else if (len >= (int64_t)5120 * 1024) L = 5120;
-  else if (len >= (int64_t)2560 * 384) L = 2560;
-  else if (len >= (int64_t)1024 * 256) L = 1024;
-  else L = 512;
+  // Two effects set the slice length (profiles/r01/ab_qtw_slice_balance.json): (a) a CU streams at a fixed share of the
+  // HBM rate, so the pass finishes when the CU with the most blocks does - G blocks on 256 CUs run at
+  // (G/256) / ceil(G/256) of the balanced rate (G = 612 or 815: 80 %, G = 489, 977, 1223: 95 %); (b) every tile ends in a
+  // small reduction + partial stores, which favours long slices (L = 512: -9 %, 1024: -3 %, >= 2560: < 1 %).
+  int64_t L = 512;
+  if (target > 0) {
+    L = round_up(target, 512);
+  } else {
+    // the longest slice that still gives every CU about two blocks and an even share; else the best-balanced one
+    double best = -1.0;
+    bool found = false;
+    for (int64_t cand = kQtwMaxL; cand >= 1024 && !found; cand -= 512) {
+      const int64_t G = (len + cand - 1) / cand;
+      if (G < 480) continue;
+      const double g = (double)G / kNumCU, bal = g / std::ceil(g);
+      if (bal >= 0.93) {
+        L = cand;
+        found = true;
+      } else if (bal * (double)cand / (double)(cand + 48) > best) {
+        best = bal * (double)cand / (double)(cand + 48);
+        L = cand;
+      }
+    }
+  }
   if (L > kQtwMaxL) L = kQtwMaxL;
   p.L = L;
   p.G = (int)((len + L - 1) / L);
@@ -535,12 +554,31 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
       hipLaunchKernelGGL((k_update<false, 1, 8>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r_fused, beta);
     return;
   }
-  // default: slice-owner kernel; pick P so that small vectors still fill the chip
+  // default: slice-owner kernel.  Positions per lane P in {8, 4, 2} (always 16 loads in flight): like the Q.w pass this
+  // one finishes with the most loaded CU, so take the P whose block count spreads most evenly over the 256 CUs
+  // (M = 1.25e6: 306 blocks of P = 8 run at 60 %, 1223 blocks of P = 2 at 95 %); ties go to the larger P.
   const int64_t span = n2 - p0;
-  if (variant == 3 || (variant == 0 && span >= (int64_t)kTPB * 8 * 1024)) {
+  int P = variant == 3 ? 8 : (variant == 4 ? 4 : 0);
+  if (!P) {
+    double best = -1.0;
+    P = 2;
+    for (int cand : {8, 4, 2}) {
+      const int64_t G = (span + (int64_t)kTPB * cand - 1) / ((int64_t)kTPB * cand);
+      const double g = (double)G / kNumCU, bal = g / std::ceil(g);
+      if (bal >= 0.93) {  // 16 loads in flight per lane: one block per CU already keeps the CU's share of HBM busy
+        P = cand;
+        break;
+      }
+      if (bal > best) {
+        best = bal;
+        P = cand;
+      }
+    }
+  }
+  if (P == 8) {
     if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
     else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
-  } else if (variant == 4 || (variant == 0 && span >= (int64_t)kTPB * 4 * 512)) {
+  } else if (P == 4) {
     if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
     else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
   } else {
