@@ -54,6 +54,9 @@ class LanczosBase:
     verbose = True  # the reference prints "+++ ..." progress lines; set False to silence
     device_id = 0
     options = 0     # lz_flags forwarded to lz_set_options (see include/lanczos_hip.h)
+    fused_norm = True  # beta = ||r|| travels with the Q^T r partial sums (c_i = (V_i.r)/beta, V[j] = r/beta formed in the update
+                       # kernel): one pass less over V[j] and one launch less per step, +2 % at the headline; False = scale first,
+                       # then dot, exactly in the reference's order (the coefficients differ by one rounding of a division)
     reorth = "full"  # "full" = the reference's sweep at every step; "partial" = opt-in Simon partial
                      # re-orthogonalisation (same sweep kernels, run only when semi-orthogonality is about to be lost)
     _check_eigs = ("normalized", "orthogonal")  # which asserts get_H_eigs runs (Lanczos.py:157-158)
@@ -153,7 +156,8 @@ class LanczosBase:
         h = self._handle
         if self.reorth not in ("full", "partial"):
             raise ValueError("reorth must be 'full' or 'partial'")
-        h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0))
+        h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0)
+                      | (_capi.FLAG_FUSED_NORM if self.fused_norm else 0))
         if packed[0] == "csr":
             h.set_csr(M, 0, packed[1], packed[2], packed[3])
         else:

@@ -388,7 +388,7 @@ int step_spmv(lz_handle h, int j) {
 // V[j] = r / sqrt(nrm2) (if scale), then c = V[0:nrows] . V[j]; V[j] = 2 V[j] - c^T V[0:nrows]
 int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in_run_loop = false) {
   const double M = (double)h->rows;
-  // fused-norm mode (multi-rank): one all-reduce carries [V_i . r (i < j), r . r]; beta and the scaling by
+  // fused-norm mode (the Python layers default to it): the reduced sums are [V_i . r (i < j), r . r] - one all-reduce at N > 1 -; beta and the scaling by
   // 1/beta are applied afterwards.  Only valid for the in-loop call shape (row j is the newest row).
   const bool fused = scale && (h->flags & LZ_FLAG_FUSED_NORM) && !(h->flags & LZ_FLAG_REORTH_PARTIAL) && nrows == j + 1;
   h->qplan.variant = h->tune[1];  // A/B knob may change between launches on one handle (same allocation for every arm)
@@ -404,16 +404,19 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in
     LZ_TRY(check_launch(h, "final_rows"));
   }
   LZ_TRY(comm_allreduce(h, h->d_c, nrows));
-  if (fused) {
+  const bool overlap = in_run_loop && (h->flags & LZ_FLAG_OVERLAP_HALO) && h->xmode == 1 && h->all_contig && h->comm_kind == 1 &&
+                       !h->peers.empty() && (h->world > 1 || h->tune[6]);
+  // inside lz_run the default (slice-owner) update kernel turns the reduced sums into beta and the coefficients itself
+  const bool raw_c = fused && in_run_loop && !overlap && (h->tune[8] == 0 || h->tune[8] >= 3);
+  if (fused && !raw_c) {
     Scope sc(h, LZ_K_FINAL, 0, 0);
     launch_fused_prepare(h->d_c, j, h->d_beta + beta_idx, h->stream);
     LZ_TRY(check_launch(h, "fused_prepare"));
   }
-  const bool overlap = in_run_loop && (h->flags & LZ_FLAG_OVERLAP_HALO) && h->xmode == 1 && h->all_contig && h->comm_kind == 1 &&
-                       !h->peers.empty() && (h->world > 1 || h->tune[6]);
   if (!overlap) {
     Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + 16.0 * M, 2.0 * nrows * M);
-    launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream);
+    launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream, 0, -1,
+                  raw_c ? 1 : 0);
     LZ_TRY(check_launch(h, "update"));
     return LZ_OK;
   }

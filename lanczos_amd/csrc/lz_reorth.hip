@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t
 template <bool FUSED, int P, int RU>
 __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, int64_t ldv, int64_t p0, int64_t n2, int nrows,
                                                       int j, const double* __restrict__ c, const double* __restrict__ r,
-                                                      const double* __restrict__ beta) {
+                                                      double* __restrict__ beta, int raw_c) {
   const int64_t base = p0 + (int64_t)blockIdx.x * (kTPB * P) + threadIdx.x;
   const int64_t ld2 = ldv >> 1;
   const double2* V2 = reinterpret_cast<const double2*>(V);
@@ -487,8 +487,15 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
   double2 w[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) w[p] = make_double2(0.0, 0.0);
+  // raw_c (fused-norm mode inside lz_run): c still holds the reduced sums [V_0.r, ..., V_{j-1}.r, r.r]; beta and the
+  // coefficients of w = r / beta are formed here with k_fused_prepare's arithmetic (one tiny launch less per step).
+  double bnorm = 1.0;
+  if (FUSED && raw_c) {
+    bnorm = sqrt(c[j]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) beta[0] = bnorm;
+  }
   if (FUSED) {
-    const double b = beta[0];
+    const double b = raw_c ? bnorm : beta[0];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       w[p] = reinterpret_cast<const double2*>(r)[pos[p]];
@@ -511,7 +518,8 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
 #pragma unroll
     for (int u = 0; u < RU; ++u)
       if (k + u < nrows) {
-        const double ck = c[k + u];
+        double ck = c[k + u];
+        if (FUSED && raw_c) ck = (k + u == j) ? ck / (bnorm * bnorm) : ck / bnorm;
         if (!FUSED && k + u == j) {  // row j is V[j] itself (j < nrows): keep it for the final 2 v - t instead of re-reading it
 #pragma unroll
           for (int p = 0; p < P; ++p) w[p] = q[u][p];
@@ -531,13 +539,13 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
 
 template <bool FUSED, int P, int RU>
 static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, int nrows, int j, const double* c, const double* r,
-                                const double* beta, hipStream_t s) {
+                                double* beta, int raw_c, hipStream_t s) {
   const int grid = (int)((n2 - p0 + kTPB * P - 1) / (kTPB * P));
-  hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r, beta);
+  hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r, beta, raw_c);
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
-                   const double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi) {
+                   double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi, int raw_c) {
   // double2 positions [pos_lo, pos_hi) of the row (default: the whole row)
   const int64_t n2 = pos_hi >= 0 ? pos_hi : (len >> 1);
   const int64_t p0 = pos_lo > 0 ? pos_lo : 0;
@@ -576,14 +584,14 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
     }
   }
   if (P == 8) {
-    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
-    else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
+    else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
   } else if (P == 4) {
-    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
-    else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
+    else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
   } else {
-    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
-    else launch_update_slice<false, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, s);
+    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
+    else launch_update_slice<false, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
   }
 }
 

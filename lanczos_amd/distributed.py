@@ -263,8 +263,9 @@ class DistributedLanczos:
         if self.plan.mode == "halo":
             gathered = self.boot.allgather_obj((self.plan.peers, self.plan.send_counts, self.plan.recv_counts))
             partition.check_plans(self.plan, self.rank, gathered)
-        if fused_norm and self.world > 1:
-            # one all-reduce per re-orthogonalisation carries [Q^T r, r.r] (saves a latency-bound collective per iteration)
+        if fused_norm:
+            # ||r||^2 rides with the Q^T r partials: one all-reduce per re-orthogonalisation carries [Q^T r, r.r] (saves a
+            # latency-bound collective per iteration at N > 1, and one pass over V[j] + one launch at any N)
             options |= _capi.FLAG_FUSED_NORM
         self.options = options
         self.h = _capi.Handle(device_id)
@@ -283,7 +284,7 @@ class DistributedLanczos:
         padded vector is the global numbering followed by zero padding up to world * chunk)."""
         from types import SimpleNamespace
 
-        if fused_norm and self.world > 1:
+        if fused_norm:
             options |= _capi.FLAG_FUSED_NORM
         self.options = options
         self.h = _capi.Handle(device_id)
