@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--workload", default="lap2d_5pt_M1e7_k200", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=0, help="override the number of Lanczos iterations")
     ap.add_argument("--options", type=int, default=0, help="extra lz_flags (A/B arms)")
+    ap.add_argument("--tune", default="", help="lz_set_tuning knobs for A/B runs, e.g. 13=1,0=2560")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-arm", action="store_true", help="N > 1: skip the extra halo-overlap measurement")
     ap.add_argument("--arm-timeout", type=float, default=240.0, help="seconds after which stalled extra arms are abandoned (main line still printed)")
@@ -216,6 +217,8 @@ def main():
     # stride-th iteration (centred, so the sampled launches have the same mean basis size as all launches).
     stride = max(1, args.profile_stride)
     solver.h.set_tuning(7, stride)
+    for kv in filter(None, args.tune.split(",")):
+        solver.h.set_tuning(*(int(x) for x in kv.split("=")))
 
     # Setup (not a step): let the runtime finish its one-time work (code-object load of every kernel variant, clock
     # ramp) on a short solve; a ~60 ms one-off stall was observed ~0.1 s after the first launches of a process.
