@@ -101,11 +101,19 @@ __device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ld
     }
   } else {
     const double2* src = SCALE == 2 ? reinterpret_cast<const double2*>(r + base) : vj;
-    for (int t = threadIdx.x; t < cnt2; t += kTPB) {
-      const double2 v = src[t];
-      sw[t] = v;
-      self = fma(v.x, v.x, self);
-      self = fma(v.y, v.y, self);
+    // five positions per trip (a full 5120-slice is two trips): all loads of a trip are issued before the first use -
+    // at launch every resident block stages at once and nothing else hides the latency
+    for (int t0 = threadIdx.x; t0 < cnt2; t0 += 5 * kTPB) {
+      double2 v[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) v[u] = (t0 + u * kTPB < cnt2) ? src[t0 + u * kTPB] : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int u = 0; u < 5; ++u)
+        if (t0 + u * kTPB < cnt2) {
+          sw[t0 + u * kTPB] = v[u];
+          self = fma(v[u].x, v[u].x, self);
+          self = fma(v[u].y, v[u].y, self);
+        }
     }
   }
   return self;
