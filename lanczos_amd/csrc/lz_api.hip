@@ -400,7 +400,7 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in
   }
   {
     Scope sc(h, LZ_K_FINAL, 0, 0);
-    launch_final_rows(h->d_part, nrows, h->qplan.P, h->d_c, h->stream);
+    launch_final_rows(h->d_part, nrows, h->qplan.P, h->d_c, h->stream, h->qplan.family == 2);
     LZ_TRY(check_launch(h, "final_rows"));
   }
   LZ_TRY(comm_allreduce(h, h->d_c, nrows));

@@ -47,8 +47,9 @@ int launch_gemv_dense(const double* A, int64_t M, int64_t cols, int64_t lda, con
 
 // out[0] = sum(part[0..n)) (fixed order)
 void launch_final_sum(const double* part, int n, double* out, hipStream_t s);
-// c[i] = sum_b part[i*G + b]
-void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s);
+// c[i] = sum_b part[i*G + b]; transposed (4x4x4 MFMA kernel): c[i] = sum_b part[b*qtw_ldp(nrows) + i]
+inline int qtw_ldp(int nrows) { return (nrows + 15) & ~15; }
+void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed = false);
 
 struct QtwPlan {
   int64_t L = 0;    // elements of w owned by one block (multiple of 512)

@@ -53,12 +53,42 @@ __global__ __launch_bounds__(kTPB) void k_final_rows(const double* __restrict__ 
   if (threadIdx.x == 0) c[blockIdx.x] = acc;
 }
 
+// Transposed partial layout of the 4x4x4 MFMA kernel: part[pid * ldp + row].  One block owns 8 rows (one 64-byte
+// sector of every pid's run): 128 pid lanes x 8 row lanes, fixed summation order.
+__global__ __launch_bounds__(kFinalThreads) void k_final_rows_t(const double* __restrict__ part, int P, int ldp, int nrows,
+                                                              double* __restrict__ c) {
+  __shared__ double sm[kFinalThreads / 8][8];
+  const int rl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int row = blockIdx.x * 8 + rl;  // < ldp (a multiple of 8); rows >= nrows hold stale values and are never stored
+  const double* p = part + row;
+  constexpr int S = kFinalThreads / 8;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int pid = pl;
+  for (; pid + 3 * S < P; pid += 4 * S) {
+    a0 += p[(int64_t)pid * ldp];
+    a1 += p[(int64_t)(pid + S) * ldp];
+    a2 += p[(int64_t)(pid + 2 * S) * ldp];
+    a3 += p[(int64_t)(pid + 3 * S) * ldp];
+  }
+  for (; pid < P; pid += S) a0 += p[(int64_t)pid * ldp];
+  sm[pl][rl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < 8 && row < nrows) {
+    double t = 0.0;
+    for (int k = 0; k < S; ++k) t += sm[k][threadIdx.x];
+    c[row] = t;
+  }
+}
+
 void launch_final_sum(const double* part, int n, double* out, hipStream_t s) {
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kFinalThreads), 0, s, part, n, out);
 }
-void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s) {
+void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed) {
   if (nrows <= 0) return;
-  hipLaunchKernelGGL(k_final_rows, dim3(nrows), dim3(kTPB), 0, s, part, G, c);
+  if (transposed)
+    hipLaunchKernelGGL(k_final_rows_t, dim3((nrows + 7) / 8), dim3(kFinalThreads), 0, s, part, G, qtw_ldp(nrows), nrows, c);
+  else
+    hipLaunchKernelGGL(k_final_rows, dim3(nrows), dim3(kTPB), 0, s, part, G, c);
 }
 
 // ------------------------------------------------------------------ re-orthogonalisation pass 1: c = Q^T w
@@ -257,9 +287,13 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
 template <int SCALE, int U, int T, int ABL = 0>  // ABL: timing-only ablation arms (tools/kbench.py), wrong results
 __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                    const double* __restrict__ r, const double* __restrict__ nrm2,
-                                                   double* __restrict__ beta_slot, int64_t L, int P,
+                                                   double* __restrict__ beta_slot, int64_t L, int ldp,
                                                    double* __restrict__ part) {
   extern __shared__ double2 sw[];
+  // Per-wave coefficients are parked in LDS (after the slice of w) and written when the wave is done, as one contiguous
+  // run part[pid][0..nrows): 8-byte partial stores trickling into the read stream cost 6 % of the pass
+  // (profiles/r01/ab_qtw_tile_epilogue.json: 1258 -> 1186 us without them), full lines at the end of a block's life do not.
+  double* keep = reinterpret_cast<double*>(sw) + L + (threadIdx.x >> 6) * ldp;
   const int64_t base = (int64_t)blockIdx.x * L;
   const int cnt = (int)(len - base < L ? len - base : L);
   double self = ABL == 4 ? 0.0 : qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
@@ -272,41 +306,69 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   int m_hi = m_lo + sub;
   if (m_hi > cnt) m_hi = cnt;
   const int nsteps = m_hi > m_lo ? (m_hi - m_lo) >> 5 : 0;  // 32 elements (256 B per row) per step
-  const int pid = blockIdx.x * (kTPB / 64) + w;
   const int eoff = 8 * blk + 2 * lk;                          // this lane's double2 within a step
   const double2* swl = sw + ((m_lo + eoff) >> 1);            // + 16 per step
   const int i_top = ((nrows - 1) / (4 * T)) * (4 * T);
-  for (int ii = i_top; ii >= 0; ii -= 4 * T) {
-    const int i0 = ABL == 3 ? i_top - ii : ii;  // ABL 3: ascending rows
-    const double2* a[T];
-    double acc[T];
+  double sink5 = 0.0;
+  // Row pointers of tile k (tiles run from the newest rows down; ABL 3: upwards).
+  auto tile_rows = [&](int i0, const double2* (&a)[T]) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       int i = i0 + 4 * t + li;
       if (i >= nrows) i = nrows - 1;  // clamped duplicate, discarded at the store
       if (i == j) i = j > 0 ? j - 1 : (nrows > 1 ? 1 : 0);  // row j is w itself: its coefficient comes from `self`
       a[t] = reinterpret_cast<const double2*>(V + (int64_t)i * ldv + base + m_lo + eoff);
-      acc[t] = 0.0;
     }
-    for (int s0 = 0; s0 < nsteps; s0 += U) {
-      double2 av[T][U];
+  };
+  auto load_batch = [&](const double2* const (&a)[T], int s0, double2 (&av)[T][U]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int t = 0; t < T; ++t) av[t][u] = (s0 + u < nsteps) ? ld_stream<1>(a[t] + 16 * (s0 + u)) : make_double2(0.0, 0.0);
+      for (int t = 0; t < T; ++t) av[t][u] = (s0 + u < nsteps) ? ld_stream<1>(a[t] + 16 * (s0 + u)) : make_double2(0.0, 0.0);
+  };
+  auto mma_batch = [&](int s0, const double2 (&av)[T][U], double (&acc)[T]) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double2 bv = ABL == 1 ? make_double2(1.0, 2.0) : ((s0 + u < nsteps) ? swl[16 * (s0 + u)] : make_double2(0.0, 0.0));
+    for (int u = 0; u < U; ++u) {
+      const double2 bv = ABL == 1 ? make_double2(1.0, 2.0) : ((s0 + u < nsteps) ? swl[16 * (s0 + u)] : make_double2(0.0, 0.0));
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          if (ABL == 2) {
-            acc[t] += av[t][u].x * bv.x + av[t][u].y * bv.y;
-          } else {
-            acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].x, bv.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].y, bv.y, acc[t], 0, 0, 0);
-          }
+      for (int t = 0; t < T; ++t) {
+        if (ABL == 2) {
+          acc[t] += av[t][u].x * bv.x + av[t][u].y * bv.y;
+        } else {
+          acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].x, bv.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].y, bv.y, acc[t], 0, 0, 0);
         }
       }
+    }
+  };
+  // The first batch of loads of the NEXT tile is issued before the current tile's results are reduced and stored: the
+  // end of a tile otherwise drains the wave's whole load queue (s_waitcnt 0 before the cross-lane adds), a bubble that
+  // cost 6 % of the pass (profiles/r01/ab_qtw_tile_epilogue.json).  ABL 6: the old, unpipelined order.
+  const int ntiles = i_top / (4 * T) + 1;
+  const double2* a[T];
+  double2 av0[T][U];
+  tile_rows(ABL == 3 ? 0 : i_top, a);
+  if (ABL != 6) load_batch(a, 0, av0);
+  for (int k = 0; k < ntiles; ++k) {
+    const int i0 = ABL == 3 ? k * 4 * T : i_top - k * 4 * T;
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0;
+    if (ABL == 6) load_batch(a, 0, av0);
+    mma_batch(0, av0, acc);
+    for (int s0 = U; s0 < nsteps; s0 += U) {
+      double2 av[T][U];
+      load_batch(a, s0, av);
+      mma_batch(s0, av, acc);
+    }
+    if (k + 1 < ntiles) {
+      tile_rows(ABL == 3 ? (k + 1) * 4 * T : i_top - (k + 1) * 4 * T, a);
+      if (ABL != 6) load_batch(a, 0, av0);
+    }
+    if (ABL == 5) {  // ABL 5: no per-tile epilogue (nothing reduced or stored)
+#pragma unroll
+      for (int t = 0; t < T; ++t) sink5 += acc[t];
+      continue;
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -314,10 +376,20 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
       v += __shfl_xor(v, 4, 64);         // add the four blocks (adjacent 64-byte chunks)
       v += __shfl_xor(v, 8, 64);
       const int row = i0 + 4 * t + lk;   // lane 16 i (+0) holds row i
-      if ((lane & 15) == 0 && row < nrows && row != j) part[(int64_t)row * P + pid] = v;
+      if (ABL == 7) {  // ABL 7: cross-lane adds but no partial stores
+        sink5 += v;
+        continue;
+      }
+      if ((lane & 15) == 0 && row < nrows) keep[row] = v;
     }
   }
-  if (lane == 0 && j < nrows) part[(int64_t)j * P + pid] = self;  // c_j = w.w from the LDS-resident values
+  if ((ABL == 5 || ABL == 7) && sink5 == 1.2345e300) part[0] = sink5;
+  if (lane == 0 && j < nrows) keep[j] = self;  // c_j = w.w from the LDS-resident values (row j itself is not streamed)
+  __syncthreads();  // the only barrier after staging: the four waves' runs are added (fixed order) and leave as one
+  const double* k0 = reinterpret_cast<const double*>(sw) + L;
+  double* mine = part + (int64_t)blockIdx.x * ldp;
+  for (int i = threadIdx.x; i < nrows; i += kTPB)
+    __builtin_nontemporal_store(((k0[i] + k0[ldp + i]) + k0[2 * ldp + i]) + k0[3 * ldp + i], mine + i);
 }
 
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
@@ -355,7 +427,7 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   p.family = (flags & LZ_FLAG_QTW_VALU) ? 0 : ((flags & LZ_FLAG_QTW_MFMA) ? 1 : 2);
   p.mfma = p.family != 0;
   p.variant = tune ? tune[1] : 0;
-  p.P = p.mfma ? p.G * (kTPB / 64) : p.G;
+  p.P = p.family == 1 ? p.G * (kTPB / 64) : p.G;  // 16x16x4 kernel: per-wave partials; the others: one run per block
   return p;
 }
 
@@ -366,17 +438,25 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
   const dim3 grid(plan.G), block(kTPB);
 #define LZ_QTW_ARGS V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, plan.P, part
   if (plan.family == 2) {
+    const int ldp = qtw_ldp(nrows);
+    const size_t lds4 = lds + (size_t)(kTPB / 64) * ldp * sizeof(double);  // slice of w + the four waves' coefficient runs
+    auto go = [&](auto kern) {
+      // more than 64 KiB of dynamic LDS (long slices with many hundred basis rows) has to be allowed per kernel
+      if (lds4 > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      hipLaunchKernelGGL(kern, grid, block, lds4, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, ldp, part);
+    };
     switch (plan.variant) {
-      case 10: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 11: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 2, 8>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 13: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      case 21: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no LDS read of w
-      case 22: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;  // VALU instead of MFMA
-      case 23: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;  // ascending rows
-      case 24: hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2, 4>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no staging of w
-      default:  // measured best (profiles/r01/ab_qtw_mfma4.json): 2 tiles of 4 rows x 4 steps = 8 loads in flight per lane
-        hipLaunchKernelGGL((k_qtw_mfma4<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS);
-        break;
+      case 10: go(k_qtw_mfma4<SCALE, 4, 4>); break;
+      case 11: go(k_qtw_mfma4<SCALE, 2, 8>); break;
+      case 13: go(k_qtw_mfma4<SCALE, 8, 2>); break;
+      case 21: go(k_qtw_mfma4<SCALE, 4, 2, 1>); break;  // no LDS read of w
+      case 22: go(k_qtw_mfma4<SCALE, 4, 2, 2>); break;  // VALU instead of MFMA
+      case 23: go(k_qtw_mfma4<SCALE, 4, 2, 3>); break;  // ascending rows
+      case 24: go(k_qtw_mfma4<SCALE, 4, 2, 4>); break;  // no staging of w
+      case 25: go(k_qtw_mfma4<SCALE, 4, 2, 5>); break;  // no per-tile epilogue
+      case 26: go(k_qtw_mfma4<SCALE, 4, 2, 6>); break;  // no cross-tile prefetch
+      case 27: go(k_qtw_mfma4<SCALE, 4, 2, 7>); break;  // coefficients not kept
+      default: go(k_qtw_mfma4<SCALE, 4, 2>); break;     // measured best: 2 tiles of 4 rows x 4 steps = 8 loads in flight per lane
     }
     return;
   }
