@@ -315,3 +315,20 @@ def test_breakdown_behaves_like_the_reference():
         s.execute_Lanczos(5)
     assert not np.isfinite(s.H_eff).all()
     assert np.array_equal(np.isfinite(np.diag(s.H_eff)), np.isfinite(a))
+
+
+def test_many_basis_rows_with_a_long_slice():
+    """n = 900 at M = 2.56e6: pass 1 then needs more than 64 KiB of dynamic LDS per block (40 KiB slice of w + four
+    coefficient runs of 912 doubles), which has to be allowed per kernel.  Size-independent checks only."""
+    A = synthetic.laplacian_2d_5pt(2000, 1280).to_scipy()
+    Lanczos.verbose = False
+    s = Lanczos(A)
+    s.execute_Lanczos(900)
+    h = s._handle
+    rows = [0, 1, 450, 700, 898, 899]
+    Vs = np.stack([h.basis_get_row(i) for i in rows])
+    assert np.abs(Vs @ Vs.T - np.eye(len(rows))).max() < 1e-12
+    al, be = np.diag(s.H_eff), np.diag(s.H_eff, 1)
+    j = 700
+    res = A @ Vs[3] - be[j - 1] * h.basis_get_row(j - 1) - al[j] * Vs[3] - be[j] * h.basis_get_row(j + 1)
+    assert np.abs(res).max() < 1e-14 and np.isfinite(s.H_eff).all()
