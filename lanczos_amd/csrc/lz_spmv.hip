@@ -271,6 +271,20 @@ __global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ 
       const double2* x2 = reinterpret_cast<const double2*>(x);
       const int64_t m2 = cols >> 1;
       int64_t p = lane;
+      for (; p + 448 < m2; p += 512) {  // eight 16-byte row loads in flight per lane
+        double2 u[8], xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = ld_stream<1>(a2 + p + 64 * q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xv[q] = x2[p + 64 * q];
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+          acc0 = fma(u[q].x, xv[q].x, acc0);
+          acc1 = fma(u[q].y, xv[q].y, acc1);
+          acc2 = fma(u[q + 1].x, xv[q + 1].x, acc2);
+          acc3 = fma(u[q + 1].y, xv[q + 1].y, acc3);
+        }
+      }
       for (; p + 64 < m2; p += 128) {
         const double2 u = ld_stream<1>(a2 + p), v = ld_stream<1>(a2 + p + 64);
         const double2 xu = x2[p], xv = x2[p + 64];
