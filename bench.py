@@ -117,16 +117,19 @@ def cpu_baseline(kind, dims, k, budget_s=40.0):
         times.append(time.perf_counter() - t0)
         j += 1
     t_iter = float(np.mean(times))
+    threads = 1
     try:
         from threadpoolctl import threadpool_info
 
         blas = ";".join(f"{i.get('internal_api')}:{i.get('num_threads')}" for i in threadpool_info())
+        threads = max([int(i.get("num_threads") or 1) for i in threadpool_info()] + [1])
     except Exception:
         blas = "unknown"
     out = {
         "value": (1.0 / t_iter) * (n_cpu / k),  # reference cost per iteration is proportional to n (independent of j)
         "unit": "iterations/s",
-        "cores": os.cpu_count(),
+        "cores": threads,  # threads the NumPy loop can actually use: the BLAS pool (np.dot / norm); everything else is one core
+        "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"{len(times)} iteration(s) of the faithful NumPy loop at M={M}, n={n_cpu} "
         f"({'full' if n_cpu == k else 'reduced to fit host RAM; value scaled by n/k'}); {t_iter:.2f} s/iteration; "
