@@ -48,7 +48,9 @@ enum lz_flags {
   LZ_FLAG_QTW_MFMA = 2,       /* A/B arm: the v_mfma_f64_16x16x4_f64 Q^T w kernel (default is the 4x4x4 MFMA kernel) */
   LZ_FLAG_QTW_VALU = 4,       /* A/B arm: the VALU + wave-shuffle Q^T w kernel                                       */
   LZ_FLAG_SPMV_SCALAR = 8,    /* force the plain one-thread-per-row CSR kernel            */
-  LZ_FLAG_FUSED_NORM = 16,    /* multi-rank only: fold ||r||^2 into the Q^T r all-reduce   */
+  LZ_FLAG_FUSED_NORM = 16,    /* ||r||^2 rides with the Q^T r sums: pass 1 dots the raw residual, the update kernel forms
+                                 beta, c_i = (V_i.r)/beta and V[j] = r/beta (one pass over V[j] and, at N > 1, one all-reduce
+                                 less).  The Python layers set it by default; 0 = scale first, then dot (reference order) */
   LZ_FLAG_SPMV_STREAM = 32,   /* force the generic CSR-stream kernel (no fixed-K fast path) */
   LZ_FLAG_OVERLAP_HALO = 128, /* multi-rank, contiguous (stencil) halos: update the faces of V[j] first, exchange them on a
                                  second stream while the interior is updated; the SpMV waits on an event (opt-in)    */
