@@ -176,6 +176,19 @@ int main() {
       char nm[64]; snprintf(nm, 64, "slices R8 U2, %d KB LDS reserved", kb);
       time([&] { hipLaunchKernelGGL((k_read_slices<8, 2>), dim3(G), dim3(256), (size_t)kb * 1024, 0, a, ld2, nrows, cnt2, out); }, 16.0 * ld2 * (nrows / 8 * 8), nm);
     }
+    // Infinity Cache (256 MB memory-side): the same S megabytes read again and again (20 back-to-back launches)
+    for (int mb : {16, 32, 64, 128, 192, 256, 384, 1024}) {
+      const size_t nn = (size_t)mb * (1 << 20) / 16;
+      for (int ntl = 0; ntl < 2; ++ntl) {
+        auto go = [&] { if (ntl) hipLaunchKernelGGL((k_read<8, true>), dim3(4096), dim3(256), 0, 0, a, nn, out); else hipLaunchKernelGGL((k_read<8, false>), dim3(4096), dim3(256), 0, 0, a, nn, out); };
+        go(); go(); hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int it = 0; it < 20; ++it) go();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("re-read %4d MB x20, %s loads: %7.1f GB/s\n", mb, ntl ? "nt" : "plain", 20.0 * nn * 16 / ms / 1e6);
+      }
+    }
     // Sustained rate: the headline solve streams for 0.5 s at a time and carries random mantissas, while the numbers
     // above are best-of-5 of ~1 ms launches over a constant byte pattern.  3 x 600 back-to-back launches per pattern.
     for (int pattern = 0; pattern < 2; ++pattern) {
