@@ -94,8 +94,10 @@ const char* lz_last_error(lz_handle h); /* h may be NULL: last error of lz_creat
 int lz_set_options(lz_handle h, int flags);
 /* Tuning knobs (index 0: Q^T w slice length per block, 1: Q^T w kernel variant, 2/4: CSR-stream rows /
  * entries per block, 3: SpMV timing-ablation arm, 5: fixed-K rows per block, 6: issue the collectives
- * even when world == 1, 7: profile only every value-th iteration of lz_run); they take effect at the next
- * lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order. */
+ * even when world == 1, 7: profile only every value-th iteration of lz_run, 8: update-kernel variant (1 cached loads,
+ * 2 one position per lane, 3/4/5 slice owner with 8/4/1 positions per lane), 11: two-sided links (2 = single launch),
+ * 12: 1 = no row-stride skew); they take effect at the next lz_set_csr / lz_basis_alloc / lz_run.  Variants 21-37 of
+ * knob 1 are timing-only ablation arms (wrong results).  Otherwise results never depend on them beyond summation order. */
 int lz_set_tuning(lz_handle h, int index, int value);
 int lz_device_synchronize(lz_handle h);
 int lz_device_name(lz_handle h, char* buf, size_t buflen);

@@ -671,7 +671,7 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
       }
     }
   }
-  if (variant == 0 && span <= 16384) {
+  if ((variant == 0 && span <= 16384) || variant == 5) {
     // a face of the slab (overlap mode) or a tiny vector: a handful of blocks walk all rows, which is a latency chain,
     // not a bandwidth problem - one position per lane (most blocks) and 32 rows in flight per lane
     if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
