@@ -1,4 +1,4 @@
-"""Timing + accuracy probe of the two-sided (bi-orthogonal) Lanczos path (GPU box only; the oracle is the checker)."""
+"""Timing probe of the two-sided (bi-orthogonal) Lanczos path (GPU box only; parity lives in tests/test_gpu_two_sided.py)."""
 import json
 import os
 import sys
@@ -8,18 +8,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lanczos_amd import IrrLanczos, _capi, synthetic  # noqa: E402
-from oracle import two_sided_ref as ts  # noqa: E402
 
 out = {}
 IrrLanczos.verbose = False
-# accuracy vs the oracle on a mid-size case
-A = synthetic.laplacian_2d_5pt(200, 150).to_scipy()
-s = IrrLanczos(A)
-s.execute_Lanczos(16, seed=3)
-a, b, g, Q = ts.execute_two_sided(A, 16, seed=3)
-sc = np.abs(a).max()
-out["accuracy_M3e4_n16"] = {"alpha": (np.abs(s._alpha - a) / sc).tolist(), "gamma": (np.abs(s._gamma - g) / sc).tolist()}
-
 for (nx, ny, n, arm) in [(1000, 1000, 50, 2), (1000, 1000, 50, 1), (4000, 2500, 24, 2), (4000, 2500, 24, 1), (300, 300, 60, 2), (300, 300, 60, 1), (512, 512, 60, 2), (512, 512, 60, 1)]:
     A = synthetic.laplacian_2d_5pt(nx, ny).to_scipy()
     s = IrrLanczos(A)
