@@ -407,7 +407,7 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in
   const bool overlap = in_run_loop && (h->flags & LZ_FLAG_OVERLAP_HALO) && h->xmode == 1 && h->all_contig && h->comm_kind == 1 &&
                        !h->peers.empty() && (h->world > 1 || h->tune[6]);
   // inside lz_run the default (slice-owner) update kernel turns the reduced sums into beta and the coefficients itself
-  const bool raw_c = fused && in_run_loop && !overlap && (h->tune[8] == 0 || h->tune[8] >= 3);
+  const bool raw_c = fused && in_run_loop && (h->tune[8] == 0 || h->tune[8] >= 3);
   if (fused && !raw_c) {
     Scope sc(h, LZ_K_FINAL, 0, 0);
     launch_fused_prepare(h->d_c, j, h->d_beta + beta_idx, h->stream);
@@ -424,14 +424,23 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in
   double* vj = h->d_V + (int64_t)j * h->ldv;
   {
     Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + 16.0 * M, 2.0 * nrows * M);
-    for (auto& rg : h->bnd_ranges)
+    // both faces leave in ONE launch of the small-range kernel (the face kernel is a latency chain over the rows)
+    const bool small = h->tune[8] == 0;
+    for (size_t q = 0; q < h->bnd_ranges.size(); q += 2) {
+      const auto& ra = h->bnd_ranges[q];
+      const bool pair = small && q + 1 < h->bnd_ranges.size() && ra.second - ra.first <= 16384 &&
+                        h->bnd_ranges[q + 1].second - h->bnd_ranges[q + 1].first <= 16384;
       launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream,
-                    rg.first, rg.second);
+                    ra.first, ra.second, raw_c ? 1 : 0, pair ? h->bnd_ranges[q + 1].first : 0, pair ? h->bnd_ranges[q + 1].second : 0);
+      if (!pair && q + 1 < h->bnd_ranges.size())
+        launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream,
+                      h->bnd_ranges[q + 1].first, h->bnd_ranges[q + 1].second, raw_c ? 1 : 0);
+    }
     LZ_TRY(check_launch(h, "update(boundary)"));
     LZ_HIP(h, hipEventRecord(h->e_bnd, h->stream));
     for (auto& rg : h->int_ranges)
       launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream,
-                    rg.first, rg.second);
+                    rg.first, rg.second, raw_c ? 1 : 0);
     LZ_TRY(check_launch(h, "update(interior)"));
   }
   LZ_HIP(h, hipStreamWaitEvent(h->cstream, h->e_bnd, 0));

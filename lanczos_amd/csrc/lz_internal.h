@@ -67,7 +67,8 @@ void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const dou
 // pass 2: V[j] = 2 V[j] - sum_{i<nrows} c[i] V[i] (sequential, unfused: bitwise NumPy order)
 // raw_c (fused mode only): c holds the reduced sums, beta = sqrt(c[j]) is formed and stored by the kernel itself
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
-                   double* beta, int variant, hipStream_t s, int64_t pos_lo = 0, int64_t pos_hi = -1, int raw_c = 0);
+                   double* beta, int variant, hipStream_t s, int64_t pos_lo = 0, int64_t pos_hi = -1, int raw_c = 0,
+                   int64_t pos_lo_b = 0, int64_t pos_hi_b = 0);  // second range: only with the small-range (face) kernel
 void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s);
 void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s);
 // r = (r - alpha v_j) - beta v_jm1 ; part[b] = partial ||r||^2 ; returns number of partials

@@ -560,8 +560,17 @@ __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t
 template <bool FUSED, int P, int RU>
 __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, int64_t ldv, int64_t p0, int64_t n2, int nrows,
                                                       int j, const double* __restrict__ c, const double* __restrict__ r,
-                                                      double* __restrict__ beta, int raw_c) {
-  const int64_t base = p0 + (int64_t)blockIdx.x * (kTPB * P) + threadIdx.x;
+                                                      double* __restrict__ beta, int raw_c, int nblk_a, int64_t p0b,
+                                                      int64_t n2b) {
+  // blocks [0, nblk_a) cover positions [p0, n2); any further blocks cover a second range [p0b, n2b) (the two faces of a
+  // slab in overlap mode leave in one launch)
+  int bx = blockIdx.x;
+  if (bx >= nblk_a) {
+    bx -= nblk_a;
+    p0 = p0b;
+    n2 = n2b;
+  }
+  const int64_t base = p0 + (int64_t)bx * (kTPB * P) + threadIdx.x;
   const int64_t ld2 = ldv >> 1;
   const double2* V2 = reinterpret_cast<const double2*>(V);
   int64_t pos[P];
@@ -627,13 +636,16 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
 
 template <bool FUSED, int P, int RU>
 static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, int nrows, int j, const double* c, const double* r,
-                                double* beta, int raw_c, hipStream_t s) {
+                                double* beta, int raw_c, hipStream_t s, int64_t p0b = 0, int64_t n2b = 0) {
   const int grid = (int)((n2 - p0 + kTPB * P - 1) / (kTPB * P));
-  hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r, beta, raw_c);
+  const int grid_b = n2b > p0b ? (int)((n2b - p0b + kTPB * P - 1) / (kTPB * P)) : 0;
+  hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid + grid_b), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r, beta, raw_c,
+                     grid, p0b, n2b);
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
-                   double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi, int raw_c) {
+                   double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi, int raw_c, int64_t pos_lo_b,
+                   int64_t pos_hi_b) {
   // double2 positions [pos_lo, pos_hi) of the row (default: the whole row)
   const int64_t n2 = pos_hi >= 0 ? pos_hi : (len >> 1);
   const int64_t p0 = pos_lo > 0 ? pos_lo : 0;
@@ -674,8 +686,8 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
   if ((variant == 0 && span <= 16384) || variant == 5) {
     // a face of the slab (overlap mode) or a tiny vector: a handful of blocks walk all rows, which is a latency chain,
     // not a bandwidth problem - one position per lane (most blocks) and 32 rows in flight per lane
-    if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
-    else launch_update_slice<false, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
+    if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, pos_lo_b, pos_hi_b);
+    else launch_update_slice<false, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, pos_lo_b, pos_hi_b);
   } else if (P == 8) {
     if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
     else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
