@@ -975,7 +975,7 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
     LZ_TRY(dev_alloc(h, h->d_nrm2, 2));
   }
   h->n = n;
-  h->qplan = plan_qtw(h->rows_pad, h->flags, h->tune);
+  h->qplan = plan_qtw(h->rows_pad, h->flags, h->tune, n);
   size_t need = (size_t)(n + 16) * (size_t)h->qplan.P;
   need = std::max<size_t>(need, 4096);
   need = std::max<size_t>(need, (size_t)(h->rows / 4 + 64));                     // dense gemv / scalar spmv partials

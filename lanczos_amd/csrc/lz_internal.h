@@ -59,7 +59,7 @@ struct QtwPlan {
   int family = 2;   // 2 = 4x4x4 MFMA (default), 1 = 16x16x4 MFMA, 0 = VALU
   int variant = 0;  // A/B knob (unroll / rows per tile)
 };
-QtwPlan plan_qtw(int64_t len, int flags, const int* tune);
+QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max);
 // pass 1 of the re-orthogonalisation (+ optional v_j = r / sqrt(nrm2)):
 //   part[i*G + b] = sum_{m in block b} V[i][m] * V[j][m],  i in [0, nrows)
 void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,

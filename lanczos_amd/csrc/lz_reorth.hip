@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
     __builtin_nontemporal_store(((k0[i] + k0[ldp + i]) + k0[2 * ldp + i]) + k0[3 * ldp + i], mine + i);
 }
 
-QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
+QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
   QtwPlan p;
   int64_t target = (tune && tune[0] > 0) ? tune[0] : 0;
   // Two effects set the slice length (profiles/r01/ab_qtw_slice_balance.json): (a) a CU streams at a fixed share of the
@@ -406,7 +406,12 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
     // the longest slice that still gives every CU about two blocks and an even share; else the best-balanced one
     double best = -1.0;
     bool found = false;
-    for (int64_t cand = kQtwMaxL; cand >= 1024 && !found; cand -= 512) {
+    // the default kernel also parks four coefficient runs of qtw_ldp(n) doubles in LDS: with thousands of basis rows the
+    // slice has to shrink to stay inside the 160 KiB of a CU (n = 4000 -> L <= 3072)
+    int64_t lmax = kQtwMaxL;
+    const int64_t room = (int64_t)155 * 1024 - (int64_t)(kTPB / 64) * qtw_ldp(nrows_max) * 8;
+    if (room / 8 < lmax) lmax = std::max<int64_t>(512, room / 8 / 512 * 512);
+    for (int64_t cand = lmax; cand >= 1024 && !found; cand -= 512) {
       const int64_t G = (len + cand - 1) / cand;
       if (G < 480) continue;
       const double g = (double)G / kNumCU, bal = g / std::ceil(g);
@@ -425,6 +430,8 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune) {
   // kernel family: 2 = 4x4x4 MFMA (default: matrix cores, line-coalesced loads), 1 = 16x16x4 MFMA (A/B arm),
   // 0 = VALU + shuffle reductions (LZ_FLAG_QTW_VALU)
   p.family = (flags & LZ_FLAG_QTW_VALU) ? 0 : ((flags & LZ_FLAG_QTW_MFMA) ? 1 : 2);
+  if (p.family == 2 && (int64_t)155 * 1024 - (int64_t)(kTPB / 64) * qtw_ldp(nrows_max) * 8 < L * 8)
+    p.family = 0;  // ~5000 basis rows and more: the coefficient runs no longer fit next to any slice - VALU kernel, partials in HBM
   p.mfma = p.family != 0;
   p.variant = tune ? tune[1] : 0;
   p.P = p.family == 1 ? p.G * (kTPB / 64) : p.G;  // 16x16x4 kernel: per-wave partials; the others: one run per block

@@ -332,3 +332,17 @@ def test_many_basis_rows_with_a_long_slice():
     j = 700
     res = A @ Vs[3] - be[j - 1] * h.basis_get_row(j - 1) - al[j] * Vs[3] - be[j] * h.basis_get_row(j + 1)
     assert np.abs(res).max() < 1e-14 and np.isfinite(s.H_eff).all()
+
+
+@pytest.mark.parametrize("dims,n", [((400, 300), 4200), ((300, 200), 5200)])
+def test_thousands_of_basis_rows(dims, n):
+    """The default pass-1 kernel parks four coefficient runs of n doubles in LDS: at n = 4200 the slice of w shrinks to
+    make room, at n = 5200 the plan falls back to the VALU kernel (partials in HBM)."""
+    A = synthetic.laplacian_2d_5pt(*dims).to_scipy()
+    Lanczos.verbose = False
+    s = Lanczos(A)
+    s.execute_Lanczos(n)
+    h = s._handle
+    rows = [0, 7, n // 2, n - 2, n - 1]
+    Vs = np.stack([h.basis_get_row(i) for i in rows])
+    assert np.abs(Vs @ Vs.T - np.eye(len(rows))).max() < 1e-12 and np.isfinite(s.H_eff).all()
