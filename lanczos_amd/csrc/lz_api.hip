@@ -212,13 +212,44 @@ int dev_alloc(lz_handle h, T*& p, size_t count) {
   return LZ_OK;
 }
 
+// ---- roctx ranges (opt-in: LZ_ROCTX=1) --------------------------------------
+// Host-side phase markers for `rocprofv3 --marker-trace`: one range per kernel class around its launches.  The marker
+// library is dlopen'ed on first use, like RCCL; nothing is linked and nothing happens without the environment variable.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  bool tried = false;
+};
+RoctxApi g_roctx;
+const char* const kClassNames[LZ_K_COUNT] = {"lz:spmv", "lz:qtw", "lz:update", "lz:three_term", "lz:final", "lz:comm", "lz:ritz"};
+bool roctx_on() {
+  if (!g_roctx.tried) {
+    g_roctx.tried = true;
+    const char* e = getenv("LZ_ROCTX");
+    if (e && e[0] == '1') {
+      void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+      if (lib) {
+        g_roctx.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        g_roctx.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+      }
+    }
+  }
+  return g_roctx.push && g_roctx.pop;
+}
+
 // ---- profiling events ---------------------------------------------------
 struct Scope {
   lz_handle h;
   int cls;
   hipEvent_t a = nullptr, b = nullptr;
   bool on;
+  bool marked = false;
   Scope(lz_handle h_, int cls_, double bytes, double flops) : h(h_), cls(cls_) {
+    if (roctx_on()) {
+      g_roctx.push(kClassNames[cls]);
+      marked = true;
+    }
     h->acc.bytes[cls] += bytes;
     h->acc.flops[cls] += flops;
     h->acc.launches[cls] += 1;
@@ -240,6 +271,7 @@ struct Scope {
     }
   }
   ~Scope() {
+    if (marked) g_roctx.pop();
     if (on) {
       hipEventRecord(b, h->stream);
       h->events.push_back({cls, a, b});
