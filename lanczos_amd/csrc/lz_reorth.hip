@@ -690,7 +690,7 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
       }
     }
   }
-  if (variant == 6 || (variant == 0 && P == 16)) {
+  if (variant == 6 || (variant == 0 && P == 16 && span > 16384)) {
     // 16 positions per lane, one row per trip (still 16 loads in flight): half as many, longer-lived blocks - fewer
     // residency rounds, so V[j] leaves in fewer, larger write bursts (1250 -> 1218 us at the headline)
     if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
