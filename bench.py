@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--no-partial", action="store_true", help="skip the extra (untimed-in-value) partial re-orthogonalisation measurement")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents (roofline fields become null)")
     ap.add_argument("--profile-stride", type=int, default=8, help="bracket only every n-th iteration with hipEvents (each event costs ~3 us)")
+    ap.add_argument("--prewarm-s", type=float, default=0.6, help="seconds of untimed short solves before the warm-up steps")
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed runtime pre-warm (used under rocprofv3 --pmc)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index (default: LOCAL_RANK); lets several ranks share one GPU with --backend host")
     ap.add_argument("--overlap", action="store_true", help="N > 1: exchange the halo on a second stream behind the interior re-orthogonalisation update (LZ_FLAG_OVERLAP_HALO)")
@@ -229,7 +230,7 @@ def main():
     while not args.no_prewarm:
         solver.execute_Lanczos(min(k, 12), v0_normalized_local=v0)
         # every rank must run the same number of solves (they contain collectives): agree on when to stop
-        if all(boot.allgather_obj(time.perf_counter() - t_pre >= 0.6)):
+        if all(boot.allgather_obj(time.perf_counter() - t_pre >= args.prewarm_s)):
             break
 
     for _ in range(args.warmup):
