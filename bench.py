@@ -140,6 +140,31 @@ def cpu_baseline(kind, dims, k, budget_s=40.0):
     return out
 
 
+def spawn_ranks(n):
+    """Launcher for `python bench.py --gpus N` without torch.distributed.run: N child processes (RANK / LOCAL_RANK /
+    WORLD_SIZE / LZ_RDZV_KEY exported), rank 0's stdout (the JSON line) relayed, exit status = the worst child's.
+    The parent never touches the GPU, and nothing that has is ever re-exec'ed."""
+    import subprocess
+    import uuid
+
+    key = uuid.uuid4().hex[:16]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LZ_RDZV_KEY=key,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit status): {bad}", file=sys.stderr)
+        return max(abs(c) for _, c in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,27 +189,30 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "halo", "allgather"])
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: this process becomes the launcher.  It has made no HIP call (and makes
+        # none): N fresh children, one rank per GPU, rendezvous over the torch-free socket bootstrap.
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
 
-    # Load the HIP library BEFORE torch so the system ROCm runtime it was built against is the one in the process.
+    if world > 1 and args.bootstrap == "torch":
+        # torch brings its own ROCm runtime (torch/lib): it must be in the process BEFORE liblanczos_hip.so, which then
+        # binds to that one runtime and takes RCCL from the same tree.  The opposite order maps two HIP runtimes into
+        # the process (round 1: abort in free() at exit); TorchBootstrap refuses it.
+        import torch  # noqa: F401
     import lanczos_amd
     from lanczos_amd import _capi, distributed, partition
 
-    lanczos_amd.load_library()
     if world > 1:
-        # Rendezvous, barriers and the max-over-ranks go over a pure-Python Unix-socket bootstrap keyed by the
-        # launcher's MASTER_PORT: importing torch here would map its bundled ROCm 7.0 runtime + RCCL next to the
-        # system ROCm 7.2 libraries the HIP library uses (observed: double free at exit).  --bootstrap torch
-        # uses torch.distributed/gloo instead.
+        # Default: rendezvous, barriers and the max-over-ranks go over a pure-Python Unix-socket bootstrap keyed by
+        # LZ_RDZV_KEY / the launcher's MASTER_PORT; no torch in the process at all.
         boot = distributed.TorchBootstrap() if args.bootstrap == "torch" else distributed.SocketBootstrap()
     else:
         boot = distributed.Bootstrap()
+    lanczos_amd.load_library()
 
     if args.device >= 0:
         local_rank = args.device
@@ -328,11 +356,17 @@ def main():
     # main line and ends every rank if an arm stalls, so the headline result cannot be lost to an experiment.
     import threading
 
+    arm_state = {"arm": "none"}
+
     def bail():  # pragma: no cover
+        # An arm (they contain collectives) made no progress for --arm-timeout seconds: that is a hang to be
+        # root-caused, not a success.  Rank 0 still delivers the already-measured main line, marked; every rank says
+        # on stderr which arm it was in, and the process ends with a non-zero status (never restarted, never re-exec'ed).
+        print(f"bench.py: rank {rank} stalled in extra arm '{arm_state['arm']}' for {args.arm_timeout:.0f} s", file=sys.stderr, flush=True)
         if rank == 0:
-            line["arms"] = "timed out; main result unaffected"
+            line["stalled"] = {"arm": arm_state["arm"], "timeout_s": args.arm_timeout, "note": "main result measured before the stall"}
             print(json.dumps(line), flush=True)
-        os._exit(0)
+        os._exit(3)
 
     watchdog = threading.Timer(args.arm_timeout, bail)
     watchdog.daemon = True
@@ -343,6 +377,7 @@ def main():
     # reference's full sweep at every step.
     partial = None
     if not args.no_partial:
+        arm_state["arm"] = "partial_reorth"
         theta_full = np.linalg.eigvalsh(solver.H_eff)
         solver.h.set_options(solver.options | _capi.FLAG_REORTH_PARTIAL)
         solver.execute_Lanczos(k, v0_normalized_local=v0)
@@ -376,6 +411,7 @@ def main():
     # this arm is that measurement.
     overlap_arm = None
     if world > 1 and not args.no_overlap_arm and not args.overlap and solver.plan.mode == "halo" and comm_used == "rccl":
+        arm_state["arm"] = "halo_overlap"
         solver.h.set_options(solver.options | _capi.FLAG_OVERLAP_HALO)
         solver.execute_Lanczos(k, v0_normalized_local=v0)
         boot.barrier()
@@ -391,6 +427,7 @@ def main():
                        "max_abs_coeff_diff_vs_default": float(max(np.abs(a_o - alpha_main).max(), np.abs(b_o - beta_main).max()))}
         solver.h.set_options(solver.options)
     watchdog.cancel()
+    arm_state["arm"] = "none"
 
     if rank == 0:
         line["partial_reorth"] = partial

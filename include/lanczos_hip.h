@@ -33,6 +33,9 @@ typedef struct lz_context* lz_handle;
 
 enum lz_status {
   LZ_OK = 0,
+  LZ_WARN_BREAKDOWN = 1, /* lz_run finished, but a residual norm beta underflowed to zero / a coefficient is not finite:
+                            the Krylov space is exhausted.  The reference divides blindly (Lanczos.py:113) and returns the
+                            same inf/NaN coefficients; they are delivered unchanged, this status is the only difference. */
   LZ_ERR_ARG = -1,       /* bad argument / shape */
   LZ_ERR_HIP = -2,       /* HIP runtime error */
   LZ_ERR_COMM = -3,      /* RCCL / host-collective error */
@@ -93,12 +96,18 @@ int lz_destroy(lz_handle h);
 const char* lz_last_error(lz_handle h); /* h may be NULL: last error of lz_create */
 int lz_set_options(lz_handle h, int flags);
 /* Tuning knobs (index 0: Q^T w slice length per block, 1: Q^T w kernel variant, 2/4: CSR-stream rows /
- * entries per block, 3: SpMV timing-ablation arm, 5: fixed-K rows per block, 6: issue the collectives
- * even when world == 1, 7: profile only every value-th iteration of lz_run, 8: update-kernel variant (1 cached loads,
- * 2 one position per lane, 3/4/5 slice owner with 8/4/1 positions per lane), 11: two-sided links (2 = single launch),
- * 12: 1 = no row-stride skew); they take effect at the next lz_set_csr / lz_basis_alloc / lz_run.  Variants 21-37 of
- * knob 1 are timing-only ablation arms (wrong results).  Otherwise results never depend on them beyond summation order. */
+ * entries per block, 5: fixed-K rows per block, 6: issue the collectives even when world == 1, 7: profile only every
+ * value-th iteration of lz_run, 8: update-kernel variant (1 cached loads, 2 one position per lane, 3/4/5 slice owner with
+ * 8/4/1 positions per lane), 11: two-sided links (2 = single launch), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
+ * fresh basis allocation before the required parts are cleared (test knob), 14: irregular SpMV plan (0 auto, 1 never
+ * the column-blocked two-phase kernels, 2 always), 15: small-problem engine (0 auto, 1 off, 2 force)); they take effect
+ * at the next lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order.  The
+ * timing-only ablation arms (knob 1 values >= 20, knob 3) exist only in the kernel-bench build (make KBENCH=1,
+ * liblanczos_kbench.so, tools/kbench.py); this library returns LZ_ERR_ARG for them. */
 int lz_set_tuning(lz_handle h, int index, int value);
+/* "hip=<path of the libamdhip64 this library is bound to>;rccl=<path of the librccl it dlopened, or empty>".
+ * RCCL is always taken from the directory of that HIP runtime (LZ_RCCL_PATH overrides): see DESIGN.md section 5. */
+int lz_runtime_info(char* buf, size_t buflen);
 int lz_device_synchronize(lz_handle h);
 int lz_device_name(lz_handle h, char* buf, size_t buflen);
 /* vectors are padded to 256-byte multiples on the device; in halo mode the ghost

@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblanczos_hip.so")
 
 LZ_OK = 0
-STATUS_NAMES = {0: "LZ_OK", -1: "LZ_ERR_ARG", -2: "LZ_ERR_HIP", -3: "LZ_ERR_COMM", -4: "LZ_ERR_STATE", -5: "LZ_ERR_NOMEM", -6: "LZ_ERR_NODEVICE"}
+LZ_WARN_BREAKDOWN = 1
+STATUS_NAMES = {0: "LZ_OK", 1: "LZ_WARN_BREAKDOWN", -1: "LZ_ERR_ARG", -2: "LZ_ERR_HIP", -3: "LZ_ERR_COMM", -4: "LZ_ERR_STATE", -5: "LZ_ERR_NOMEM", -6: "LZ_ERR_NODEVICE"}
 
 FLAG_PROFILE = 1
 FLAG_QTW_MFMA = 2
@@ -63,6 +64,7 @@ SIGNATURES = {
     "lz_last_error": (C.c_char_p, [_P]),
     "lz_set_options": (C.c_int, [_P, C.c_int]),
     "lz_set_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
+    "lz_runtime_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "lz_device_synchronize": (C.c_int, [_P]),
     "lz_device_name": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "lz_padded_rows": (C.c_int64, [C.c_int64]),
@@ -111,6 +113,35 @@ class LanczosHipError(RuntimeError):
 
 
 _lib = None
+_live_handles = None  # weakref.WeakSet of open Handle objects, closed by an atexit hook (see Handle)
+
+
+def mapped_runtimes():
+    """{"amdhip64": [paths], "hsa-runtime64": [...], "rccl": [...]} of the ROCm runtime copies mapped into THIS process
+    (from /proc/self/maps).  More than one libamdhip64 means two HIP runtimes share the process - what happens when
+    PyTorch (which bundles its own ROCm libraries under torch/lib, found through unversioned NEEDED names that never
+    match the system sonames) is imported AFTER this library was loaded; DESIGN.md section 5 has the round-1 abort it caused."""
+    import re
+
+    found = {"amdhip64": set(), "hsa-runtime64": set(), "rccl": set()}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                m = re.search(r"(/\S*lib(amdhip64|hsa-runtime64|rccl)\.so\S*)", line)
+                if m:
+                    found[m.group(2)].add(m.group(1))
+    except OSError:
+        pass
+    return {k: sorted(v) for k, v in found.items()}
+
+
+def check_single_runtime():
+    """Raise if two HIP runtimes are mapped (see ``mapped_runtimes``)."""
+    hip = mapped_runtimes()["amdhip64"]
+    if len(hip) > 1:
+        raise LanczosHipError(-4, "two HIP runtimes are mapped into this process (" + ", ".join(hip) + "): torch must be imported BEFORE "
+                              "lanczos_amd.load_library() so that liblanczos_hip.so binds to the runtime torch brings, "
+                              "or keep torch out of the process (SocketBootstrap needs none)")
 
 
 def load_library(path=None):
@@ -126,7 +157,9 @@ def load_library(path=None):
     if not os.path.isfile(p):
         raise LanczosHipError(-6, f"HIP extension not built: {p} is missing (run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C lanczos_amd/csrc`)")
     try:
-        lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+        # default (RTLD_LOCAL) scope: nothing in this library is meant to interpose on, or be interposed by, another
+        # ROCm copy in the process
+        lib = C.CDLL(p)
     except OSError as e:  # missing libamdhip64 etc.
         raise LanczosHipError(-6, f"cannot load {p}: {e}") from e
     for name, (res, args) in SIGNATURES.items():
@@ -136,6 +169,25 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def runtime_info():
+    """{"hip": path of the libamdhip64 the library is bound to, "rccl": path of the librccl it opened ('' if none yet)}."""
+    buf = C.create_string_buffer(1024)
+    load_library().lz_runtime_info(buf, 1024)
+    return dict(kv.split("=", 1) for kv in buf.value.decode().split(";"))
+
+
+def _close_live_handles():
+    # Runs from atexit, i.e. BEFORE the interpreter tears modules down and long before the HIP runtime's own exit
+    # handlers / static destructors: device memory, streams and the RCCL communicator are released while the runtime
+    # that owns them is still alive (Handle.__del__ at interpreter shutdown may run after it is gone).
+    if _live_handles is not None:
+        for h in list(_live_handles):
+            try:
+                h.close()
+            except Exception:
+                pass
 
 
 def preload_rccl():
@@ -174,6 +226,15 @@ class Handle:
             self._h = None
             raise LanczosHipError(st, msg)
         self._keep = []  # keeps ctypes callbacks alive
+        self.breakdown = False
+        global _live_handles
+        if _live_handles is None:
+            import atexit
+            import weakref
+
+            _live_handles = weakref.WeakSet()
+            atexit.register(_close_live_handles)
+        _live_handles.add(self)
 
     def check(self, st):
         if st != LZ_OK:
@@ -331,7 +392,10 @@ class Handle:
             raise ValueError("v0 has the wrong length")
         alpha = np.zeros(n)
         beta = np.zeros(max(n - 1, 1))
-        self.check(self.lib.lz_run(self._h, int(n), dptr(v0), dptr(alpha), dptr(beta)))
+        st = self.lib.lz_run(self._h, int(n), dptr(v0), dptr(alpha), dptr(beta))
+        self.breakdown = st == LZ_WARN_BREAKDOWN  # positive status: the run completed, coefficients as the reference's (inf/NaN)
+        if not self.breakdown:
+            self.check(st)
         self.n = n
         return alpha, beta[: n - 1]
 

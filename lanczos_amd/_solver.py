@@ -163,7 +163,7 @@ class LanczosBase:
         else:
             h.set_dense(packed[1])
         alpha, beta = h.run(n, v0)
-        if not (np.isfinite(alpha).all() and np.isfinite(beta).all()):
+        if h.breakdown:  # lz_run returned LZ_WARN_BREAKDOWN
             # The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov space gives inf/NaN there too.
             import warnings
 

@@ -39,12 +39,39 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+// RCCL must pair with the HIP runtime THIS library is bound to: its streams and device pointers are handed to
+// ncclAllReduce & co.  A process can hold two ROCm trees (PyTorch bundles its own libamdhip64 / libhsa-runtime64 /
+// librccl under torch/lib, and its NEEDED names carry no version, so they never match the system libraries' sonames):
+// `dlopen("librccl.so.1")` by bare soname then returns whichever copy happens to be mapped already - in round 1 that
+// was torch's RCCL (bound to torch's HIP runtime) driven with streams of the system runtime, and the process aborted in
+// free() at teardown.  So: take librccl from the directory of the libamdhip64 that resolves OUR
+// hipMalloc; LZ_RCCL_PATH overrides; the system path is the last resort.  RTLD_LOCAL: symbols are only reached through
+// dlsym on this handle, nothing is interposed.
+std::string g_rccl_path;
 const char* load_rccl() {
   if (g_rccl.lib) return nullptr;
-  void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) return "cannot dlopen librccl.so.1";
+  void* lib = nullptr;
+  std::vector<std::string> cand;
+  if (const char* e = getenv("LZ_RCCL_PATH")) cand.push_back(e);
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void*>(static_cast<hipError_t (*)(void**, size_t)>(&hipMalloc)), &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash);
+      cand.push_back(dir + "/librccl.so.1");
+      cand.push_back(dir + "/librccl.so");
+    }
+  }
+  cand.push_back("/opt/rocm/lib/librccl.so.1");
+  for (const auto& c : cand) {
+    lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (lib) {
+      g_rccl_path = c;
+      break;
+    }
+  }
+  if (!lib) return "cannot dlopen librccl next to the HIP runtime in use (set LZ_RCCL_PATH)";
 #define LZ_SYM(field, name)                                          \
   g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name)); \
   if (!g_rccl.field) return "missing RCCL symbol " name;
@@ -426,8 +453,8 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in
   h->qplan.variant = h->tune[1];  // A/B knob may change between launches on one handle (same allocation for every arm)
   {
     Scope sc(h, LZ_K_QTW, 8.0 * (nrows - 1) * M + (scale && !fused ? 16.0 : 8.0) * M, 2.0 * nrows * M);
-    launch_qtw(h->d_V, h->ldv, h->rows_pad, nrows, j, scale ? h->d_r : nullptr, h->d_nrm2, h->d_beta + beta_idx, h->qplan,
-               h->d_part, fused ? 2 : (scale ? 1 : 0), h->stream);
+    LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, nrows, j, scale ? h->d_r : nullptr, h->d_nrm2, h->d_beta + beta_idx, h->qplan,
+                         h->d_part, fused ? 2 : (scale ? 1 : 0), h->stream));
     LZ_TRY(check_launch(h, "qtw"));
   }
   {
@@ -713,8 +740,25 @@ int lz_set_options(lz_handle h, int flags) {
 }
 
 int lz_set_tuning(lz_handle h, int index, int value) {
-  if (!h || index < 0 || index >= 16) return LZ_ERR_ARG;
+  if (!h) return LZ_ERR_ARG;
+  if (index < 0 || index >= 16) return fail(h, LZ_ERR_ARG, "lz_set_tuning: knob index out of range");
+#ifndef LZ_KBENCH
+  // Timing-only ablation arms (they compute wrong results on purpose) exist only in the kernel-bench build
+  // (`make KBENCH=1` -> liblanczos_kbench.so, loaded by tools/kbench.py); the product library refuses them.
+  if ((index == 1 && value >= 20) || (index == 3 && value != 0))
+    return fail(h, LZ_ERR_ARG, "lz_set_tuning: ablation arms are not part of the product library (build with KBENCH=1)");
+#endif
+  if (value < 0) return fail(h, LZ_ERR_ARG, "lz_set_tuning: negative value");
   h->tune[index] = value;
+  return LZ_OK;
+}
+
+int lz_runtime_info(char* buf, size_t buflen) {
+  if (!buf || buflen == 0) return LZ_ERR_ARG;
+  Dl_info info;
+  const char* hip = "";
+  if (dladdr(reinterpret_cast<const void*>(static_cast<hipError_t (*)(void**, size_t)>(&hipMalloc)), &info) && info.dli_fname) hip = info.dli_fname;
+  snprintf(buf, buflen, "hip=%s;rccl=%s", hip, g_rccl_path.c_str());
   return LZ_OK;
 }
 
@@ -997,7 +1041,8 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
   LZ_HIP(h, hipSetDevice(h->dev));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
   const size_t vsz = (size_t)n * (size_t)h->ldv;
-  if (!h->d_V || h->n != n) {
+  const bool fresh = !h->d_V || h->n != n;
+  if (fresh) {
     LZ_TRY(dev_alloc(h, h->d_V, vsz));
     if (getenv("LZ_DEBUG_PTR")) fprintf(stderr, "[lz] basis %p (%zu bytes, ld %lld)\n", (void*)h->d_V, vsz * sizeof(double), (long long)h->ldv);
     LZ_TRY(dev_alloc(h, h->d_r, (size_t)h->ldv));
@@ -1005,6 +1050,15 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
     LZ_TRY(dev_alloc(h, h->d_beta, (size_t)n + 1));
     LZ_TRY(dev_alloc(h, h->d_c, (size_t)n + 1));
     LZ_TRY(dev_alloc(h, h->d_nrm2, 2));
+  }
+  if (fresh) {
+    // Columns [rows_pad, ldv) of a basis row (ghost tail in halo mode, the chunk padding in all-gather mode, the stride
+    // skew) are read by the SpMV as part of the extended vector but written by no kernel: they must not hold whatever
+    // the recycled allocation held (0 * NaN = NaN in the dense GEMV over zero-padded columns).  Cleared once per allocation.
+    if (h->tune[13] == 1) LZ_HIP(h, hipMemsetAsync(h->d_V, 0xFF, vsz * sizeof(double), h->stream));  // test knob: NaN-poison
+    if (h->ldv > h->rows_pad)
+      LZ_HIP(h, hipMemset2DAsync(h->d_V + h->rows_pad, (size_t)h->ldv * sizeof(double), 0, (size_t)(h->ldv - h->rows_pad) * sizeof(double),
+                                 (size_t)n, h->stream));
   }
   h->n = n;
   h->qplan = plan_qtw(h->rows_pad, h->flags, h->tune, n);
@@ -1232,6 +1286,20 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
     h->acc.total_ms += ms;
     h->run_timed = false;
+  }
+  // Breakdown report.  The reference divides by beta blindly (Lanczos.py:113) and carries inf/NaN
+  // forward; the coefficients are returned exactly like that, and the status says so.  beta[n-2] is also where step
+  // j = 0 parks its norm before step n-1 overwrites it, so every entry of beta_out has been a divisor.
+  for (int j = 0; j < n; ++j) {
+    const bool bad_a = !std::isfinite(alpha_out[j]);
+    const bool bad_b = j < n - 1 && !(std::isfinite(beta_out[j]) && beta_out[j] >= 2.2250738585072014e-308);
+    if (bad_a || bad_b) {
+      char msg[160];
+      snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - %s[%d] is %s (invariant subspace reached; later coefficients are not finite)",
+               bad_b ? "beta" : "alpha", j, bad_b && beta_out[j] == 0.0 ? "zero" : "not a normal number");
+      h->err = msg;
+      return LZ_WARN_BREAKDOWN;
+    }
   }
   return LZ_OK;
 }

@@ -62,8 +62,9 @@ struct QtwPlan {
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max);
 // pass 1 of the re-orthogonalisation (+ optional v_j = r / sqrt(nrm2)):
 //   part[i*G + b] = sum_{m in block b} V[i][m] * V[j][m],  i in [0, nrows)
-void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s);
+// returns the error of the per-kernel LDS-limit raise (hipFuncSetAttribute), if that was needed and failed
+hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
+                      double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s);
 // pass 2: V[j] = 2 V[j] - sum_{i<nrows} c[i] V[i] (sequential, unfused: bitwise NumPy order)
 // raw_c (fused mode only): c holds the reduced sums, beta = sqrt(c[j]) is formed and stored by the kernel itself
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,

@@ -439,7 +439,7 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
 }
 
 template <int SCALE>
-static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
+static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
                          double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s) {
   const size_t lds = (size_t)plan.L * sizeof(double);
   const dim3 grid(plan.G), block(kTPB);
@@ -447,15 +447,19 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
   if (plan.family == 2) {
     const int ldp = qtw_ldp(nrows);
     const size_t lds4 = lds + (size_t)(kTPB / 64) * ldp * sizeof(double);  // slice of w + the four waves' coefficient runs
+    hipError_t err = hipSuccess;
     auto go = [&](auto kern) {
       // more than 64 KiB of dynamic LDS (long slices with many hundred basis rows) has to be allowed per kernel
-      if (lds4 > 65536) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-      hipLaunchKernelGGL(kern, grid, block, lds4, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, ldp, part);
+      if (lds4 > 65536)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+      if (err == hipSuccess)
+        hipLaunchKernelGGL(kern, grid, block, lds4, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, ldp, part);
     };
     switch (plan.variant) {
       case 10: go(k_qtw_mfma4<SCALE, 4, 4>); break;
       case 11: go(k_qtw_mfma4<SCALE, 2, 8>); break;
       case 13: go(k_qtw_mfma4<SCALE, 8, 2>); break;
+#ifdef LZ_KBENCH  // timing-only ablation arms (wrong results on purpose): kernel-bench build only
       case 21: go(k_qtw_mfma4<SCALE, 4, 2, 1>); break;  // no LDS read of w
       case 22: go(k_qtw_mfma4<SCALE, 4, 2, 2>); break;  // VALU instead of MFMA
       case 23: go(k_qtw_mfma4<SCALE, 4, 2, 3>); break;  // ascending rows
@@ -463,9 +467,10 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
       case 25: go(k_qtw_mfma4<SCALE, 4, 2, 5>); break;  // no per-tile epilogue
       case 26: go(k_qtw_mfma4<SCALE, 4, 2, 6>); break;  // no cross-tile prefetch
       case 27: go(k_qtw_mfma4<SCALE, 4, 2, 7>); break;  // coefficients not kept
+#endif
       default: go(k_qtw_mfma4<SCALE, 4, 2>); break;     // measured best: 2 tiles of 4 rows x 4 steps = 8 loads in flight per lane
     }
-    return;
+    return err;
   }
   if constexpr (SCALE != 2) {
     if (plan.family == 1) {
@@ -475,17 +480,19 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
         case 4: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
         default: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
       }
-      return;
+      return hipSuccess;
     }
   }
   switch (plan.variant) {
     case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
     case 7: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 0>), grid, block, lds, s, LZ_QTW_ARGS); break;  // plain (cached) loads
+#ifdef LZ_KBENCH
     case 31: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no reductions/stores
     case 32: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;  // ascending
     case 33: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;  // both
     case 35: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 5>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no reductions, no LDS
     case 37: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 7>), grid, block, lds, s, LZ_QTW_ARGS); break;  // all three
+#endif
     default:  // measured best on MI355X (profiles/r01): 8 rows x 2 positions = 16 loads in flight per lane
       if (nrows > 4)
         hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS);
@@ -494,16 +501,14 @@ static void launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, 
       break;
   }
 #undef LZ_QTW_ARGS
+  return hipSuccess;
 }
 
-void launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s) {
-  if (mode == 2)
-    launch_qtw_t<2>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
-  else if (mode == 1)
-    launch_qtw_t<1>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
-  else
-    launch_qtw_t<0>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
+hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
+                      double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s) {
+  if (mode == 2) return launch_qtw_t<2>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
+  if (mode == 1) return launch_qtw_t<1>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
+  return launch_qtw_t<0>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
 }
 
 // ------------------------------------------------------------------ re-orthogonalisation pass 2

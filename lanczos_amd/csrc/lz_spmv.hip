@@ -220,12 +220,13 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
     hipLaunchKernelGGL(k_spmv_scalar, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, x, x_own, y, A.rows, part);
     return grid;
   }
-  if (!A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) {
+  if (!A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) {  // A.ablation is always 0 in the product build
     if (A.fixed_k == 5) return launch_spmv_fixed<5>(A, x, y, x_own, part, A.fixed_rb, s);
     if (A.fixed_k == 7) return launch_spmv_fixed<7>(A, x, y, x_own, part, A.fixed_rb, s);
   }
   const int grid = A.n_rowblk;
   const size_t lds = (size_t)(A.blk_nnz_cap + 2) * sizeof(double);
+#ifdef LZ_KBENCH  // timing-only ablation arms (wrong results on purpose): kernel-bench build only
 #define LZ_ABL(n)                                                                                                   \
   case n:                                                                                                          \
     hipLaunchKernelGGL((k_spmv_stream<5, n>), dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, \
@@ -238,6 +239,7 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
     }
   }
 #undef LZ_ABL
+#endif
   if (A.fixed_k == 5)
     hipLaunchKernelGGL(k_spmv_stream<5>, dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, 5,
                        A.blk_nnz_cap, part);

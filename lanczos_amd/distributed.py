@@ -47,15 +47,62 @@ class Bootstrap:
         return a
 
 
+def _enc(o):
+    """JSON-able form of the control-plane messages (None, bool, int, float, str, bytes, tuples, lists, dicts with any
+    such keys, NumPy scalars and arrays).  No pickle: a message can never execute code on the receiving rank."""
+    import base64
+
+    if isinstance(o, np.ndarray):
+        return {"__nd__": [o.dtype.str, list(o.shape)], "d": base64.b64encode(np.ascontiguousarray(o).tobytes()).decode("ascii")}
+    if isinstance(o, (bytes, bytearray)):
+        return {"__b__": base64.b64encode(bytes(o)).decode("ascii")}
+    if isinstance(o, tuple):
+        return {"__t__": [_enc(x) for x in o]}
+    if isinstance(o, list):
+        return [_enc(x) for x in o]
+    if isinstance(o, dict):
+        return {"__d__": [[_enc(k), _enc(v)] for k, v in o.items()]}
+    if isinstance(o, np.bool_):
+        return bool(o)
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, np.floating):
+        return float(o)
+    if o is None or isinstance(o, (bool, int, float, str)):
+        return o
+    raise TypeError(f"SocketBootstrap cannot send a {type(o).__name__}")
+
+
+def _dec(o):
+    import base64
+
+    if isinstance(o, list):
+        return [_dec(x) for x in o]
+    if isinstance(o, dict):
+        if "__nd__" in o:
+            dt, shape = o["__nd__"]
+            return np.frombuffer(base64.b64decode(o["d"]), dtype=np.dtype(dt)).reshape(shape).copy()
+        if "__b__" in o:
+            return base64.b64decode(o["__b__"])
+        if "__t__" in o:
+            return tuple(_dec(x) for x in o["__t__"])
+        if "__d__" in o:
+            return {_dec(k): _dec(v) for k, v in o["__d__"]}
+        raise ValueError("malformed rendezvous message")
+    return o
+
+
 class SocketBootstrap(Bootstrap):
     """Pure-Python single-node rendezvous over a Unix-domain socket (star topology, rank 0 is the hub).
 
     Needs only RANK / WORLD_SIZE (as exported by ``torch.distributed.run`` or any other launcher) and a
-    key shared by the ranks of one launch - by default ``MASTER_PORT`` plus the launcher's pid - so no
+    key shared by the ranks of one launch - ``LZ_RDZV_KEY``, else ``MASTER_PORT`` plus the launcher's pid - so no
     TCP port is taken and no PyTorch (with its bundled copies of the ROCm runtime and RCCL) is mapped
-    into the process next to the system ROCm libraries liblanczos_hip.so is built against.
-    Control plane only: unique-id broadcast, plan checks, barriers, the max-over-ranks of timings
+    into the process.  Control plane only: unique-id broadcast, plan checks, barriers, the max-over-ranks of timings
     (and, for ``backend="host"``, the host-staged test collectives).
+
+    The socket lives in a directory only this user can enter (``LZ_RDZV_DIR`` or ``/tmp/lz_rdzv_<uid>``, mode 0700,
+    ownership verified), both ends check the peer's uid with SO_PEERCRED, and messages are JSON (``_enc``), never pickle.
     """
 
     def __init__(self, rank=None, world=None, key=None, timeout=600.0):
@@ -67,7 +114,7 @@ class SocketBootstrap(Bootstrap):
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         if key is None:
             key = os.environ.get("LZ_RDZV_KEY") or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-        self.path = os.path.join(os.environ.get("LZ_RDZV_DIR", "/tmp"), f"lz_rdzv_{key}.sock")
+        self.path = os.path.join(self._private_dir(), f"{key}.sock")
         self._conns = {}
         self._sock = None
         if self.world == 1:
@@ -85,6 +132,7 @@ class SocketBootstrap(Bootstrap):
             self._srv = srv
             while len(self._conns) < self.world - 1:
                 c, _ = srv.accept()
+                self._check_peer(c)
                 c.settimeout(timeout)
                 r = self._recv(c)
                 self._conns[int(r)] = c
@@ -100,9 +148,32 @@ class SocketBootstrap(Bootstrap):
                     if time.time() > deadline:
                         raise TimeoutError(f"rank {self.rank}: no rendezvous socket at {self.path}")
                     time.sleep(0.05)
+            self._check_peer(s)
             s.settimeout(timeout)
             self._sock = s
             self._send(s, self.rank)
+
+    @staticmethod
+    def _private_dir():
+        import stat
+
+        d = os.environ.get("LZ_RDZV_DIR") or os.path.join("/tmp", f"lz_rdzv_{os.getuid()}")
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.lstat(d)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError(f"rendezvous directory {d} must be a directory owned by uid {os.getuid()} with mode 0700")
+        return d
+
+    @staticmethod
+    def _check_peer(sock):
+        import socket
+        import struct
+
+        cred = sock.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i"))
+        _pid, uid, _gid = struct.unpack("3i", cred)
+        if uid != os.getuid():
+            sock.close()
+            raise PermissionError(f"rendezvous peer runs as uid {uid}, expected {os.getuid()}")
 
     def _cleanup(self):
         try:
@@ -112,15 +183,15 @@ class SocketBootstrap(Bootstrap):
 
     @staticmethod
     def _send(sock, obj):
-        import pickle
+        import json
         import struct
 
-        data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+        data = json.dumps(_enc(obj)).encode("utf-8")
         sock.sendall(struct.pack("<Q", len(data)) + data)
 
     @staticmethod
     def _recv(sock):
-        import pickle
+        import json
         import struct
 
         def read(n):
@@ -133,7 +204,7 @@ class SocketBootstrap(Bootstrap):
             return bytes(buf)
 
         (n,) = struct.unpack("<Q", read(8))
-        return pickle.loads(read(n))
+        return _dec(json.loads(read(n).decode("utf-8")))
 
     def _hub(self, obj, combine):
         """rank 0 collects one object per rank, ``combine(list) -> per-rank replies``; everyone gets its reply."""
@@ -181,12 +252,18 @@ class SocketBootstrap(Bootstrap):
 
 
 class TorchBootstrap(Bootstrap):
-    """torch.distributed (gloo, CPU) rendezvous from the RANK/WORLD_SIZE/MASTER_* environment."""
+    """torch.distributed (gloo, CPU) rendezvous from the RANK/WORLD_SIZE/MASTER_* environment.
+
+    Construct it BEFORE ``lanczos_amd.load_library()`` / the first ``Handle``: the HIP library then binds to the one
+    runtime torch has mapped (and takes RCCL from the same tree).  The opposite order is refused."""
 
     def __init__(self, init=True):
         import torch
         import torch.distributed as dist
 
+        # torch brings its own ROCm runtime (torch/lib): if liblanczos_hip.so was loaded first there are now TWO HIP
+        # runtimes in the process - the round-1 teardown abort (DESIGN.md section 5).  Fail here, loudly.
+        _capi.check_single_runtime()
         self._torch, self._dist = torch, dist
         if init and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -175,3 +175,66 @@ def test_plain_c_client_runs(tmp_path):
     p = subprocess.run([exe, "64", "48", "24"], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "sweeps=24" in p.stdout
+
+
+def test_product_library_has_no_ablation_kernels():
+    """The timing-only ablation arms (template parameter ABL != 0: wrong results on purpose) live only in the
+    kernel-bench build (make KBENCH=1 -> liblanczos_kbench.so).  The kernels' mangled names are embedded in the
+    shared library (host stubs + code-object symbol table): none of them may carry a non-zero ABL argument, and
+    lz_set_tuning refuses the knob values that used to select them."""
+    blob = open(_capi.LIB_PATH, "rb").read()
+    # k_qtw_mfma4<SCALE, U, T, ABL>, k_qtw_valu<SCALE, R, U, NT, ABL>, k_spmv_stream<FIXED_K, ABL>
+    assert re.search(rb"k_qtw_mfma4ILi\d+ELi\d+ELi\d+ELi0EE", blob), "default Q^T w kernel not found - naming changed?"
+    assert not re.search(rb"k_qtw_mfma4ILi\d+ELi\d+ELi\d+ELi[1-9]\d*EE", blob)
+    assert not re.search(rb"k_qtw_valuILi\d+ELi\d+ELi\d+ELi\d+ELi[1-9]\d*EE", blob)
+    assert not re.search(rb"k_spmv_streamILi\d+ELi[1-9]\d*EE", blob)
+    lib = lanczos_amd.load_library()
+    assert lib.lz_set_tuning(None, 1, 21) == -1  # (no handle on a CPU box; with one: tests/test_gpu_kernels.py)
+
+
+def test_two_hip_runtimes_are_detected_and_refused():
+    """Round-1 teardown abort, root cause: PyTorch bundles its own libamdhip64 / libhsa-runtime64 /
+    librccl under torch/lib and looks them up by UNVERSIONED names, which never match the system libraries' sonames - so
+    importing torch AFTER liblanczos_hip.so maps a second HIP runtime into the process.  The opposite order gives one
+    runtime (torch's), to which the library binds and from whose directory it takes RCCL.  Checked in child processes
+    (this needs no GPU: it is pure dynamic-loader behaviour)."""
+    import json
+    import subprocess
+    import sys
+
+    code = r"""
+import json, sys
+sys.path.insert(0, %r)
+order = sys.argv[1]
+import lanczos_amd
+from lanczos_amd import _capi, distributed
+if order == "lz_first":
+    lanczos_amd.load_library()
+    import torch
+else:
+    import torch
+    lanczos_amd.load_library()
+out = {"maps": _capi.mapped_runtimes(), "info": _capi.runtime_info()}
+try:
+    _capi.check_single_runtime()
+    out["refused"] = False
+except _capi.LanczosHipError as e:
+    out["refused"] = True
+try:
+    distributed.TorchBootstrap(init=False)
+    out["bootstrap_refused"] = False
+except _capi.LanczosHipError:
+    out["bootstrap_refused"] = True
+except Exception as e:  # process group not initialised etc.: the runtime check passed
+    out["bootstrap_refused"] = False
+print("OUT" + json.dumps(out))
+""" % ROOT
+    res = {}
+    for order in ("lz_first", "torch_first"):
+        p = subprocess.run([sys.executable, "-c", code, order], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[order] = json.loads([l for l in p.stdout.splitlines() if l.startswith("OUT")][0][3:])
+    bad, good = res["lz_first"], res["torch_first"]
+    assert len(bad["maps"]["amdhip64"]) == 2 and len(bad["maps"]["hsa-runtime64"]) == 2 and bad["refused"] and bad["bootstrap_refused"]
+    assert len(good["maps"]["amdhip64"]) == 1 and not good["refused"] and not good["bootstrap_refused"]
+    assert "torch/lib" in good["info"]["hip"] and good["maps"]["amdhip64"] == [os.path.realpath(good["info"]["hip"])] or good["info"]["hip"] in good["maps"]["amdhip64"]

@@ -21,22 +21,33 @@ WORKER = textwrap.dedent('''
     import numpy as np
     sys.path.insert(0, os.environ["LZ_ROOT"])
     import lanczos_amd
-    lanczos_amd.load_library()                      # system ROCm runtime first, torch (gloo only) second
-    from lanczos_amd import distributed, partition, synthetic
+    from lanczos_amd import _capi, distributed, partition, synthetic
     from oracle import lanczos_ref as oracle
+    # torch (when used at all) comes first: one HIP runtime in the process; the socket bootstrap needs no torch
     boot = distributed.SocketBootstrap() if os.environ.get("LZ_BOOT") == "socket" else distributed.TorchBootstrap()
+    lanczos_amd.load_library()
+    assert len(_capi.mapped_runtimes()["amdhip64"]) == 1, _capi.mapped_runtimes()
     out = {}
     cases = [("lap2d", lambda lo, hi: synthetic.laplacian_2d_5pt(96, 80, rows=(lo, hi)), 96 * 80, "auto", 40),
              ("lap3d", lambda lo, hi: synthetic.laplacian_3d_7pt(24, 20, 18, rows=(lo, hi)), 24 * 20 * 18, "halo", 30),
              ("graph", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 30),
              ("graph_halo", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "halo", 30),
              ("lap3d_partial", lambda lo, hi: synthetic.laplacian_3d_7pt(20, 18, 16, rows=(lo, hi)), 20 * 18 * 16, "halo", 120),
-             ("dense", lambda lo, hi: synthetic.dense_symmetric_hashed(701, rows=(lo, hi), seed=3), 701, "auto", 25)]
+             ("dense", lambda lo, hi: synthetic.dense_symmetric_hashed(701, rows=(lo, hi), seed=3), 701, "auto", 25),
+             # M = 1000 is not a multiple of world * 32: the last rank's all-gather chunk has a tail no kernel writes; the
+             # fresh basis allocation is NaN-poisoned first (tuning knob 13), so the run only survives if the library
+             # clears what the dense GEMV reads against zero-padded columns (0 * NaN = NaN)
+             ("dense_poison", lambda lo, hi: synthetic.dense_symmetric_hashed(1000, rows=(lo, hi), seed=5), 1000, "auto", 25),
+             # BASELINE C4 (3-D 7-point, z-slab partition, k = 200) and C5 (2-D 5-point, k = 500) at reduced size
+             ("c4_slab_k200", lambda lo, hi: synthetic.laplacian_3d_7pt(24, 24, 32, rows=(lo, hi)), 24 * 24 * 32, "halo", 200),
+             ("c5_k500", lambda lo, hi: synthetic.laplacian_2d_5pt(160, 120, rows=(lo, hi)), 160 * 120, "halo", 500)]
     for name, build, M, mode, n in cases:
         b = partition.row_bounds(M, boot.world)
         lo, hi = b[boot.rank], b[boot.rank + 1]
         opts = 64 if name.endswith("_partial") else 0  # LZ_FLAG_REORTH_PARTIAL: every rank must take the same sweep decisions
         s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode, fused_norm=(name != "lap3d"), options=opts)
+        if name == "dense_poison":
+            s.h.set_tuning(13, 1)
         a, bta = s.execute_Lanczos(n)
         sweeps = s.h.last_sweeps()
         theta = s.get_H_eigs()
@@ -48,13 +59,18 @@ WORKER = textwrap.dedent('''
         ao, bo, Vo = oracle.execute_lanczos(full, n, economy=True)
         th_o = np.linalg.eigvalsh(oracle.build_h_eff(ao, bo))
         S = np.linalg.eigh(s.H_eff)[1]
-        out[name] = dict(mode=s.plan.mode, da=float(np.abs(a - ao).max()), db=float(np.abs(bta - bo).max()),
-                         dth=float(np.abs(theta - th_o).max() / np.abs(th_o).max()),
+        # long runs outlive the prefix the reference arithmetic itself determines (converged Ritz values make the late
+        # coefficients rounding noise, see oracle.stable_masks): compare coefficients on that prefix, Ritz values on the mask
+        prefix, mask = (n, np.ones(n, bool)) if n < 100 or name.endswith("_partial") else oracle.stable_masks(full, n, ao, bo)
+        out[name] = dict(mode=s.plan.mode, da=float(np.abs(a - ao)[:prefix].max()), db=float(np.abs(bta - bo)[:max(prefix - 1, 1)].max()),
+                         dth=float(np.abs(theta - th_o)[mask].max() / np.abs(th_o).max()), prefix=int(prefix), nmask=int(mask.sum()),
                          dV=float(np.abs(V[:, :8] - Vo[:8, lo:hi].T).max()), dY=float(np.abs(Y - V @ S).max()),
+                         orth=float(np.abs(boot.allreduce_sum(V.T @ V) - np.eye(n)).max()),
                          comm_launches=s.timings()["comm"]["launches"], sweeps=sweeps, n=n)
     res = boot.allgather_obj(out)
     if boot.rank == 0:
-        print("RESULT", res)
+        import json
+        print("RESULT", json.dumps(res))
 ''')
 
 
@@ -70,12 +86,16 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
            "--master-port", str(port), str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    res = eval([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][len("RESULT"):])
+    import json
+
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0][len("RESULT"):])
     assert len(res) == world
     for per_rank in res:
         assert per_rank["lap2d"]["mode"] == "halo" and per_rank["lap3d"]["mode"] == "halo"
         assert per_rank["graph"]["mode"] == "allgather" and per_rank["graph_halo"]["mode"] == "halo"
-        assert per_rank["dense"]["mode"] == "allgather"
+        assert per_rank["dense"]["mode"] == "allgather" and per_rank["dense_poison"]["mode"] == "allgather"
+        assert per_rank["c4_slab_k200"]["mode"] == "halo" and per_rank["c5_k500"]["mode"] == "halo"
+        assert per_rank["c4_slab_k200"]["prefix"] >= 100 and per_rank["c5_k500"]["prefix"] >= 300, per_rank
         for name, r in per_rank.items():
             if name.endswith("_partial"):
                 # converging run with sweeps: Ritz values of the partial mode vs the oracle's full sweep
@@ -83,7 +103,7 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
                 assert r["sweeps"] == res[0][name]["sweeps"]
                 continue
             assert r["da"] < 1e-11 and r["db"] < 1e-11 and r["dth"] < 1e-10 and r["dV"] < 1e-9 and r["dY"] < 1e-12, (name, r)
-            assert r["comm_launches"] > 0 and r["sweeps"] == r["n"]
+            assert r["comm_launches"] > 0 and r["sweeps"] == r["n"] and r["orth"] < 1e-12, (name, r)
 
 
 def test_rccl_single_rank_communicator():

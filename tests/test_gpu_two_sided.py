@@ -55,7 +55,12 @@ def test_golden(name):
     Y = s.V @ S
     np.testing.assert_allclose(s.H_eigvecs, Y, rtol=0, atol=1e-10 * max(1.0, np.abs(Y).max()))
     if ka == n:
-        assert np.abs(s.H_eigvals - d["H_eigvals"]).max() <= 1e-8 * np.abs(d["H_eigvals"]).max()
+        # get_H_eigs is eigh on the lower triangle, i.e. the symmetric tridiagonal (alpha, beta): by Weyl's inequality the
+        # Ritz values move by at most |dT|_2 <= max|d alpha| + 2 max|d beta|, which the coefficient checks above already
+        # hold to the north-star bar - so the same 1e-10 bar applies to the Ritz values (a factor 3 is the inequality's).
+        delta = max(np.abs(s._alpha - d["alpha"]).max(), np.abs(s._beta - d["beta"]).max())
+        assert np.abs(s.H_eigvals - d["H_eigvals"]).max() <= max(3 * delta, 1e-13 * scale)
+        assert np.abs(s.H_eigvals - d["H_eigvals"]).max() <= 1e-10 * max(np.abs(d["H_eigvals"]).max(), scale)
 
 
 def test_bireorthogonalize_step_matches_oracle():

@@ -131,7 +131,8 @@ WORKER = textwrap.dedent('''
         out[name] = (float(np.abs(a - a1).max()), float(np.abs(b - b1).max()), float(np.abs(V[:8] - V1[:8, lo:hi]).max()), plan.mode)
     res = boot.allgather_obj(out)
     if rank == 0:
-        print("RESULT", res)
+        import json
+        print("RESULT", json.dumps(res))
 ''')
 
 
@@ -147,7 +148,9 @@ def test_two_rank_gloo_partitioned_lanczos(tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0]
-    res = eval(line[len("RESULT"):])
+    import json
+
+    res = json.loads(line[len("RESULT"):])
     for per_rank in res:
         assert per_rank["lap2d"][3] == "halo" and per_rank["graph"][3] == "allgather"
         for name in ("lap2d", "graph"):
