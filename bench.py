@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--no-prewarm", action="store_true", help="skip the untimed runtime pre-warm (used under rocprofv3 --pmc)")
     ap.add_argument("--device", type=int, default=-1, help="GPU index (default: LOCAL_RANK); lets several ranks share one GPU with --backend host")
     ap.add_argument("--overlap", action="store_true", help="N > 1: exchange the halo on a second stream behind the interior re-orthogonalisation update (LZ_FLAG_OVERLAP_HALO)")
+    ap.add_argument("--one-reduce", action="store_true", help="N > 1: LZ_FLAG_ONE_REDUCE - one all-reduce per iteration (alpha, |r|^2 and the coefficients in one buffer)")
     ap.add_argument("--bootstrap", default="socket", choices=["socket", "torch"])
     ap.add_argument("--backend", default="rccl", choices=["rccl", "host"])
     ap.add_argument("--mode", default="auto", choices=["auto", "halo", "allgather"])
@@ -231,9 +232,10 @@ def main():
     if args.overlap:
         prof |= _capi.FLAG_OVERLAP_HALO
     comm_used = "none" if world == 1 else args.backend
+    tuning = {int(kv.split("=")[0]): int(kv.split("=")[1]) for kv in filter(None, args.tune.split(","))}
     try:
         solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend=args.backend, mode=args.mode,
-                                                options=args.options | prof)
+                                                options=args.options | prof, one_reduce=args.one_reduce, tuning=tuning)
         ok = True
     except _capi.LanczosHipError as e:
         if world == 1 or args.backend != "rccl":
@@ -243,14 +245,12 @@ def main():
     if world > 1 and not all(boot.allgather_obj(ok)):
         comm_used = "host-staged (RCCL init failed)"
         solver = distributed.DistributedLanczos(local, M, boot, device_id=local_rank, backend="host", mode=args.mode,
-                                                options=args.options | prof)
+                                                options=args.options | prof, one_reduce=args.one_reduce, tuning=tuning)
     v0 = solver.start_vector(99)[lo:hi].copy()
     # Per-kernel events cost ~3 us each (1.8 % of the headline run when every launch is bracketed): sample every
     # stride-th iteration (centred, so the sampled launches have the same mean basis size as all launches).
     stride = max(1, args.profile_stride)
     solver.h.set_tuning(7, stride)
-    for kv in filter(None, args.tune.split(",")):
-        solver.h.set_tuning(*(int(x) for x in kv.split("=")))
 
     # Setup (not a step): let the runtime finish its one-time work (code-object load of every kernel variant, clock
     # ramp) on a short solve; a ~60 ms one-off stall was observed ~0.1 s after the first launches of a process.
@@ -329,6 +329,7 @@ def main():
                        "partition": f"row-block x{world}", "exchange": solver.plan.mode, "comm": comm_used,
                        "fused_norm_allreduce": bool(solver.options & _capi.FLAG_FUSED_NORM), "profile_stride": stride,
                        "halo_overlap": bool(solver.options & _capi.FLAG_OVERLAP_HALO),
+                       "one_reduce": bool(solver.options & _capi.FLAG_ONE_REDUCE), "spmv_kernel": solver.h.spmv_plan(),
                        "step": "one full k-iteration Lanczos solve"},
             "roofline": dict(per_class[dominant], kernel=dominant) if dominant else None,
             "roofline_all": per_class,

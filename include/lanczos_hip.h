@@ -33,9 +33,10 @@ typedef struct lz_context* lz_handle;
 
 enum lz_status {
   LZ_OK = 0,
-  LZ_WARN_BREAKDOWN = 1, /* lz_run finished, but a residual norm beta underflowed to zero / a coefficient is not finite:
-                            the Krylov space is exhausted.  The reference divides blindly (Lanczos.py:113) and returns the
-                            same inf/NaN coefficients; they are delivered unchanged, this status is the only difference. */
+  LZ_WARN_BREAKDOWN = 1, /* lz_run finished, but a residual norm beta fell to <= 64 eps * max(|alpha|, |beta|) or a
+                            coefficient is not finite: the Krylov space is exhausted.  The reference divides blindly
+                            (Lanczos.py:113) and carries on with rounding noise / inf / NaN; the coefficients are
+                            delivered exactly as computed, this status is the only difference. */
   LZ_ERR_ARG = -1,       /* bad argument / shape */
   LZ_ERR_HIP = -2,       /* HIP runtime error */
   LZ_ERR_COMM = -3,      /* RCCL / host-collective error */
@@ -57,6 +58,12 @@ enum lz_flags {
   LZ_FLAG_SPMV_STREAM = 32,   /* force the generic CSR-stream kernel (no fixed-K fast path) */
   LZ_FLAG_OVERLAP_HALO = 128, /* multi-rank, contiguous (stencil) halos: update the faces of V[j] first, exchange them on a
                                  second stream while the interior is updated; the SpMV waits on an event (opt-in)    */
+  LZ_FLAG_ONE_REDUCE = 256,   /* opt-in, multi-rank runs: ONE all-reduce per iteration.  Pass 1 dots the basis against two
+                                 columns at once on the matrix cores - r'' = A v_j - beta v_{j-1} and v_j - so that alpha_j, the
+                                 coefficients V_i.(r'' - alpha_j v_j) = V_i.r'' - alpha_j V_i.v_j and |r|^2 = r''.r'' - 2 alpha_j
+                                 v_j.r'' + alpha_j^2 v_j.v_j all come out of one reduced buffer (implies LZ_FLAG_FUSED_NORM).
+                                 Same mathematics, different rounding (the three-term update subtracts beta v_{j-1} first, |r|^2
+                                 is formed from three sums): within the 1e-10 bar, not bit-identical to the default. */
   LZ_FLAG_REORTH_PARTIAL = 64 /* opt-in: partial re-orthogonalisation (Simon 1984).  The reference sweeps the whole basis
                                  every step; with this flag the sweep (same kernels, same arithmetic) runs only when the
                                  omega-recurrence estimate of the loss of orthogonality exceeds sqrt(eps), on that and the
@@ -162,6 +169,9 @@ int lz_set_dense_block(lz_handle h, int64_t M_global, int64_t row0, int64_t rows
 int lz_build_stencil3d(lz_handle h, int N, int points, double T_factor, const double* weights4, const double* potential,
                        int negate_T);
 int lz_csr_info(lz_handle h, int64_t* rows, int64_t* nnz);
+/* which SpMV kernel the current matrix + options select: 0 scalar CSR (LZ_FLAG_SPMV_SCALAR), 1 CSR-stream, 2 fixed-K
+ * (stencils), 3 column-blocked two-phase (matrices without column locality, lz_spmv_pb.hip), 4 dense GEMV */
+int lz_spmv_plan(lz_handle h, int* plan);
 /* download the handle's CSR matrix (sizes from lz_csr_info) */
 int lz_get_csr(lz_handle h, int32_t* rowptr, int32_t* colidx, double* vals);
 /* halo plan: for peer p (npeers of them) send x[send_idx[..]] (local row

@@ -27,6 +27,7 @@ FLAG_FUSED_NORM = 16
 FLAG_SPMV_STREAM = 32
 FLAG_REORTH_PARTIAL = 64
 FLAG_OVERLAP_HALO = 128
+FLAG_ONE_REDUCE = 256
 
 KERNEL_CLASSES = ("spmv", "qtw", "update", "three_term", "final", "comm", "ritz")
 K_COUNT = len(KERNEL_CLASSES)
@@ -77,6 +78,7 @@ SIGNATURES = {
     "lz_set_dense_block": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _D]),
     "lz_build_stencil3d": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _D, _D, C.c_int]),
     "lz_csr_info": (C.c_int, [_P, _I64, _I64]),
+    "lz_spmv_plan": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_get_csr": (C.c_int, [_P, _I32, _I32, _D]),
     "lz_set_halo": (C.c_int, [_P, C.c_int, _I32, _I64, _I32, _I64]),
     "lz_set_allgather": (C.c_int, [_P, C.c_int64]),
@@ -365,6 +367,13 @@ class Handle:
             raise ValueError("potential must have N^3 entries")
         self.check(self.lib.lz_build_stencil3d(self._h, int(N), int(points), float(T_factor), dptr(w), None if pot is None else dptr(pot), int(bool(negate_T))))
         self.rows = N**3
+
+    SPMV_PLANS = ("scalar", "csr-stream", "fixed-k", "two-phase", "dense")
+
+    def spmv_plan(self):
+        k = C.c_int()
+        self.check(self.lib.lz_spmv_plan(self._h, C.byref(k)))
+        return self.SPMV_PLANS[k.value]
 
     def get_csr(self):
         rows, nnz = C.c_int64(), C.c_int64()

@@ -416,8 +416,10 @@ double spmv_bytes(lz_handle h) {
 }
 double spmv_flops(lz_handle h) { return h->kind == 1 ? 2.0 * h->csr.nnz : 2.0 * (double)h->rows * (double)h->Mg; }
 
-// r = A V[j]; d_alpha[j] = sum over ranks of V[j] . r
-int step_spmv(lz_handle h, int j) {
+// r = A V[j]; alpha_dst[0] = V[j] . r, summed over ranks unless reduce == false (one-reduce mode: the partial sum rides
+// in the next all-reduce)
+int step_spmv(lz_handle h, int j, double* alpha_dst = nullptr, bool reduce = true) {
+  if (!alpha_dst) alpha_dst = h->d_alpha + j;
   const double* x = nullptr;
   if (h->halo_inflight_j == j) {  // exchange already issued on the comm stream behind the boundary update
     LZ_HIP(h, hipStreamWaitEvent(h->stream, h->e_halo, 0));
@@ -438,10 +440,10 @@ int step_spmv(lz_handle h, int j) {
   }
   {
     Scope sc(h, LZ_K_FINAL, 0, 0);
-    launch_final_sum(h->d_part, np, h->d_alpha + j, h->stream);
+    launch_final_sum(h->d_part, np, alpha_dst, h->stream);
     LZ_TRY(check_launch(h, "final_sum(alpha)"));
   }
-  return comm_allreduce(h, h->d_alpha + j, 1);
+  return reduce ? comm_allreduce(h, alpha_dst, 1) : LZ_OK;
 }
 
 // V[j] = r / sqrt(nrm2) (if scale), then c = V[0:nrows] . V[j]; V[j] = 2 V[j] - c^T V[0:nrows]
@@ -537,6 +539,64 @@ int step_three_term(lz_handle h, int j, int jm1, const double* d_alpha, const do
   return comm_allreduce(h, h->d_nrm2, 1);
 }
 
+// ---- one-reduce mode (LZ_FLAG_ONE_REDUCE): the whole Krylov loop with ONE all-reduce per iteration ---------------------
+// State entering step j: r holds the two-term residual r'' = A u - beta v_{j-2} of the newest vector u = v_{j-1} (at j = 0:
+// r'' = A v0, u = v0 in basis row 0), and the local partial of alpha = u.(A u) sits in the reduce buffer.  Step j:
+//   pass 1 dots rows 0..j-1 against BOTH columns (r'', u) + the three self terms   -> one all-reduce with alpha
+//   prepare: alpha, c_i = V_i.r'' - alpha V_i.u, |r|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u
+//   r = r'' - alpha u;  update: beta = |r|, V[j] = 2 r/beta - sum c_i/beta V_i - ...   (unchanged kernels from here)
+//   exchange V[j]; r = A V[j] (alpha partial into the buffer); r'' = r - beta V[j-1]
+inline int onered_ldp(int m) { return qtw_ldp(m + 2); }
+inline int onered_slot(int m) { return onered_ldp(m) + m + 2; }  // where alpha lives in the reduce buffer at a step with m rows
+
+int run_loop_onereduce(lz_handle h, int n) {
+  const double M = (double)h->rows;
+  LZ_TRY(step_spmv(h, 0, h->d_c + onered_slot(0), false));  // warm-up: r'' = A v0 (Lanczos.py:108), alpha0 partial
+  for (int j = 0; j < n; ++j) {
+    const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+    h->prof_iter = (j % pstride) == pstride / 2;
+    const int bidx = (j + n - 2) % (n - 1);
+    const int m = j, urow = j > 0 ? j - 1 : 0, ldp = onered_ldp(m);
+    double* u = h->d_V + (int64_t)urow * h->ldv;
+    h->qplan.variant = 0;
+    {
+      Scope sc(h, LZ_K_QTW, 8.0 * m * M + 16.0 * M, 4.0 * (m + 1) * M);
+      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, m, urow, h->d_r, nullptr, nullptr, h->qplan, h->d_part, 3, h->stream));
+      LZ_TRY(check_launch(h, "qtw(two columns)"));
+    }
+    {
+      Scope sc(h, LZ_K_FINAL, 0, 0);
+      launch_final_rows_t(h->d_part, h->qplan.G, 2 * ldp, ldp + m + 2, h->d_c, h->stream);
+      LZ_TRY(check_launch(h, "final_rows"));
+    }
+    LZ_TRY(comm_allreduce(h, h->d_c, onered_slot(m) + 1));  // THE collective of this iteration
+    {
+      Scope sc(h, LZ_K_FINAL, 0, 0);
+      launch_onereduce_prepare(h->d_c, m, ldp, h->d_alpha + urow, h->stream);  // j = 0: alpha[0] of the warm-up, rewritten below
+      LZ_TRY(check_launch(h, "onereduce_prepare"));
+    }
+    {
+      Scope sc(h, LZ_K_THREE, 24.0 * M, 2.0 * M);
+      launch_three_term(h->d_r, u, nullptr, h->d_alpha + urow, nullptr, h->rows_pad, h->d_part, h->stream);  // r = r'' - alpha u
+      LZ_TRY(check_launch(h, "three_term(alpha)"));
+    }
+    {
+      Scope sc(h, LZ_K_UPDATE, 8.0 * j * M + 16.0 * M, 2.0 * (j + 1) * M);
+      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_c, h->d_r, h->d_beta + bidx, h->tune[8] == 0 || h->tune[8] >= 3 ? h->tune[8] : 0,
+                    h->stream, 0, -1, 1);
+      LZ_TRY(check_launch(h, "update"));
+    }
+    const bool last = j == n - 1;
+    LZ_TRY(step_spmv(h, j, last ? h->d_alpha + j : h->d_c + onered_slot(j + 1), last));  // the last alpha has no pass to ride on
+    if (!last && j > 0) {
+      Scope sc(h, LZ_K_THREE, 24.0 * M, 2.0 * M);
+      launch_three_term(h->d_r, h->d_V + (int64_t)(j - 1) * h->ldv, nullptr, h->d_beta + bidx, nullptr, h->rows_pad, h->d_part, h->stream);
+      LZ_TRY(check_launch(h, "three_term(beta)"));  // r'' = A V[j] - beta V[j-1]; at j = 0 the reference's V[-1] is the zero row
+    }
+  }
+  return LZ_OK;
+}
+
 int require_basis(lz_handle h, int j) {
   if (!h->d_V) return fail(h, LZ_ERR_STATE, "no basis allocated (call lz_run or lz_basis_alloc first)");
   if (j < 0 || j >= h->n) return fail(h, LZ_ERR_ARG, "basis row index out of range");
@@ -599,6 +659,15 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   A.fixed_k = fixed_k;
   A.max_row_nnz = max_nnz;
   A.avg_row_nnz = (double)nnz / (double)rows_local;
+  // Matrices without column locality (random graphs): the SpMV is bound by cache-missing 8-byte gathers, so it runs as
+  // the column-blocked two-phase kernel pair that gathers out of LDS only (lz_spmv_pb.hip).  Auto: the vector is larger
+  // than the L2s can hold (>= 2^20 columns), rows are not a fixed-K stencil, and more than a quarter of the entries sit
+  // further than 2^18 columns from the diagonal.  tune[14]: 1 = never, 2 = always (tests run it on small matrices).
+  pb_free(A.pb);
+  const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
+  if (want) {
+    LZ_HIP(h, pb_build(A, rowptr_host, &A.pb, h->stream));
+  }
   return LZ_OK;
 }
 
@@ -614,8 +683,15 @@ int upload_csr(lz_handle h, CsrDev& A, const char* who, int64_t rows, int64_t nc
     if (d > max_nnz) max_nnz = (int)d;
     if (d != fixed_k) fixed_k = 0;
   }
-  for (int64_t k = 0; k < nnz; ++k)
-    if (colidx[k] < 0 || colidx[k] >= ncols) return fail(h, LZ_ERR_ARG, std::string(who) + ": column index out of range");
+  int64_t far = 0;
+  for (int64_t i = 0; i < rows; ++i)
+    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+      const int64_t c = colidx[k];
+      if (c < 0 || c >= ncols) return fail(h, LZ_ERR_ARG, std::string(who) + ": column index out of range");
+      far += (c > i ? c - i : i - c) > ((int64_t)1 << 18);
+    }
+  A.far_frac = nnz > 0 ? (double)far / (double)nnz : 0.0;
+  pb_free(A.pb);
   if (fixed_k > 64) fixed_k = 0;
   LZ_TRY(dev_alloc(h, A.rowptr, (size_t)rows + 1));
   LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
@@ -688,6 +764,8 @@ int lz_destroy(lz_handle h) {
   hipFree(h->csr.colidx);
   hipFree(h->csr.vals);
   hipFree(h->csr.rowblk);
+  pb_free(h->csr.pb);
+  pb_free(h->csrT.pb);
   hipFree(h->d_dense);
   hipFree(h->d_V);
   hipFree(h->d_r);
@@ -890,6 +968,21 @@ int lz_csr_info(lz_handle h, int64_t* rows, int64_t* nnz) {
   return LZ_OK;
 }
 
+int lz_spmv_plan(lz_handle h, int* plan) {
+  if (!h || !plan) return LZ_ERR_ARG;
+  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "lz_spmv_plan: no matrix set");
+  if (h->kind == 2) {
+    *plan = 4;
+    return LZ_OK;
+  }
+  const CsrDev& A = h->csr;
+  if (h->flags & LZ_FLAG_SPMV_SCALAR) *plan = 0;
+  else if (A.pb && !(h->flags & LZ_FLAG_SPMV_STREAM)) *plan = 3;
+  else if (!(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7)) *plan = 2;
+  else *plan = 1;
+  return LZ_OK;
+}
+
 int lz_get_csr(lz_handle h, int32_t* rowptr, int32_t* colidx, double* vals) {
   if (!h || !rowptr || !colidx || !vals) return LZ_ERR_ARG;
   if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_get_csr: no CSR matrix set");
@@ -1048,7 +1141,7 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
     LZ_TRY(dev_alloc(h, h->d_r, (size_t)h->ldv));
     LZ_TRY(dev_alloc(h, h->d_alpha, (size_t)n + 1));
     LZ_TRY(dev_alloc(h, h->d_beta, (size_t)n + 1));
-    LZ_TRY(dev_alloc(h, h->d_c, (size_t)n + 1));
+    LZ_TRY(dev_alloc(h, h->d_c, (size_t)2 * qtw_ldp(n + 2) + 8));  // n + 1 coefficients; one-reduce mode: two runs + alpha
     LZ_TRY(dev_alloc(h, h->d_nrm2, 2));
   }
   if (fresh) {
@@ -1063,15 +1156,18 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
   h->n = n;
   h->qplan = plan_qtw(h->rows_pad, h->flags, h->tune, n);
   size_t need = (size_t)(n + 16) * (size_t)h->qplan.P;
+  if (h->flags & LZ_FLAG_ONE_REDUCE) need = (size_t)2 * qtw_ldp(n + 2) * (size_t)h->qplan.P;
   need = std::max<size_t>(need, 4096);
   need = std::max<size_t>(need, (size_t)(h->rows / 4 + 64));                     // dense gemv / scalar spmv partials
   need = std::max<size_t>(need, (size_t)h->csr.n_rowblk + 64);
+  if (h->csr.pb) need = std::max<size_t>(need, (size_t)pb_num_partials(h->csr.pb) + 64);
+  if (h->csrT.pb) need = std::max<size_t>(need, (size_t)pb_num_partials(h->csrT.pb) + 64);
   LZ_TRY(ensure_part(h, need));
   LZ_HIP(h, hipMemsetAsync(h->d_V, 0, (size_t)std::min(zero_rows, n) * (size_t)h->ldv * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_r, 0, (size_t)h->ldv * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_alpha, 0, ((size_t)n + 1) * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_beta, 0, ((size_t)n + 1) * sizeof(double), h->stream));
-  LZ_HIP(h, hipMemsetAsync(h->d_c, 0, ((size_t)n + 1) * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_c, 0, ((size_t)2 * qtw_ldp(n + 2) + 8) * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_nrm2, 0, 2 * sizeof(double), h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
   return LZ_OK;
@@ -1167,7 +1263,7 @@ int lz_spmv_host(lz_handle h, const double* x, double* y) {
   LZ_TRY(dev_alloc(h, h->d_xtmp, nx));
   double* dx = h->d_xtmp;
   double* dy = h->d_xtmp + round_up(h->ncols_ext, kPadDoubles);
-  LZ_TRY(ensure_part(h, std::max<size_t>((size_t)h->csr.n_rowblk + 64, (size_t)(h->rows / 4 + 64))));
+  LZ_TRY(ensure_part(h, std::max<size_t>((size_t)h->csr.n_rowblk + 64, (size_t)(h->rows / 4 + 64))));  // >= the two-phase kernel's row blocks
   LZ_HIP(h, hipMemcpyAsync(dx, x, (size_t)h->ncols_ext * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (h->kind == 1)
     launch_spmv_csr(h->csr, dx, dy, dx, h->d_part, h->flags, h->stream);
@@ -1194,10 +1290,12 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const double t2 = now();
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+  const bool one_reduce = (h->flags & LZ_FLAG_ONE_REDUCE) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL) && h->qplan.family == 2;
+  if (one_reduce) LZ_TRY(run_loop_onereduce(h, n));
   // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
-  LZ_TRY(step_spmv(h, 0));
+  if (!one_reduce) LZ_TRY(step_spmv(h, 0));
   const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL);
-  LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
+  if (!one_reduce) LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
   const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
   const bool partial = (h->flags & LZ_FLAG_REORTH_PARTIAL) != 0;
   // Partial re-orthogonalisation (opt-in): Simon's omega-recurrence on the host, fed with alpha_j and beta_{j+1}
@@ -1219,7 +1317,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   bool force_next = false;
   double normA = 0.0;
   int sweeps = 0;
-  for (int j = 0; j < n; ++j) {
+  for (int j = 0; j < n && !one_reduce; ++j) {
     h->prof_iter = (j % pstride) == pstride / 2;  // centred sample: same mean j as the full run
     const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
     bool sweep = true;
@@ -1270,7 +1368,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
       normA = std::max(normA, std::fabs(two[0]) + hb[(size_t)j] + hb[(size_t)j + 1]);
     }
   }
-  h->last_sweeps = sweeps;
+  h->last_sweeps = one_reduce ? n : sweeps;
   h->prof_iter = true;
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
   const double t3 = now();
@@ -1287,16 +1385,27 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     h->acc.total_ms += ms;
     h->run_timed = false;
   }
-  // Breakdown report.  The reference divides by beta blindly (Lanczos.py:113) and carries inf/NaN
-  // forward; the coefficients are returned exactly like that, and the status says so.  beta[n-2] is also where step
-  // j = 0 parks its norm before step n-1 overwrites it, so every entry of beta_out has been a divisor.
+  // Breakdown report.  The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov
+  // space gives it a residual of rounding noise (or an exact zero and then inf/NaN), and it carries on.  So does this
+  // run - the coefficients are delivered exactly as computed - but the status says so: a beta at or below 64 eps times
+  // the scale of T (max |alpha|, |beta|), or any non-finite coefficient.  beta[n-2] is also where step j = 0 parks its
+  // norm before step n-1 overwrites it, so every entry of beta_out has been a divisor.
+  double tscale = 0.0;
+  for (int j = 0; j < n; ++j) {
+    if (std::isfinite(alpha_out[j])) tscale = std::max(tscale, std::fabs(alpha_out[j]));
+    if (j < n - 1 && std::isfinite(beta_out[j])) tscale = std::max(tscale, std::fabs(beta_out[j]));
+  }
+  const double tiny = 64.0 * 2.220446049250313e-16 * tscale;
   for (int j = 0; j < n; ++j) {
     const bool bad_a = !std::isfinite(alpha_out[j]);
-    const bool bad_b = j < n - 1 && !(std::isfinite(beta_out[j]) && beta_out[j] >= 2.2250738585072014e-308);
+    const bool bad_b = j < n - 1 && !(std::isfinite(beta_out[j]) && beta_out[j] > tiny);
     if (bad_a || bad_b) {
-      char msg[160];
-      snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - %s[%d] is %s (invariant subspace reached; later coefficients are not finite)",
-               bad_b ? "beta" : "alpha", j, bad_b && beta_out[j] == 0.0 ? "zero" : "not a normal number");
+      char msg[200];
+      if (bad_b && std::isfinite(beta_out[j]))
+        snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - beta[%d] = %.3e <= 64 eps * %.3e: the Krylov space is exhausted, later vectors are rounding noise",
+                 j, beta_out[j], tscale);
+      else
+        snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - %s[%d] is not finite (a residual norm reached zero)", bad_b ? "beta" : "alpha", j);
       h->err = msg;
       return LZ_WARN_BREAKDOWN;
     }
@@ -1547,7 +1656,7 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
   }
   if (e == hipSuccess) {
     Scope sc(h, LZ_K_RITZ, 16.0 * n * (double)h->rows + 8.0 * n * n, 2.0 * (double)h->rows * n * n);
-    launch_ritz_gemm(h->d_V, h->ldv, h->rows, n, dS, npad, h->d_Y, n, h->stream);
+    launch_ritz_gemm(h->d_V, h->ldv, h->rows, n, dS, npad, h->d_Y, n, h->stream, h->tune[9]);
     e = hipGetLastError();
   }
   if (e == hipSuccess && Y_out)

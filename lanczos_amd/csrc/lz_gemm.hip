@@ -104,6 +104,120 @@ __global__ __launch_bounds__(kTPB) void k_gemm_tn(const double* __restrict__ A, 
     }
 }
 
+// Persistent variant for the Ritz back-transform (one K chunk, all columns in one group): the same 32 x NT*16 wave tile
+// and MFMA schedule, but a wave does not end with its tile - a grid of one workgroup per CU (one wave per SIMD: the tile
+// needs ~330 registers) walks the row tiles with a grid stride.  Why: with one short-lived workgroup per tile the CU
+// sits idle from the moment the first of its four waves finishes until the next workgroup has been dispatched and its
+// first operands have arrived - 50 k-steps (35 us) of work per 10-15 us of turnover, MfmaUtil 65 % (profiles/r01).  Here the
+// operand pipeline simply runs on into the next tile: the A ring (PA k-steps ahead) is fed by a cursor that crosses tile
+// boundaries, the B row of step 0 is prefetched during the last step, and the only per-tile overhead left is storing
+// the 32 x n results.  Each tile consumes a whole number of ring turns (the padding steps load nothing).
+template <int NT>
+__global__ __launch_bounds__(kTPB) void k_gemm_tn_persist(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
+                                                         const double* __restrict__ B, int64_t ldb, int ncols,
+                                                         double* __restrict__ C, int64_t ldc) {
+  // Branch-free inner loop (one basic block per ring turn, so the scheduler can count outstanding loads exactly):
+  //  * every step of a tile runs, the padding steps included: their A rows are clamped to the last real row (finite
+  //    values) and their B rows are the zero rows of the padded S (4 * nsteps_pad == ldb rows exist), product 0;
+  //  * the A cursor runs past the last tile with clamped (valid, unused) addresses.
+  constexpr int PA = 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int64_t ntiles = (mdim + 31) / 32;
+  const int64_t wave = (int64_t)blockIdx.x * (kTPB / 64) + w, nwaves = (int64_t)gridDim.x * (kTPB / 64);
+  const int nsteps_pad = ((kcount + 3) / 4 + PA - 1) / PA * PA;
+  const int CT = (ncols + 15) / 16;
+  int colb[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) colb[b] = 16 * (b < CT ? b : CT - 1) + lr;
+  // A cursor: (tile, step) of the next load to issue
+  int64_t pt = wave;
+  int ps = 0;
+  auto issue_a = [&](double& x0, double& x1) {
+    const int64_t t = pt < ntiles ? pt : ntiles - 1;
+    int64_t ma = t * 32 + lr, mb = ma + 16;
+    ma = ma < mdim ? ma : mdim - 1;  // rows past the end: valid address, result never stored
+    mb = mb < mdim ? mb : mdim - 1;
+    int kr = 4 * ps + lk;
+    kr = kr < kcount ? kr : kcount - 1;
+    const double* ar = A + (int64_t)kr * lda;
+    x0 = __builtin_nontemporal_load(ar + ma);
+    x1 = __builtin_nontemporal_load(ar + mb);
+    ++ps;
+    if (ps == nsteps_pad) {
+      ps = 0;
+      pt += nwaves;
+    }
+  };
+  double ra[PA][2];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) issue_a(ra[p][0], ra[p][1]);
+  double bcur[NT];
+  {
+    const double* sr = B + (int64_t)lk * ldb;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bcur[b] = sr[colb[b]];
+  }
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+    double4_t acc[2][NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      acc[0][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      acc[1][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    for (int s0 = 0; s0 < nsteps_pad; s0 += PA) {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) {
+        const int st = s0 + p;
+        const double a0 = ra[p][0], a1 = ra[p][1];
+        issue_a(ra[p][0], ra[p][1]);  // refill this ring slot (PA steps ahead, possibly in the next tile)
+        double bnxt[NT];
+        {
+          const int nx = st + 1 < nsteps_pad ? st + 1 : 0;  // last step: row 0 for the next tile
+          const double* sr = B + (int64_t)(4 * nx + lk) * ldb;
+#pragma unroll
+          for (int b = 0; b < NT; ++b) bnxt[b] = sr[colb[b]];
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          acc[0][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bcur[b], acc[0][b], 0, 0, 0);
+          acc[1][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bcur[b], acc[1][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bcur[b] = bnxt[b];
+      }
+    }
+    const int64_t m0 = tile * 32;
+    if (m0 + 32 <= mdim) {  // wave-uniform: every tile but possibly the last stores without row checks
+      double* cbase = C + (m0 + lk) * ldc + lr;
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        const bool colok = b + 1 < CT || 16 * b + lr < ncols;  // only the last column tile can be ragged
+        if (b < CT && colok) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cbase[(int64_t)(16 * a + 4 * g) * ldc + 16 * b] = acc[a][b][g];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          if (b >= CT) continue;
+          const int col = 16 * b + lr;
+          if (col >= ncols) continue;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int64_t m = m0 + 16 * a + lk + 4 * g;
+            if (m < mdim) C[m * ldc + col] = acc[a][b][g];
+          }
+        }
+    }
+  }
+}
+
 static void launch_gemm_tn(const double* A, int64_t lda, int64_t mdim, int64_t kcount, int64_t kchunk, int nz, const double* B,
                            int64_t ldb, int ncols, double* C, int64_t ldc, int64_t zstride, hipStream_t s) {
   const int CT = (ncols + 15) / 16;
@@ -123,8 +237,24 @@ static void launch_gemm_tn(const double* A, int64_t lda, int64_t mdim, int64_t k
 }
 
 void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
-                      int64_t ldy, hipStream_t s) {
-  launch_gemm_tn(V, ldv, rows, n, n, 1, Spad, npad, n, Y, ldy, 0, s);
+                      int64_t ldy, hipStream_t s, int variant) {
+  const int CT = (n + 15) / 16;
+  const int64_t ntiles = (rows + 31) / 32;
+  if (variant == 1 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) {  // A/B arm, > 256 columns, or too few tiles to loop over
+    launch_gemm_tn(V, ldv, rows, n, n, 1, Spad, npad, n, Y, ldy, 0, s);
+    return;
+  }
+  const dim3 grid(kNumCU), block(kTPB);
+#define LZ_TNP(nt)                                                                                                  \
+  case nt:                                                                                                          \
+    hipLaunchKernelGGL((k_gemm_tn_persist<nt>), grid, block, 0, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy); \
+    break;
+  switch (CT) {
+    LZ_TNP(1) LZ_TNP(2) LZ_TNP(3) LZ_TNP(4) LZ_TNP(5) LZ_TNP(6) LZ_TNP(7) LZ_TNP(8)
+    LZ_TNP(9) LZ_TNP(10) LZ_TNP(11) LZ_TNP(12) LZ_TNP(13) LZ_TNP(14) LZ_TNP(15) LZ_TNP(16)
+    default: break;
+  }
+#undef LZ_TNP
 }
 
 // out[i] = sum_z part[z*count + i] (fixed order)

@@ -34,7 +34,15 @@ struct CsrDev {
   int blk_nnz_cap = 4096;     // products per row block (LDS tile of the CSR-stream kernel)
   int max_row_nnz = 0;
   double avg_row_nnz = 0;
+  double far_frac = 0;        // share of entries whose column is > 2^18 away from their row: no L2 reuse of x to speak of
+  struct PbDev* pb = nullptr; // column-blocked two-phase layout (lz_spmv_pb.hip), built when the matrix has no column locality
 };
+
+// ---- column-blocked two-phase SpMV (lz_spmv_pb.hip): gathers out of LDS only; y bit-identical to the CSR-stream kernel
+hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s);  // *out == nullptr: not applicable
+void pb_free(PbDev*& pb);
+int pb_num_partials(const PbDev* pb);
+int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s);
 
 // launch wrappers (all asynchronous on `s`)
 // y = A x (rows), part[b] = sum_{rows of block b} x_own[i] * y[i]; returns number of partials written
@@ -50,6 +58,7 @@ void launch_final_sum(const double* part, int n, double* out, hipStream_t s);
 // c[i] = sum_b part[i*G + b]; transposed (4x4x4 MFMA kernel): c[i] = sum_b part[b*qtw_ldp(nrows) + i]
 inline int qtw_ldp(int nrows) { return (nrows + 15) & ~15; }
 void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed = false);
+void launch_final_rows_t(const double* part, int G, int ldp, int nout, double* c, hipStream_t s);
 
 struct QtwPlan {
   int64_t L = 0;    // elements of w owned by one block (multiple of 512)
@@ -72,6 +81,7 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
                    int64_t pos_lo_b = 0, int64_t pos_hi_b = 0);  // second range: only with the small-range (face) kernel
 void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s);
 void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s);
+void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, hipStream_t s);
 // r = (r - alpha v_j) - beta v_jm1 ; part[b] = partial ||r||^2 ; returns number of partials
 int launch_three_term(double* r, const double* vj, const double* vjm1, const double* alpha, const double* beta,
                       int64_t len, double* part, hipStream_t s);
@@ -92,8 +102,9 @@ void launch_bi_two_term(int sub, int dots, double* r, double* sv, const double* 
 int bi_partials_needed();
 
 // Y(rows x n, row-major, ldy) = sum_k V[k][m] * S[k][i]   (FP64 MFMA)
+// variant 0: persistent waves (one workgroup per CU walks the row tiles); 1: one workgroup per 128 rows (A/B arm)
 void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
-                      int64_t ldy, hipStream_t s);
+                      int64_t ldy, hipStream_t s, int variant = 0);
 // G = Y^T Y as K-chunk partials (n x n each); returns the number of chunks (<= nz_max)
 int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part, int nz_max, hipStream_t s);
 void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s);

@@ -83,6 +83,11 @@ __global__ __launch_bounds__(kFinalThreads) void k_final_rows_t(const double* __
 void launch_final_sum(const double* part, int n, double* out, hipStream_t s) {
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kFinalThreads), 0, s, part, n, out);
 }
+// explicit run length: c[i] = sum_b part[b * ldp + i], i < nout (one-reduce mode: two coefficient runs per block)
+void launch_final_rows_t(const double* part, int G, int ldp, int nout, double* c, hipStream_t s) {
+  if (nout <= 0) return;
+  hipLaunchKernelGGL(k_final_rows_t, dim3((nout + 7) / 8), dim3(kFinalThreads), 0, s, part, G, ldp, nout, c);
+}
 void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed) {
   if (nrows <= 0) return;
   if (transposed)
@@ -147,6 +152,36 @@ __device__ __forceinline__ double qtw_stage_w(double* __restrict__ V, int64_t ld
     }
   }
   return self;
+}
+
+// One-reduce mode (SCALE == 3): two columns are staged - the two-term residual r'' = A u - beta v_{j-2} (sw) and the newest
+// basis vector u = v_{j-1} (su) - and their three mutual dots come back: self[0] = r''.r'', self[1] = u.r'', self[2] = u.u.
+__device__ __forceinline__ void qtw_stage_two(const double* __restrict__ r, const double* __restrict__ u, int64_t base, int cnt2,
+                                              double2* sw, double2* su, double (&self)[3]) {
+  const double2* rr = reinterpret_cast<const double2*>(r + base);
+  const double2* uu = reinterpret_cast<const double2*>(u + base);
+  self[0] = self[1] = self[2] = 0.0;
+  for (int t0 = threadIdx.x; t0 < cnt2; t0 += 4 * kTPB) {
+    double2 a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = t0 + q * kTPB < cnt2;
+      a[q] = ok ? rr[t0 + q * kTPB] : make_double2(0.0, 0.0);
+      b[q] = ok ? uu[t0 + q * kTPB] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (t0 + q * kTPB < cnt2) {
+        sw[t0 + q * kTPB] = a[q];
+        su[t0 + q * kTPB] = b[q];
+        self[0] = fma(a[q].x, a[q].x, self[0]);
+        self[0] = fma(a[q].y, a[q].y, self[0]);
+        self[1] = fma(a[q].x, b[q].x, self[1]);
+        self[1] = fma(a[q].y, b[q].y, self[1]);
+        self[2] = fma(b[q].x, b[q].x, self[2]);
+        self[2] = fma(b[q].y, b[q].y, self[2]);
+      }
+  }
 }
 
 template <int SCALE, int R, int U, int NT = 1, int ABL = 0>  // ABL: timing-only ablation arms, wrong results
@@ -293,11 +328,23 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   // Per-wave coefficients are parked in LDS (after the slice of w) and written when the wave is done, as one contiguous
   // run part[pid][0..nrows): 8-byte partial stores trickling into the read stream cost 6 % of the pass
   // (profiles/r01/ab_qtw_tile_epilogue.json: 1258 -> 1186 us without them), full lines at the end of a block's life do not.
-  double* keep = reinterpret_cast<double*>(sw) + L + (threadIdx.x >> 6) * ldp;
+  // SCALE == 3 (one-reduce mode): two LDS slices - r'' (argument `r`) and u = basis row `j` - and coefficient runs twice
+  // as long: [0, ldp) the dots with r'', [ldp, 2 ldp) the dots with u.  Rows [0, nrows) are ALL streamed (u's own row
+  // included, nothing is skipped); nrows may be 0 (first step: only the three self terms come back).
+  constexpr int NCOL = SCALE == 3 ? 2 : 1;
+  double* keep = reinterpret_cast<double*>(sw) + NCOL * L + (threadIdx.x >> 6) * (NCOL * ldp);
   const int64_t base = (int64_t)blockIdx.x * L;
   const int cnt = (int)(len - base < L ? len - base : L);
-  double self = ABL == 4 ? 0.0 : qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
-  self = wave_sum(self);  // this wave's share of w.w (lane 0); replaces the streamed row-j result below
+  double self = 0.0, self3[3] = {0.0, 0.0, 0.0};
+  if constexpr (SCALE == 3) {
+    qtw_stage_two(r, V + (int64_t)j * ldv, base, cnt >> 1, sw, sw + (L >> 1), self3);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) self3[q] = wave_sum(self3[q]);
+  } else {
+    self = ABL == 4 ? 0.0 : qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
+    self = wave_sum(self);  // this wave's share of w.w (lane 0); replaces the streamed row-j result below
+  }
+  const int jskip = SCALE == 3 ? -1 : j;
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int li = lane & 3, blk = (lane >> 2) & 3, lk = lane >> 4;
@@ -307,8 +354,9 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   if (m_hi > cnt) m_hi = cnt;
   const int nsteps = m_hi > m_lo ? (m_hi - m_lo) >> 5 : 0;  // 32 elements (256 B per row) per step
   const int eoff = 8 * blk + 2 * lk;                          // this lane's double2 within a step
-  const double2* swl = sw + ((m_lo + eoff) >> 1);            // + 16 per step
-  const int i_top = ((nrows - 1) / (4 * T)) * (4 * T);
+  // B operand: column jj = lane & 3 of each 4x4 block; one-reduce mode gives the odd columns the second vector
+  const double2* swl = sw + ((m_lo + eoff) >> 1) + ((SCALE == 3 && (lane & 1)) ? (L >> 1) : 0);  // + 16 per step
+  const int i_top = nrows > 0 ? ((nrows - 1) / (4 * T)) * (4 * T) : 0;
   double sink5 = 0.0;
   // Row pointers of tile k (tiles run from the newest rows down; ABL 3: upwards).
   auto tile_rows = [&](int i0, const double2* (&a)[T]) {
@@ -316,7 +364,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
     for (int t = 0; t < T; ++t) {
       int i = i0 + 4 * t + li;
       if (i >= nrows) i = nrows - 1;  // clamped duplicate, discarded at the store
-      if (i == j) i = j > 0 ? j - 1 : (nrows > 1 ? 1 : 0);  // row j is w itself: its coefficient comes from `self`
+      if (i == jskip) i = j > 0 ? j - 1 : (nrows > 1 ? 1 : 0);  // row j is w itself: its coefficient comes from `self`
       a[t] = reinterpret_cast<const double2*>(V + (int64_t)i * ldv + base + m_lo + eoff);
     }
   };
@@ -344,11 +392,13 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   // The first batch of loads of the NEXT tile is issued before the current tile's results are reduced and stored: the
   // end of a tile otherwise drains the wave's whole load queue (s_waitcnt 0 before the cross-lane adds), a bubble that
   // cost 6 % of the pass (profiles/r01/ab_qtw_tile_epilogue.json).  ABL 6: the old, unpipelined order.
-  const int ntiles = i_top / (4 * T) + 1;
+  const int ntiles = nrows > 0 ? i_top / (4 * T) + 1 : 0;  // one-reduce mode at j = 0: no rows yet, only the self terms
   const double2* a[T];
   double2 av0[T][U];
-  tile_rows(ABL == 3 ? 0 : i_top, a);
-  if (ABL != 6) load_batch(a, 0, av0);
+  if (ntiles > 0) {
+    tile_rows(ABL == 3 ? 0 : i_top, a);
+    if (ABL != 6) load_batch(a, 0, av0);
+  }
   for (int k = 0; k < ntiles; ++k) {
     const int i0 = ABL == 3 ? k * 4 * T : i_top - k * 4 * T;
     double acc[T];
@@ -381,15 +431,26 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
         continue;
       }
       if ((lane & 15) == 0 && row < nrows) keep[row] = v;
+      if (SCALE == 3 && (lane & 15) == 1 && row < nrows) keep[ldp + row] = v;  // column 1: dots with u
     }
   }
   if ((ABL == 5 || ABL == 7) && sink5 == 1.2345e300) part[0] = sink5;
-  if (lane == 0 && j < nrows) keep[j] = self;  // c_j = w.w from the LDS-resident values (row j itself is not streamed)
+  if (SCALE == 3) {
+    if (lane == 0) {  // slots behind the streamed rows: [nrows] = r''.r'', [ldp + nrows] = u.u, [ldp + nrows + 1] = u.r''
+      keep[nrows] = self3[0];
+      keep[ldp + nrows] = self3[2];
+      keep[ldp + nrows + 1] = self3[1];
+    }
+  } else if (lane == 0 && j < nrows) {
+    keep[j] = self;  // c_j = w.w from the LDS-resident values (row j itself is not streamed)
+  }
   __syncthreads();  // the only barrier after staging: the four waves' runs are added (fixed order) and leave as one
-  const double* k0 = reinterpret_cast<const double*>(sw) + L;
-  double* mine = part + (int64_t)blockIdx.x * ldp;
-  for (int i = threadIdx.x; i < nrows; i += kTPB)
-    __builtin_nontemporal_store(((k0[i] + k0[ldp + i]) + k0[2 * ldp + i]) + k0[3 * ldp + i], mine + i);
+  const int run = NCOL * ldp;
+  const int nout = SCALE == 3 ? ldp + nrows + 2 : nrows;
+  const double* k0 = reinterpret_cast<const double*>(sw) + NCOL * L;
+  double* mine = part + (int64_t)blockIdx.x * run;
+  for (int i = threadIdx.x; i < nout; i += kTPB)
+    __builtin_nontemporal_store(((k0[i] + k0[run + i]) + k0[2 * run + i]) + k0[3 * run + i], mine + i);
 }
 
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
@@ -408,7 +469,7 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
     bool found = false;
     // the default kernel also parks four coefficient runs of qtw_ldp(n) doubles in LDS: with thousands of basis rows the
     // slice has to shrink to stay inside the 160 KiB of a CU (n = 4000 -> L <= 3072)
-    int64_t lmax = kQtwMaxL;
+    int64_t lmax = (flags & LZ_FLAG_ONE_REDUCE) ? kQtwMaxL / 2 : kQtwMaxL;  // one-reduce mode stages two slices per block
     const int64_t room = (int64_t)155 * 1024 - (int64_t)(kTPB / 64) * qtw_ldp(nrows_max) * 8;
     if (room / 8 < lmax) lmax = std::max<int64_t>(512, room / 8 / 512 * 512);
     for (int64_t cand = lmax; cand >= 1024 && !found; cand -= 512) {
@@ -445,8 +506,9 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
   const dim3 grid(plan.G), block(kTPB);
 #define LZ_QTW_ARGS V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, plan.P, part
   if (plan.family == 2) {
-    const int ldp = qtw_ldp(nrows);
-    const size_t lds4 = lds + (size_t)(kTPB / 64) * ldp * sizeof(double);  // slice of w + the four waves' coefficient runs
+    const int ncol = SCALE == 3 ? 2 : 1;
+    const int ldp = qtw_ldp(SCALE == 3 ? nrows + 2 : nrows);
+    const size_t lds4 = ncol * (lds + (size_t)(kTPB / 64) * ldp * sizeof(double));  // slice(s) of w + the four waves' coefficient runs
     hipError_t err = hipSuccess;
     auto go = [&](auto kern) {
       // more than 64 KiB of dynamic LDS (long slices with many hundred basis rows) has to be allowed per kernel
@@ -472,7 +534,8 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
     }
     return err;
   }
-  if constexpr (SCALE != 2) {
+  if constexpr (SCALE == 3) return hipErrorInvalidValue;  // one-reduce mode exists for the default (4x4x4 MFMA) family only
+  if constexpr (SCALE != 2 && SCALE != 3) {
     if (plan.family == 1) {
       switch (plan.variant) {
         case 1: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
@@ -506,6 +569,7 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
 
 hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
                       double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s) {
+  if (mode == 3) return launch_qtw_t<3>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
   if (mode == 2) return launch_qtw_t<2>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
   if (mode == 1) return launch_qtw_t<1>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
   return launch_qtw_t<0>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
@@ -753,6 +817,24 @@ __global__ void k_fused_prepare(double* __restrict__ c, int j, double* __restric
     beta_slot[0] = b;
   }
 }
+// One-reduce mode, after the single all-reduce of buf = [p_0..p_{m-1}, r''.r'', gap.., q_0..q_{m-1}, u.u, u.r'', alpha]
+// (p_i = V_i.r'', q_i = V_i.u, m rows, second half at offset ldp, alpha = u.(A u) at ldp + m + 2):
+//   c_i = V_i . (r'' - alpha u) = p_i - alpha q_i,   c_m = |r'' - alpha u|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u
+// left in buf[0..m] exactly where the update kernel's raw-sums path expects [V_i.r ..., r.r]; alpha to alpha_slot.
+__global__ void k_onereduce_prepare(double* __restrict__ buf, int m, int ldp, double* __restrict__ alpha_slot) {
+  const double a = buf[ldp + m + 2];
+  for (int i = threadIdx.x; i < m; i += blockDim.x) buf[i] = buf[i] - a * buf[ldp + i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double rr = buf[m], uu = buf[ldp + m], ur = buf[ldp + m + 1];
+    buf[m] = (rr - 2.0 * a * ur) + a * a * uu;
+    alpha_slot[0] = a;
+  }
+}
+void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_onereduce_prepare, dim3(1), dim3(kTPB), 0, s, buf, m, ldp, alpha_slot);
+}
+
 void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s) {
   hipLaunchKernelGGL(k_fused_prepare, dim3(1), dim3(kTPB), 0, s, c, j, beta_slot);
 }

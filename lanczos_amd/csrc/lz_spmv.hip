@@ -220,6 +220,7 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
     hipLaunchKernelGGL(k_spmv_scalar, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, x, x_own, y, A.rows, part);
     return grid;
   }
+  if (A.pb && !A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) return launch_spmv_pb(A, A.pb, x, y, x_own, part, s);
   if (!A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) {  // A.ablation is always 0 in the product build
     if (A.fixed_k == 5) return launch_spmv_fixed<5>(A, x, y, x_own, part, A.fixed_rb, s);
     if (A.fixed_k == 7) return launch_spmv_fixed<7>(A, x, y, x_own, part, A.fixed_rb, s);

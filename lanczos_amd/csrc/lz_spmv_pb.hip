@@ -1,0 +1,348 @@
+// Column-blocked two-phase SpMV for CSR matrices WITHOUT column locality (random graphs: BASELINE config C3).
+//
+// Why.  r = A v with random columns is a gather of nnz 8-byte values out of a vector that does not fit any cache
+// (C3: 8e7 gathers into 80 MB).  Measured on MI355X (profiles/r01/gather_probe_random_graph.json): such gathers run at
+// ~50e9/s whether v sits in HBM or in the 256 MB Infinity Cache and ~96e9/s out of an XCD's L2 - the limit is the number
+// of outstanding misses, not bytes - so the row-major CSR-stream kernel needs 1.37 ms for a 1.16 GB SpMV (10.6 % of the
+// HBM roofline).  The only memory on the chip that serves a random 8-byte read at full rate is the LDS.
+//
+// How.  Two kernels, each of which gathers out of LDS only (a reorganisation of the technique known as propagation
+// blocking; the layout below is this build's own):
+//   phase 1, one workgroup per COLUMN block cb (W consecutive entries of v staged into LDS with coalesced loads):
+//            streams its matrix entries - stored column-block-major: values `pvals` and 16-bit local columns `pcol` -
+//            and writes the products  T[t] = pvals[t] * v[cb*W + pcol[t]]  as one contiguous stream.
+//   phase 2, one workgroup per ROW block rb (consecutive rows with <= kPbCap entries): copies its products - one short
+//            run per column block - into LDS, then every row adds ITS products out of LDS in CSR order through the
+//            16-bit map `perm` (CSR position -> LDS slot).  Same multiplications, same additions in the same order as
+//            SciPy's csr_matvec: y is bit-identical to the CSR-stream kernel's (tests/test_gpu_kernels.py).
+// T is ordered (column block, row block, -): phase 1 reads and writes purely sequential streams; the only fragmented
+// access is phase 2's read of nCB runs of ~kPbCap/nCB products per row block.
+// Traffic per SpMV: 26 bytes per entry + ~40 bytes per row (C3: 2.5 GB, all of it streamed) instead of 8e7 cache misses.
+//
+// The layout is built on the device at lz_set_csr time (three small integer kernels, LDS histograms); the slot an entry
+// gets inside its (row block, column block) tile depends on atomic order, which is harmless: `perm` is a bijection onto
+// the tile whatever that order is, so every run produces the same bits.
+#include <algorithm>
+#include <vector>
+
+#include "lz_device.h"
+
+namespace lz {
+
+constexpr int kPbThreads = 1024;
+constexpr int kPbCap = 16384;      // products per row block: 128 KiB of LDS in phase 2
+constexpr int kPbMaxRows = 8192;   // rows per row block
+constexpr int kPbMaxW = 19968;     // doubles of v per column block: 156 KiB of LDS in phase 1
+
+struct PbDev {
+  int nCB = 0, nRB = 0;
+  int W = 0;
+  int64_t nnz = 0;
+  int32_t* rbptr = nullptr;    // nRB + 1 row-block boundaries
+  int32_t* cbptr = nullptr;    // nCB + 1: T range of each column block
+  int32_t* toff = nullptr;     // [nRB][nCB]: T offset of tile (cb, rb)
+  uint16_t* lstart = nullptr;  // [nRB][nCB + 1]: LDS slot where tile (rb, cb) starts in phase 2
+  uint16_t* perm = nullptr;    // nnz: CSR position -> LDS slot within its row block
+  uint16_t* pcol = nullptr;    // nnz (T order): column - cb * W
+  double* pvals = nullptr;     // nnz (T order)
+  double* T = nullptr;         // nnz products
+  bool wide_runs = false;      // tiles average more than 20 products: 32 lanes copy a tile (else 16)
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_pb_hist(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                 const int32_t* __restrict__ rbptr, int W, int nCB, int32_t* __restrict__ toff) {
+  extern __shared__ int hist[];
+  const int rb = blockIdx.x;
+  for (int c = threadIdx.x; c < nCB; c += blockDim.x) hist[c] = 0;
+  __syncthreads();
+  const int k0 = rowptr[rbptr[rb]], k1 = rowptr[rbptr[rb + 1]];
+  for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) atomicAdd(&hist[colidx[k] / W], 1);
+  __syncthreads();
+  for (int c = threadIdx.x; c < nCB; c += blockDim.x) toff[(int64_t)rb * nCB + c] = hist[c];
+}
+
+// per column block: exclusive prefix over the row blocks (in place), total to tot[cb]
+__global__ __launch_bounds__(256) void k_pb_scan_rb(int32_t* __restrict__ toff, int nRB, int nCB, int32_t* __restrict__ tot) {
+  const int cb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cb >= nCB) return;
+  int run = 0;
+  for (int rb = 0; rb < nRB; ++rb) {
+    const int v = toff[(int64_t)rb * nCB + cb];
+    toff[(int64_t)rb * nCB + cb] = run;
+    run += v;
+  }
+  tot[cb] = run;
+}
+
+// place every entry: T slot, 16-bit local column, and the LDS slot phase 2 will find its product in
+__global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                                  const double* __restrict__ vals, const int32_t* __restrict__ rbptr, int W, int nCB,
+                                                  int nRB, const int32_t* __restrict__ cbptr, int32_t* __restrict__ toff,
+                                                  uint16_t* __restrict__ lstart, uint16_t* __restrict__ perm,
+                                                  uint16_t* __restrict__ pcol, double* __restrict__ pvals) {
+  extern __shared__ int sm[];
+  int* cursor = sm;          // nCB
+  int* ls = sm + nCB;        // nCB + 1
+  const int rb = blockIdx.x;
+  // tile lengths of this row block = difference of the per-column-block prefixes of row blocks rb and rb + 1
+  for (int c = threadIdx.x; c < nCB; c += blockDim.x) {
+    const int a = toff[(int64_t)rb * nCB + c];
+    const int b = rb + 1 < nRB ? toff[(int64_t)(rb + 1) * nCB + c] : cbptr[c + 1] - cbptr[c];
+    cursor[c] = 0;
+    ls[c + 1] = b - a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // setup path: a plain serial scan over <= a few thousand counters
+    ls[0] = 0;
+    for (int c = 0; c < nCB; ++c) ls[c + 1] += ls[c];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c <= nCB; c += blockDim.x) lstart[(int64_t)rb * (nCB + 1) + c] = (uint16_t)ls[c];
+  const int k0 = rowptr[rbptr[rb]], k1 = rowptr[rbptr[rb + 1]];
+  for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+    const int col = colidx[k];
+    const int cb = col / W;
+    const int p = atomicAdd(&cursor[cb], 1);
+    const int64_t t = (int64_t)cbptr[cb] + toff[(int64_t)rb * nCB + cb] + p;
+    pvals[t] = vals[k];
+    pcol[t] = (uint16_t)(col - cb * W);
+    perm[k] = (uint16_t)(ls[cb] + p);
+  }
+}
+
+// toff[rb][cb] += cbptr[cb]: absolute T offsets for phase 2
+__global__ __launch_bounds__(256) void k_pb_add(int32_t* __restrict__ toff, const int32_t* __restrict__ cbptr, int64_t total, int nCB) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) toff[i] += cbptr[i % nCB];
+}
+
+// ---- phase 1: T = pvals * v[columns], column block in LDS
+template <int U>
+__global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __restrict__ cbptr, const double* __restrict__ pvals,
+                                                           const uint16_t* __restrict__ pcol, const double* __restrict__ x,
+                                                           int64_t ncols, int W, double* __restrict__ T) {
+  extern __shared__ double xs[];
+  const int cb = blockIdx.x;
+  const int64_t c0 = (int64_t)cb * W;
+  const int wn = (int)(ncols - c0 < W ? ncols - c0 : W);
+  // W and c0 are multiples of 32: whole double2 lanes except possibly the very last pair of the vector
+  {
+    const double2* x2 = reinterpret_cast<const double2*>(x + c0);
+    double2* s2 = reinterpret_cast<double2*>(xs);
+    const int n2 = wn >> 1;
+    for (int i = threadIdx.x; i < n2; i += kPbThreads) s2[i] = x2[i];
+    if ((wn & 1) && threadIdx.x == 0) xs[wn - 1] = x[c0 + wn - 1];
+  }
+  __syncthreads();
+  const int64_t t0 = cbptr[cb], t1 = cbptr[cb + 1];
+  for (int64_t tb = t0 + threadIdx.x; tb < t1; tb += (int64_t)U * kPbThreads) {
+    double a[U];
+    uint16_t c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = tb + (int64_t)u * kPbThreads;
+      const bool ok = t < t1;
+      a[u] = ok ? __builtin_nontemporal_load(pvals + t) : 0.0;
+      c[u] = ok ? __builtin_nontemporal_load(pcol + t) : (uint16_t)0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = tb + (int64_t)u * kPbThreads;
+      if (t < t1) T[t] = a[u] * xs[c[u]];
+    }
+  }
+}
+
+// ---- phase 2: row sums out of LDS in CSR order, alpha partial per row block
+template <int GS>  // lanes that copy one tile together
+__global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restrict__ rbptr, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ toff, const uint16_t* __restrict__ lstart,
+                                                       const uint16_t* __restrict__ perm, const double* __restrict__ T, int nCB,
+                                                       const double* __restrict__ xown, double* __restrict__ y,
+                                                       double* __restrict__ part) {
+  extern __shared__ double seg[];
+  __shared__ double red[kPbThreads / 64];
+  const int rb = blockIdx.x;
+  const int32_t* to = toff + (int64_t)rb * nCB;
+  const uint16_t* ls = lstart + (int64_t)rb * (nCB + 1);
+  constexpr int NG = kPbThreads / GS;
+  const int g = threadIdx.x / GS, l = threadIdx.x % GS;
+  // four tiles per trip: all their first loads are issued before the first LDS store
+  for (int cb0 = g; cb0 < nCB; cb0 += 4 * NG) {
+    int off[4], a[4], len[4];
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cb = cb0 + q * NG;
+      const bool ok = cb < nCB;
+      off[q] = ok ? to[cb] : 0;
+      a[q] = ok ? ls[cb] : 0;
+      len[q] = ok ? ls[cb + 1] - a[q] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = l < len[q] ? __builtin_nontemporal_load(T + off[q] + l) : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (l < len[q]) seg[a[q] + l] = v[q];
+      for (int t = l + GS; t < len[q]; t += GS) seg[a[q] + t] = __builtin_nontemporal_load(T + off[q] + t);
+    }
+  }
+  __syncthreads();
+  const int r0 = rbptr[rb], r1 = rbptr[rb + 1];
+  const int k0 = rowptr[r0];
+  double d = 0.0;
+  for (int row = r0 + threadIdx.x; row < r1; row += kPbThreads) {
+    const int ka = rowptr[row], kb = rowptr[row + 1];
+    const uint16_t* pp = perm + ka;
+    double sum = 0.0;
+    int k = 0;
+    const int n = kb - ka;
+    for (; k + 4 <= n; k += 4) {  // four LDS reads in flight; the adds stay in CSR order
+      const double p0 = seg[pp[k]], p1 = seg[pp[k + 1]], p2 = seg[pp[k + 2]], p3 = seg[pp[k + 3]];
+      sum += p0;
+      sum += p1;
+      sum += p2;
+      sum += p3;
+    }
+    for (; k < n; ++k) sum += seg[pp[k]];
+    y[row] = sum;
+    d += xown[row] * sum;
+  }
+  (void)k0;
+  d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < kPbThreads / 64; ++i) t += red[i];
+    part[rb] = t;
+  }
+}
+
+template <class T>
+hipError_t pb_alloc(T*& p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+  p = static_cast<T*>(q);
+  return e;
+}
+
+}  // namespace
+
+void pb_free(PbDev*& pb) {
+  if (!pb) return;
+  hipFree(pb->rbptr);
+  hipFree(pb->cbptr);
+  hipFree(pb->toff);
+  hipFree(pb->lstart);
+  hipFree(pb->perm);
+  hipFree(pb->pcol);
+  hipFree(pb->pvals);
+  hipFree(pb->T);
+  delete pb;
+  pb = nullptr;
+}
+
+// Build the two-phase layout for the device CSR matrix A.  Returns hipSuccess with *out == nullptr when the matrix does
+// not qualify (a single row longer than the LDS tile, or too few columns to be worth blocking).
+hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s) {
+  *out = nullptr;
+  if (A.rows <= 0 || A.nnz <= 0 || A.max_row_nnz > kPbCap) return hipSuccess;
+  // Column blocks: as few as the LDS allows (a tile run is ~kPbCap / nCB products: fewer blocks, longer runs), and a
+  // multiple of 256 workgroups where that matters for balance.
+  int64_t W = round_up((A.ncols + 511) / 512, kPadDoubles);
+  if (W < 256) W = 256;
+  if (W > kPbMaxW) W = kPbMaxW;
+  const int nCB = (int)((A.ncols + W - 1) / W);
+  // row blocks: consecutive rows, <= kPbCap entries, <= kPbMaxRows rows
+  std::vector<int32_t> rb;
+  rb.push_back(0);
+  for (int64_t r = 0; r < A.rows;) {
+    int64_t e = r;
+    const int64_t k0 = rowptr_host[r];
+    while (e < A.rows && e - r < kPbMaxRows && (int64_t)rowptr_host[e + 1] - k0 <= kPbCap) ++e;
+    rb.push_back((int32_t)e);  // e > r: no row is longer than kPbCap
+    r = e;
+  }
+  const int nRB = (int)rb.size() - 1;
+  PbDev* pb = new PbDev();
+  pb->nCB = nCB;
+  pb->nRB = nRB;
+  pb->W = (int)W;
+  pb->nnz = A.nnz;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t x) {
+    if (e == hipSuccess && x != hipSuccess) e = x;
+  };
+  int32_t* tot = nullptr;
+  chk(pb_alloc(pb->rbptr, (size_t)nRB + 1));
+  chk(pb_alloc(pb->cbptr, (size_t)nCB + 1));
+  chk(pb_alloc(pb->toff, (size_t)nRB * nCB));
+  chk(pb_alloc(pb->lstart, (size_t)nRB * (nCB + 1)));
+  chk(pb_alloc(pb->perm, (size_t)A.nnz));
+  chk(pb_alloc(pb->pcol, (size_t)A.nnz));
+  chk(pb_alloc(pb->pvals, (size_t)A.nnz));
+  chk(pb_alloc(pb->T, (size_t)A.nnz));
+  chk(pb_alloc(tot, (size_t)nCB));
+  if (e == hipSuccess) chk(hipMemcpyAsync(pb->rbptr, rb.data(), rb.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_pb_hist, dim3(nRB), dim3(256), (size_t)nCB * sizeof(int), s, A.rowptr, A.colidx, pb->rbptr, (int)W, nCB, pb->toff);
+    hipLaunchKernelGGL(k_pb_scan_rb, dim3((nCB + 255) / 256), dim3(256), 0, s, pb->toff, nRB, nCB, tot);
+    chk(hipGetLastError());
+  }
+  std::vector<int32_t> cbp((size_t)nCB + 1, 0);
+  if (e == hipSuccess) chk(hipMemcpyAsync(cbp.data() + 1, tot, (size_t)nCB * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (e == hipSuccess) chk(hipStreamSynchronize(s));
+  if (e == hipSuccess) {
+    for (int c = 0; c < nCB; ++c) cbp[(size_t)c + 1] += cbp[(size_t)c];
+    if (cbp[(size_t)nCB] != A.nnz) e = hipErrorUnknown;  // cannot happen: every entry was counted once
+  }
+  if (e == hipSuccess) chk(hipMemcpyAsync(pb->cbptr, cbp.data(), cbp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_pb_place, dim3(nRB), dim3(256), (size_t)(2 * nCB + 1) * sizeof(int), s, A.rowptr, A.colidx, A.vals, pb->rbptr,
+                       (int)W, nCB, nRB, pb->cbptr, pb->toff, pb->lstart, pb->perm, pb->pcol, pb->pvals);
+    const int64_t total = (int64_t)nRB * nCB;
+    hipLaunchKernelGGL(k_pb_add, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pb->toff, pb->cbptr, total, nCB);
+    chk(hipGetLastError());
+    chk(hipStreamSynchronize(s));
+  }
+  hipFree(tot);
+  pb->wide_runs = (double)pb->nnz / ((double)nRB * (double)nCB) > 20.0;
+  // both phases may need more than the default 64 KiB of dynamic LDS: allowed once per kernel, here, so that the
+  // launches themselves have no failure mode
+  if (e == hipSuccess && W * sizeof(double) > 65536)
+    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_products<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W * sizeof(double))));
+  if (e == hipSuccess) {
+    const int lds2 = kPbCap * (int)sizeof(double);
+    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+  }
+  if (e != hipSuccess) {
+    pb_free(pb);
+    return e;
+  }
+  *out = pb;
+  return hipSuccess;
+}
+
+int pb_num_partials(const PbDev* pb) { return pb->nRB; }
+
+// y = A x (both phases, asynchronous on s); part[rb] = sum over the rows of row block rb of x_own[i] * y[i].
+// Returns the number of partials.
+int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s) {
+  const size_t lds1 = (size_t)pb->W * sizeof(double);
+  const size_t lds2 = (size_t)kPbCap * sizeof(double);
+  hipLaunchKernelGGL(k_pb_products<8>, dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, x, A.ncols, pb->W, pb->T);
+  if (pb->wide_runs)
+    hipLaunchKernelGGL(k_pb_rows<32>, dim3(pb->nRB), dim3(kPbThreads), lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T,
+                       pb->nCB, x_own, y, part);
+  else
+    hipLaunchKernelGGL(k_pb_rows<16>, dim3(pb->nRB), dim3(kPbThreads), lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T,
+                       pb->nCB, x_own, y, part);
+  return pb->nRB;
+}
+
+}  // namespace lz

@@ -318,7 +318,12 @@ class DistributedLanczos:
     / ``H_eigvecs_local`` hold this rank's rows.
     """
 
-    def __init__(self, local, M, boot=None, device_id=0, backend="rccl", mode="auto", options=0, fused_norm=True):
+    def __init__(self, local, M, boot=None, device_id=0, backend="rccl", mode="auto", options=0, fused_norm=True, one_reduce=False,
+                 tuning=None):
+        self._tuning = dict(tuning or {})  # lz_set_tuning knobs applied BEFORE the matrix is uploaded (some are read there)
+        if one_reduce:  # opt-in: alpha, |r|^2 and the re-orthogonalisation coefficients travel in ONE all-reduce per iteration
+            options |= _capi.FLAG_ONE_REDUCE
+            fused_norm = True
         self.boot = boot or Bootstrap()
         self.M = int(M)
         self.rank, self.world = self.boot.rank, self.boot.world
@@ -347,6 +352,8 @@ class DistributedLanczos:
         self.options = options
         self.h = _capi.Handle(device_id)
         self.h.set_options(options)
+        for k, v in self._tuning.items():
+            self.h.set_tuning(k, v)
         self.backend = backend
         self._init_comm(backend)
         self.h.set_csr(self.M, self.lo, local.rowptr, self.plan.colidx, local.vals, ncols_ext=self.plan.ncols_ext)
@@ -366,6 +373,8 @@ class DistributedLanczos:
         self.options = options
         self.h = _capi.Handle(device_id)
         self.h.set_options(options)
+        for k, v in self._tuning.items():
+            self.h.set_tuning(k, v)
         self.backend = backend
         self._init_comm(backend)
         chunk = partition.chunk_size(self.M, self.world)

@@ -280,6 +280,15 @@ def stable_masks(H, n, alpha, beta, seed=99, v0=None, tol=1e-12):
     return prefix, np.abs(th2 - th) <= tol * scale
 
 
+def stable_basis_rows(H, n, V, seed=99, v0=None, tol=1e-11):
+    """Number of leading basis rows that the reordered evaluation reproduces to ``tol`` (absolute; rows are unit
+    vectors).  The vectors lose determinacy a few steps BEFORE the coefficients do: near the end of the stable
+    coefficient prefix they already differ by 1e-8 between two summation orders of the reference arithmetic itself."""
+    _, _, V2 = execute_lanczos_reordered(H, n, seed, v0)
+    bad = np.abs(V2 - V).max(axis=1) > tol
+    return int(np.argmax(bad)) if bad.any() else n
+
+
 def converged_ritz(alpha, beta, tol=1e-9):
     """Ritz values of T(alpha, beta) whose residual bound max(beta)*|S[n-1, i]| is below
     ``tol`` times the spectral scale: these approximate true eigenvalues and are

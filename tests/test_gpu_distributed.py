@@ -34,6 +34,9 @@ WORKER = textwrap.dedent('''
              ("graph_halo", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "halo", 30),
              ("lap3d_partial", lambda lo, hi: synthetic.laplacian_3d_7pt(20, 18, 16, rows=(lo, hi)), 20 * 18 * 16, "halo", 120),
              ("dense", lambda lo, hi: synthetic.dense_symmetric_hashed(701, rows=(lo, hi), seed=3), 701, "auto", 25),
+             # LZ_FLAG_ONE_REDUCE: one all-reduce (+ one halo exchange / all-gather) per iteration instead of two
+             ("lap2d_onereduce", lambda lo, hi: synthetic.laplacian_2d_5pt(96, 80, rows=(lo, hi)), 96 * 80, "halo", 40),
+             ("graph_onereduce", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 30),
              # M = 1000 is not a multiple of world * 32: the last rank's all-gather chunk has a tail no kernel writes; the
              # fresh basis allocation is NaN-poisoned first (tuning knob 13), so the run only survives if the library
              # clears what the dense GEMV reads against zero-padded columns (0 * NaN = NaN)
@@ -45,7 +48,8 @@ WORKER = textwrap.dedent('''
         b = partition.row_bounds(M, boot.world)
         lo, hi = b[boot.rank], b[boot.rank + 1]
         opts = 64 if name.endswith("_partial") else 0  # LZ_FLAG_REORTH_PARTIAL: every rank must take the same sweep decisions
-        s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode, fused_norm=(name != "lap3d"), options=opts)
+        s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode, fused_norm=(name != "lap3d"), options=opts,
+                                           one_reduce=name.endswith("_onereduce"))
         if name == "dense_poison":
             s.h.set_tuning(13, 1)
         a, bta = s.execute_Lanczos(n)
@@ -64,6 +68,7 @@ WORKER = textwrap.dedent('''
         prefix, mask = (n, np.ones(n, bool)) if n < 100 or name.endswith("_partial") else oracle.stable_masks(full, n, ao, bo)
         out[name] = dict(mode=s.plan.mode, da=float(np.abs(a - ao)[:prefix].max()), db=float(np.abs(bta - bo)[:max(prefix - 1, 1)].max()),
                          dth=float(np.abs(theta - th_o)[mask].max() / np.abs(th_o).max()), prefix=int(prefix), nmask=int(mask.sum()),
+                         scale=float(max(np.abs(ao).max(), np.abs(bo).max())),
                          dV=float(np.abs(V[:, :8] - Vo[:8, lo:hi].T).max()), dY=float(np.abs(Y - V @ S).max()),
                          orth=float(np.abs(boot.allreduce_sum(V.T @ V) - np.eye(n)).max()),
                          comm_launches=s.timings()["comm"]["launches"], sweeps=sweeps, n=n)
@@ -102,8 +107,14 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
                 assert 1 <= r["sweeps"] < r["n"] and r["dth"] < 1e-10 and r["dY"] < 1e-12, (name, r)
                 assert r["sweeps"] == res[0][name]["sweeps"]
                 continue
-            assert r["da"] < 1e-11 and r["db"] < 1e-11 and r["dth"] < 1e-10 and r["dV"] < 1e-9 and r["dY"] < 1e-12, (name, r)
+            # short runs: 1e-11 absolute on every coefficient; the k = 200 / 500 runs: the north-star bar (1e-10 of the
+            # spectral scale) on the stable prefix, whose end is by definition where coefficients start to move at 1e-12
+            ctol = 1e-11 if r["n"] < 100 else 1e-10 * r["scale"]
+            assert r["da"] < ctol and r["db"] < ctol and r["dth"] < 1e-10 and r["dV"] < 1e-9 and r["dY"] < 1e-12, (name, r)
             assert r["comm_launches"] > 0 and r["sweeps"] == r["n"] and r["orth"] < 1e-12, (name, r)
+        # collectives per run: default (fused norm) = (n + 1) exchanges + (n + 1) alpha all-reduces + n coefficient
+        # all-reduces; one-reduce = (n + 1) exchanges + n combined all-reduces + the last alpha
+        assert per_rank["lap2d"]["comm_launches"] == 3 * 40 + 2 and per_rank["lap2d_onereduce"]["comm_launches"] == 2 * 40 + 2, per_rank
 
 
 def test_rccl_single_rank_communicator():

@@ -65,6 +65,72 @@ def test_spmv_bit_exact(hip, name, flags):
     h.close()
 
 
+def _two_phase_matrices():
+    rng = np.random.default_rng(11)
+    big = synthetic.random_graph_laplacian(60000, 210000, seed=8).to_scipy()  # several row blocks x 118 column blocks
+    vals = big.copy()
+    vals.data = rng.standard_normal(big.nnz)  # non-integer values: products and partial sums really round
+    too_long = scipy.sparse.random(40000, 40000, density=0.0002, random_state=rng, format="lil")
+    too_long[7, :] = 1.0  # 40000 entries > the 16384-product LDS tile: the layout does not apply, CSR-stream runs instead
+    return {"graph_60000": big, "graph_60000_real": vals.tocsr(), "row_too_long": too_long.tocsr()}
+
+
+@pytest.mark.parametrize("name", ["graph_5000", "ragged_3000", "longrow_9000", "empty_rows", "lap2d_37x29", "lap2d_400x300",
+                                  "graph_60000", "graph_60000_real", "row_too_long"])
+def test_spmv_two_phase_bit_exact(hip, name):
+    """The column-blocked two-phase SpMV (lz_spmv_pb.hip; auto-selected for matrices without column locality, forced here
+    with tuning knob 14 = 2): products staged through a column-block-major buffer, every row summed out of LDS in CSR
+    order - bit-identical to SciPy's csr_matvec, including rows of up to 16384 entries."""
+    H = MATS[name] if name in MATS else _two_phase_matrices()[name]
+    M = H.shape[0]
+    h = hip.Handle(0)
+    h.set_tuning(14, 2)
+    h.set_csr(M, 0, H.indptr, H.indices, H.data)
+    assert h.spmv_plan() == ("csr-stream" if name == "row_too_long" else "two-phase")
+    x = np.random.default_rng(1).uniform(-1, 1, M)
+    ref = H * x
+    for _ in range(2):  # the layout's scratch buffer is reused between calls
+        y = h.spmv_host(x)
+        if name == "row_too_long":
+            long_rows = np.diff(H.indptr) > 4096
+            assert np.array_equal(y[~long_rows], ref[~long_rows])
+            np.testing.assert_allclose(y[long_rows], ref[long_rows], rtol=0, atol=1e-12)
+        else:
+            assert np.array_equal(y, ref), f"max diff {np.abs(y - ref).max()}"
+    # fused alpha partials
+    h.basis_alloc(3)
+    v = np.random.default_rng(2).standard_normal(M)
+    h.basis_set_row(1, v)
+    a = h.step_spmv(1)
+    r = h.r_get()
+    if name != "row_too_long":
+        assert np.array_equal(r, H * v)
+    assert abs(a - np.dot(v, H * v)) <= 1e-13 * np.dot(np.abs(v), np.abs(H) * np.abs(v))
+    h.close()
+
+
+def test_two_phase_spmv_in_the_run_loop(hip):
+    """Whole Lanczos runs with and without the two-phase SpMV: r is bit-identical, alpha differs only by the grouping of
+    its partial sums."""
+    A = synthetic.random_graph_laplacian(60000, 210000, seed=8)
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    out = []
+    for knob in (1, 2):
+        h = hip.Handle(0)
+        h.set_tuning(14, knob)
+        h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+        a, b = h.run(50, v0)
+        out.append((a, b, h.get_basis()))
+        h.close()
+    (a0, b0, V0), (a1, b1, V1) = out
+    scale = np.abs(a0).max()
+    assert np.abs(a1 - a0).max() < 1e-12 * scale and np.abs(b1 - b0).max() < 1e-12 * scale
+    assert np.abs(V1[:10] - V0[:10]).max() < 1e-11
+    assert np.abs(V1 @ V1.T - np.eye(50)).max() < 1e-12
+
+
 def test_spmv_step_and_alpha(hip):
     H = MATS["graph_5000"]
     M = H.shape[0]

@@ -56,8 +56,11 @@ def test_golden(name):
         # hold the device basis to the reference's own level on this fixture
         ref_orth = np.abs(d["V"] @ d["V"].T - np.eye(n)).max()
         assert np.abs(s.V.T @ s.V - np.eye(n)).max() < max(1e-12, 100 * ref_orth)
-        # the golden basis on the WHOLE prefix the reference arithmetic determines (not just its first rows)
-        np.testing.assert_allclose(s.V[:, :prefix], d["V"][:prefix].T, rtol=0, atol=1e-9)
+        # the golden basis on the WHOLE prefix of rows the reference arithmetic determines (to 1e-11 under a change of
+        # summation order; the vectors lose determinacy a few steps before the coefficients do)
+        vrows = oracle.stable_basis_rows(H, n, d["V"], seed=seed, v0=v0)
+        assert vrows >= min(prefix, 20) - 5 and vrows >= min(n, 10)
+        np.testing.assert_allclose(s.V[:, :vrows], d["V"][:vrows].T, rtol=0, atol=1e-9)
     if "H_eigvecs_first3" in d:
         # Ritz vectors of the three lowest Ritz values against the reference's, sign-fixed.  A Ritz vector is only as well
         # determined as its Ritz value is isolated in T (sin(angle) ~ |dT| / gap), and - when the run outlives the stable
@@ -88,13 +91,12 @@ def test_golden_n_equals_M_edge():
     assert np.isfinite(s.H_eff).all()
     th = np.linalg.eigvalsh(s.H_eff)
     scale = np.abs(d["H_eigvals"]).max()
-    # n = M: T is (numerically) similar to H, so its converged Ritz values are H's eigenvalues whatever rounding noise the
-    # late coefficients carry.  North-star bar (1e-10 of the spectral scale) on every Ritz value the REFERENCE run itself
-    # has converged (residual bound <= 1e-9 scale); at least the 20 lowest the old 1e-8 check looked at must be among them.
-    conv = oracle.converged_ritz(d["alpha"], d["beta"])
-    assert len(conv) >= 20
-    nearest = np.abs(th[None, :] - conv[:, None]).min(axis=1)
-    assert nearest.max() <= RTOL * scale
+    # North-star bar (1e-10 of the spectral scale) on every Ritz value the reference arithmetic itself determines
+    # (unchanged to 1e-12 when its inner products are summed in another order, oracle.stable_masks): on this fixture
+    # that is the whole spectrum - the tridiagonal 1-D problem keeps beta = O(1) to the last step.
+    prefix, mask = oracle.stable_masks(H, 1001, d["alpha"], d["beta"])
+    assert mask[:20].all() and mask.sum() >= 900
+    assert ritz_close(th, d["H_eigvals"], mask)
 
 
 def test_irregular_facade_matches_regular():
@@ -174,10 +176,11 @@ def test_error_surface_on_device():
     assert ritz_close(s.H_eigvals, d["H_eigvals"])
 
 
-@pytest.mark.parametrize("flags", [2, 4, 16, 4 | 16, 32, 8])
+@pytest.mark.parametrize("flags", [2, 4, 16, 4 | 16, 32, 8, 16 | 256])
 def test_kernel_variants_agree(flags):
     """16x16x4-MFMA (2) and VALU (4) Q^T w arms, fused-norm (16, also with VALU), generic CSR-stream (32) and scalar
-    SpMV (8) arms against the default path (4x4x4-MFMA Q^T w, fixed-K SpMV)."""
+    SpMV (8) arms, and the one-all-reduce-per-iteration loop (256: pass 1 dots two columns at once, alpha and |r|^2
+    come out of the same reduced buffer) against the default path (4x4x4-MFMA Q^T w, fixed-K SpMV)."""
     from lanczos_amd import _capi
 
     A = synthetic.laplacian_2d_5pt(300, 200)
@@ -385,7 +388,7 @@ def test_breakdown_status_through_the_c_abi(hip):
     st = h.lib.lz_run(h._h, 5, hip.dptr(v0), hip.dptr(alpha), hip.dptr(beta))
     assert st == hip.LZ_WARN_BREAKDOWN == 1
     assert b"breakdown" in h.lib.lz_last_error(h._h)
-    assert not np.isfinite(alpha).all()
+    assert not (np.isfinite(beta).all() and beta.min() > 64 * np.finfo(float).eps)  # noise-level or non-finite residual norm
     # a healthy run on the same handle reports LZ_OK again
     A = synthetic.laplacian_2d_5pt(12, 8)
     h.set_csr(96, 0, A.rowptr, A.colidx, A.vals)
