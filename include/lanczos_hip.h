@@ -168,6 +168,19 @@ int lz_set_dense_block(lz_handle h, int64_t M_global, int64_t row0, int64_t rows
  * columns sorted.  The matrix becomes the handle's operator, exactly as after lz_set_csr. */
 int lz_build_stencil3d(lz_handle h, int N, int points, double T_factor, const double* weights4, const double* potential,
                        int negate_T);
+/* The same assembly for a Nx x Ny x Nz grid and for ONE RANK'S ROW BLOCK [row0, row0 + rows_local) of it (the 8-GPU form of
+ * BASELINE config C4 assembles its 1.25e7-row slab in place; nothing to mirror in the single-process reference).
+ * Columns are renumbered into the extended local vector of halo mode: owned rows first, then the ghost entries, given
+ * as nranges <= 16 contiguous GLOBAL index ranges in the order they occupy the ghost tail (what lanczos_amd.partition
+ * plans for a stencil slab; follow with lz_set_halo).  rows_local == Nx Ny Nz: whole matrix, global columns.
+ * potential_kind 0: none; 1: `potential` = rows_local host doubles (this rank's diagonal); 2: `potential` = 8 parameters
+ * {eCore, rCore, eWell, rWell, power, Lx, Ly, Lz} of the deuteron hard core + well of 3Ddeuteron.py:51-61,
+ * eCore exp(-(r/rCore)^power) - eWell exp(-(r/rWell)^power), evaluated ON THE DEVICE at np.linspace(-L/2, L/2, N)
+ * coordinates (replaces the point-by-point host loop of Hamiltonian.py:38-43; device exp/pow differ from NumPy's in the
+ * last bits, so the bit-exact-vs-reference builder keeps kind 1). */
+int lz_build_stencil3d_block(lz_handle h, int Nx, int Ny, int Nz, int points, double T_factor, const double* weights4,
+                             int potential_kind, const double* potential, int negate_T, int64_t row0, int64_t rows_local,
+                             int nranges, const int64_t* ghost_start, const int64_t* ghost_len);
 int lz_csr_info(lz_handle h, int64_t* rows, int64_t* nnz);
 /* which SpMV kernel the current matrix + options select: 0 scalar CSR (LZ_FLAG_SPMV_SCALAR), 1 CSR-stream, 2 fixed-K
  * (stencils), 3 column-blocked two-phase (matrices without column locality, lz_spmv_pb.hip), 4 dense GEMV */

@@ -77,6 +77,8 @@ SIGNATURES = {
     "lz_set_dense": (C.c_int, [_P, C.c_int64, _D]),
     "lz_set_dense_block": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _D]),
     "lz_build_stencil3d": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _D, _D, C.c_int]),
+    "lz_build_stencil3d_block": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _D, C.c_int, _D, C.c_int, C.c_int64, C.c_int64,
+                                           C.c_int, _I64, _I64]),
     "lz_csr_info": (C.c_int, [_P, _I64, _I64]),
     "lz_spmv_plan": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_get_csr": (C.c_int, [_P, _I32, _I32, _D]),
@@ -367,6 +369,29 @@ class Handle:
             raise ValueError("potential must have N^3 entries")
         self.check(self.lib.lz_build_stencil3d(self._h, int(N), int(points), float(T_factor), dptr(w), None if pot is None else dptr(pot), int(bool(negate_T))))
         self.rows = N**3
+
+    def build_stencil3d_block(self, dims, points, T_factor, weights4, row0, rows_local, ghost_ranges=(), potential=None,
+                              potential_params=None, negate_T=False):
+        """Row block ``[row0, row0 + rows_local)`` of the periodic ``Nx x Ny x Nz`` stencil operator, assembled on the device.
+        ``ghost_ranges``: ``[(global_start, length), ...]`` in ghost-tail order (``partition.plan_stencil_slab``).
+        ``potential``: this rank's diagonal (host array) or ``potential_params`` = the 8 device-potential parameters."""
+        Nx, Ny, Nz = (int(d) for d in dims)
+        w = f64(weights4)
+        assert w.shape == (4,)
+        kind, pot = 0, None
+        if potential_params is not None:
+            kind, pot = 2, f64(potential_params)
+            assert pot.shape == (8,)
+        elif potential is not None:
+            kind, pot = 1, f64(potential).reshape(-1)
+            if pot.shape != (rows_local,):
+                raise ValueError("potential must have one entry per local row")
+        gs = np.ascontiguousarray([g[0] for g in ghost_ranges], dtype=np.int64)
+        gl = np.ascontiguousarray([g[1] for g in ghost_ranges], dtype=np.int64)
+        self.check(self.lib.lz_build_stencil3d_block(self._h, Nx, Ny, Nz, int(points), float(T_factor), dptr(w), kind,
+                                                     None if pot is None else dptr(pot), int(bool(negate_T)), int(row0), int(rows_local),
+                                                     len(gs), i64ptr(gs) if len(gs) else None, i64ptr(gl) if len(gl) else None))
+        self.rows = int(rows_local)
 
     SPMV_PLANS = ("scalar", "csr-stream", "fixed-k", "two-phase", "dense")
 

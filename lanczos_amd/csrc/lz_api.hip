@@ -666,7 +666,7 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   pb_free(A.pb);
   const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
-    LZ_HIP(h, pb_build(A, rowptr_host, &A.pb, h->stream));
+    LZ_HIP(h, pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]));
   }
   return LZ_OK;
 }
@@ -925,13 +925,49 @@ int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, 
   return finish_csr(h, rowptr, M_global, row0, rows_local, ncols_ext, nnz, fixed_k, max_nnz);
 }
 
-int lz_build_stencil3d(lz_handle h, int N, int points, double T_factor, const double* weights4, const double* potential,
-                       int negate_T) {
+int lz_build_stencil3d_block(lz_handle h, int Nx, int Ny, int Nz, int points, double T_factor, const double* weights4,
+                             int potential_kind, const double* potential, int negate_T, int64_t row0, int64_t rows_local,
+                             int nranges, const int64_t* ghost_start, const int64_t* ghost_len) {
   if (!h) return LZ_ERR_ARG;
-  if (N < 3 || (points != 7 && points != 27) || !weights4) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d: need N >= 3, points in {7, 27}, 4 weights");
-  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_build_stencil3d: single-rank only");
-  const int64_t M = (int64_t)N * N * N, nnz = M * points;
-  if (nnz >= (int64_t)1 << 31) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d: nnz exceeds int32 CSR indexing");
+  if (Nx < 3 || Ny < 3 || Nz < 3 || (points != 7 && points != 27) || !weights4)
+    return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: need Nx, Ny, Nz >= 3, points in {7, 27}, 4 weights");
+  const int64_t M = (int64_t)Nx * Ny * Nz;
+  if (row0 < 0 || rows_local <= 0 || row0 + rows_local > M) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: bad row block");
+  if (potential_kind < 0 || potential_kind > 2 || (potential_kind != 0 && !potential))
+    return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: potential_kind in {0, 1, 2}; kinds 1 and 2 need the array / the 8 parameters");
+  if (nranges < 0 || nranges > 16 || (nranges > 0 && (!ghost_start || !ghost_len)))
+    return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: at most 16 ghost ranges");
+  const bool whole = rows_local == M;
+  if (!whole && h->world == 1) return fail(h, LZ_ERR_STATE, "lz_build_stencil3d_block: a row block needs a multi-rank handle (lz_comm_init_*)");
+  const int64_t nnz = rows_local * points;
+  if (nnz >= (int64_t)1 << 31 || M >= (int64_t)1 << 31) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: sizes exceed int32 CSR indexing");
+  StencilArgs a;
+  memset(&a, 0, sizeof a);
+  a.Nx = Nx;
+  a.Ny = Ny;
+  a.Nz = Nz;
+  a.negate = negate_T;
+  a.pot_kind = potential_kind;
+  a.renumber = whole ? 0 : 1;
+  a.nranges = nranges;
+  a.row0 = row0;
+  a.rows_local = rows_local;
+  a.tf = T_factor;
+  for (int q = 0; q < 4; ++q) a.w[q] = weights4[q];
+  if (potential_kind == 2)
+    for (int q = 0; q < 8; ++q) a.par[q] = potential[q];
+  const int64_t rows_pad = round_up(rows_local, kPadDoubles);
+  int64_t ext = rows_pad, nghost = 0;
+  for (int q = 0; q < nranges; ++q) {
+    if (ghost_len[q] <= 0 || ghost_start[q] < 0 || ghost_start[q] + ghost_len[q] > M ||
+        (ghost_start[q] < row0 + rows_local && ghost_start[q] + ghost_len[q] > row0))
+      return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: ghost range outside the grid or overlapping the owned rows");
+    a.gstart[q] = ghost_start[q];
+    a.glen[q] = ghost_len[q];
+    a.gext[q] = ext;
+    ext += ghost_len[q];
+    nghost += ghost_len[q];
+  }
   LZ_HIP(h, hipSetDevice(h->dev));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
   h->kind = 0;
@@ -939,25 +975,36 @@ int lz_build_stencil3d(lz_handle h, int N, int points, double T_factor, const do
   LZ_TRY(dev_free(h, h->d_V));
   h->n = 0;
   CsrDev& A = h->csr;
-  LZ_TRY(dev_alloc(h, A.rowptr, (size_t)M + 1));
+  pb_free(A.pb);
+  LZ_TRY(dev_alloc(h, A.rowptr, (size_t)rows_local + 1));
   LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
   LZ_TRY(dev_alloc(h, A.vals, (size_t)nnz + 2));
   LZ_HIP(h, hipMemsetAsync(A.colidx + nnz, 0, 2 * sizeof(int32_t), h->stream));
   LZ_HIP(h, hipMemsetAsync(A.vals + nnz, 0, 2 * sizeof(double), h->stream));
   double* dpot = nullptr;
-  if (potential) {
-    LZ_TRY(dev_alloc(h, dpot, (size_t)M));
-    LZ_HIP(h, hipMemcpyAsync(dpot, potential, (size_t)M * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (potential_kind == 1) {
+    LZ_TRY(dev_alloc(h, dpot, (size_t)rows_local));
+    LZ_HIP(h, hipMemcpyAsync(dpot, potential, (size_t)rows_local * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
-  launch_build_stencil3d(N, points, T_factor, weights4, negate_T, dpot, A.rowptr, A.colidx, A.vals, h->stream);
+  launch_build_stencil3d(a, points, dpot, A.rowptr, A.colidx, A.vals, h->stream);
   int rc = check_launch(h, "build_stencil3d");
   hipError_t e = hipStreamSynchronize(h->stream);
   if (dpot) hipFree(dpot);
   if (rc != LZ_OK) return rc;
-  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_build_stencil3d: ") + hipGetErrorString(e));
-  std::vector<int32_t> rowptr((size_t)M + 1);
-  for (int64_t i = 0; i <= M; ++i) rowptr[(size_t)i] = (int32_t)(i * points);
-  return finish_csr(h, rowptr.data(), M, 0, M, M, nnz, points, points);
+  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_build_stencil3d_block: ") + hipGetErrorString(e));
+  std::vector<int32_t> rowptr((size_t)rows_local + 1);
+  for (int64_t i = 0; i <= rows_local; ++i) rowptr[(size_t)i] = (int32_t)(i * points);
+  A.far_frac = 0.0;
+  return finish_csr(h, rowptr.data(), M, row0, rows_local, whole ? M : rows_pad + nghost, nnz, points, points);
+}
+
+int lz_build_stencil3d(lz_handle h, int N, int points, double T_factor, const double* weights4, const double* potential,
+                       int negate_T) {
+  if (!h) return LZ_ERR_ARG;
+  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_build_stencil3d: whole matrix on one rank; use lz_build_stencil3d_block for a row partition");
+  if (N < 3) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d: need N >= 3, points in {7, 27}, 4 weights");
+  return lz_build_stencil3d_block(h, N, N, N, points, T_factor, weights4, potential ? 1 : 0, potential, negate_T, 0, (int64_t)N * N * N, 0,
+                                  nullptr, nullptr);
 }
 
 int lz_csr_info(lz_handle h, int64_t* rows, int64_t* nnz) {

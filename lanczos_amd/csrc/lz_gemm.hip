@@ -218,6 +218,124 @@ __global__ __launch_bounds__(kTPB) void k_gemm_tn_persist(const double* __restri
   }
 }
 
+// Ritz back-transform, default kernel: persistent waves, TWO per SIMD, S staged through LDS.
+// What the two earlier kernels taught (profiles/r02/ritz_gemm_ab.json): k_gemm_tn and its persistent-wave variant both sit at
+// MfmaUtil 65 % - so wave turnover was not the gap; what they share is ONE wave per SIMD (a 32-row x n tile needs ~330
+// registers), and a lone wave cannot keep the f64 matrix pipe issuing back to back.  Halving the tile to 16 rows (104
+// accumulator registers) lets two waves share a SIMD, but doubles the S traffic per MFMA - one 512-byte L1/L2 read per
+// MFMA is the vector-memory pipe's whole budget - so S is staged through LDS instead: the 512 threads of a block copy S
+// in panels of 16 k-rows (4 MFMA k-steps) into a double buffer, one barrier per panel, and every wave reads its B
+// operands with ds_read_b64 (a quarter of the LDS bandwidth).  The only per-wave global traffic left in the loop is the
+// V stream itself: one 8-byte non-temporal load per lane per k-step, four steps ahead.
+// Every wave of a block runs the same number of tiles (surplus tiles are clamped and not stored): the barriers match.
+template <int NT>
+__global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
+                                                    const double* __restrict__ B, int ldb, int ncols, double* __restrict__ C,
+                                                    int64_t ldc) {
+  constexpr int KP = 4;       // k-steps per panel = turns of the A ring
+  constexpr int NTHR = 512;
+  extern __shared__ double sB[];  // 2 panels of 16 rows x ldb doubles
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int64_t ntiles = (mdim + 15) / 16;
+  const int64_t nwaves = (int64_t)gridDim.x * (NTHR / 64);
+  const int64_t wave = (int64_t)blockIdx.x * (NTHR / 64) + w;
+  const int64_t rounds = (ntiles + nwaves - 1) / nwaves;
+  const int npanels = ((kcount + 3) / 4 + KP - 1) / KP;  // 16 * npanels == ldb rows of the zero-padded S
+  const int panel_d2 = 16 * ldb / 2;                     // double2 elements per panel
+  constexpr int PF = 4;                                  // double2 loads per thread per panel (ldb <= 256: 16 * 256 / 2 / 512 = 4)
+  const int CT = (ncols + 15) / 16;
+  int colb[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) colb[b] = 16 * (b < CT ? b : CT - 1) + lr;
+  const double2* B2 = reinterpret_cast<const double2*>(B);
+  double2* s2 = reinterpret_cast<double2*>(sB);
+  // panel 0 -> buffer 0
+  for (int i = threadIdx.x; i < panel_d2; i += NTHR) s2[i] = B2[i];
+  // A cursor: (round, step) of the next load
+  int64_t pr = 0;
+  int ps = 0;
+  auto issue_a = [&](double& x0) {
+    int64_t t = wave + pr * nwaves;
+    t = t < ntiles ? t : ntiles - 1;
+    int64_t m = t * 16 + lr;
+    m = m < mdim ? m : mdim - 1;
+    int kr = 4 * ps + lk;
+    kr = kr < kcount ? kr : kcount - 1;  // padding steps: finite values, multiplied by the zero rows of S
+    x0 = __builtin_nontemporal_load(A + (int64_t)kr * lda + m);
+    if (++ps == KP * npanels) {
+      ps = 0;
+      ++pr;
+    }
+  };
+  double ra[KP];
+#pragma unroll
+  for (int p = 0; p < KP; ++p) issue_a(ra[p]);
+  int buf = 0;
+  for (int64_t rd = 0; rd < rounds; ++rd) {
+    double4_t acc[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int pn = 0; pn < npanels; ++pn) {
+      __syncthreads();  // panel `pn` is complete in buffer `buf`; nobody reads buffer buf^1 any more
+      // prefetch the next panel of S (wrapping to panel 0 for the next tile) into registers
+      const int nxt = pn + 1 < npanels ? pn + 1 : 0;
+      double2 pf[PF];
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int i = threadIdx.x + q * NTHR;
+        pf[q] = i < panel_d2 ? B2[(int64_t)nxt * panel_d2 + i] : make_double2(0.0, 0.0);
+      }
+      const double* sb = sB + (size_t)buf * 16 * ldb;
+#pragma unroll
+      for (int p = 0; p < KP; ++p) {
+        const double a0 = ra[p];
+        issue_a(ra[p]);
+        const double* srow = sb + (4 * p + lk) * ldb;
+        double bv[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bv[b] = srow[colb[b]];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv[b], acc[b], 0, 0, 0);
+      }
+      double2* dst = s2 + (size_t)(buf ^ 1) * panel_d2;
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int i = threadIdx.x + q * NTHR;
+        if (i < panel_d2) dst[i] = pf[q];
+      }
+      buf ^= 1;
+    }
+    const int64_t tile = wave + rd * nwaves;
+    if (tile < ntiles) {  // wave-uniform
+      const int64_t m0 = tile * 16;
+      if (m0 + 16 <= mdim) {
+        double* cbase = C + (m0 + lk) * ldc + lr;
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          const bool colok = b + 1 < CT || 16 * b + lr < ncols;
+          if (b < CT && colok) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cbase[(int64_t)(4 * g) * ldc + 16 * b] = acc[b][g];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          if (b >= CT) continue;
+          const int col = 16 * b + lr;
+          if (col >= ncols) continue;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int64_t m = m0 + lk + 4 * g;
+            if (m < mdim) C[m * ldc + col] = acc[b][g];
+          }
+        }
+      }
+    }
+  }
+}
+
 static void launch_gemm_tn(const double* A, int64_t lda, int64_t mdim, int64_t kcount, int64_t kchunk, int nz, const double* B,
                            int64_t ldb, int ncols, double* C, int64_t ldc, int64_t zstride, hipStream_t s) {
   const int CT = (ncols + 15) / 16;
@@ -242,6 +360,20 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
   const int64_t ntiles = (rows + 31) / 32;
   if (variant == 1 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) {  // A/B arm, > 256 columns, or too few tiles to loop over
     launch_gemm_tn(V, ldv, rows, n, n, 1, Spad, npad, n, Y, ldy, 0, s);
+    return;
+  }
+  if (variant != 2) {  // default: two waves per SIMD, S through LDS
+    const size_t lds = (size_t)2 * 16 * npad * sizeof(double);
+#define LZ_TNL(nt)                                                                                                            \
+  case nt:                                                                                                                    \
+    hipLaunchKernelGGL((k_gemm_tn_lds<nt>), dim3(kNumCU), dim3(512), lds, s, V, ldv, rows, n, Spad, npad, n, Y, ldy);         \
+    break;
+    switch (CT) {
+      LZ_TNL(1) LZ_TNL(2) LZ_TNL(3) LZ_TNL(4) LZ_TNL(5) LZ_TNL(6) LZ_TNL(7) LZ_TNL(8)
+      LZ_TNL(9) LZ_TNL(10) LZ_TNL(11) LZ_TNL(12) LZ_TNL(13) LZ_TNL(14) LZ_TNL(15) LZ_TNL(16)
+      default: break;
+    }
+#undef LZ_TNL
     return;
   }
   const dim3 grid(kNumCU), block(kTPB);

@@ -39,7 +39,7 @@ struct CsrDev {
 };
 
 // ---- column-blocked two-phase SpMV (lz_spmv_pb.hip): gathers out of LDS only; y bit-identical to the CSR-stream kernel
-hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s);  // *out == nullptr: not applicable
+hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob = 0);  // *out == nullptr: not applicable
 void pb_free(PbDev*& pb);
 int pb_num_partials(const PbDev* pb);
 int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s);
@@ -48,8 +48,14 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
 // y = A x (rows), part[b] = sum_{rows of block b} x_own[i] * y[i]; returns number of partials written
 int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
                     hipStream_t s);
-void launch_build_stencil3d(int N, int points, double tf, const double* w, int negate, const double* pot, int32_t* rowptr,
-                            int32_t* colidx, double* vals, hipStream_t s);
+struct StencilArgs {  // by-value kernel argument of the stencil assembly
+  int Nx, Ny, Nz, negate, pot_kind, renumber, nranges;
+  int64_t row0, rows_local;
+  double tf, w[4], par[8];
+  int64_t gstart[16], glen[16], gext[16];  // ghost ranges: global start, length, first extended-local index
+};
+void launch_build_stencil3d(const StencilArgs& a, int points, const double* pot, int32_t* rowptr, int32_t* colidx, double* vals,
+                            hipStream_t s);
 int launch_gemv_dense(const double* A, int64_t M, int64_t cols, int64_t lda, const double* x, const double* x_own, double* y,
                       double* part, hipStream_t s);
 
@@ -102,7 +108,8 @@ void launch_bi_two_term(int sub, int dots, double* r, double* sv, const double* 
 int bi_partials_needed();
 
 // Y(rows x n, row-major, ldy) = sum_k V[k][m] * S[k][i]   (FP64 MFMA)
-// variant 0: persistent waves (one workgroup per CU walks the row tiles); 1: one workgroup per 128 rows (A/B arm)
+// variant 0: persistent waves, two per SIMD, S staged through LDS (default); 1: one workgroup per 128 rows, one wave per
+// SIMD (round-1 kernel, also used for small problems); 2: persistent waves, one per SIMD, S from L2 (A/B arms)
 void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
                       int64_t ldy, hipStream_t s, int variant = 0);
 // G = Y^T Y as K-chunk partials (n x n each); returns the number of chunks (<= nz_max)

@@ -323,26 +323,29 @@ int launch_gemv_dense(const double* A, int64_t M, int64_t cols, int64_t lda, con
 }
 
 // ------------------------------------------------------------------ stencil Hamiltonian assembly on the device
-// CSR of  sign * T_factor * Laplacian (+ diagonal potential)  on the reference's periodic N^3 grid
-// (Python/Regular/Hamiltonian.py:73-128): flat index x + y N + z N^2, neighbours wrap, 7-point weights
-// (-6, 1) or 27-point weights (centre, face, edge, corner) passed in `w` exactly as the host computed them.
-// One lane builds one row: P (column, value) pairs, insertion-sorted by column like SciPy's sort_indices.
+// CSR of  sign * T_factor * Laplacian (+ diagonal potential)  on the reference's periodic grid
+// (Python/Regular/Hamiltonian.py:73-128, there N^3; here Nx x Ny x Nz): flat index x + y Nx + z Nx Ny, neighbours wrap,
+// 7-point weights (-6, 1) or 27-point weights (centre, face, edge, corner) passed in `w` exactly as the host computed them.
+// One lane builds one row of the block [row0, row0 + rows_local): P (column, value) pairs, insertion-sorted by GLOBAL
+// column like SciPy's sort_indices, then the columns are renumbered for a row-partitioned run (owned: col - row0; remote:
+// position in the ghost tail, given as up to 16 contiguous global ranges - what a slab of a stencil needs).
 // Values follow SciPy's arithmetic of `-T + V`: t = T_factor * w; entry = sign * t (+ potential on the diagonal).
+// Potential: none, a per-row array, or the deuteron hard-core + well of 3Ddeuteron.py:51-61 evaluated here on
+// np.linspace(-L/2, L/2, N) coordinates (device exp/pow: last-bit differences from NumPy, hence opt-in).
 template <int P>
-__global__ __launch_bounds__(kTPB) void k_build_stencil3d(int N, double tf, double w0, double w1, double w2, double w3,
-                                                         int negate, const double* __restrict__ pot,
-                                                         int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx,
-                                                         double* __restrict__ vals) {
-  const int64_t M = (int64_t)N * N * N;
-  const int64_t row = (int64_t)blockIdx.x * kTPB + threadIdx.x;
-  if (row > M) return;
-  if (row == M) {
-    rowptr[M] = (int32_t)(M * P);
+__global__ __launch_bounds__(kTPB) void k_build_stencil3d(StencilArgs a, const double* __restrict__ pot, int32_t* __restrict__ rowptr,
+                                                         int32_t* __restrict__ colidx, double* __restrict__ vals) {
+  const int64_t lrow = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  if (lrow > a.rows_local) return;
+  if (lrow == a.rows_local) {
+    rowptr[lrow] = (int32_t)(lrow * P);
     return;
   }
-  rowptr[row] = (int32_t)(row * P);
-  const int x = (int)(row % N), y = (int)((row / N) % N), z = (int)(row / ((int64_t)N * N));
-  int32_t c[P];
+  rowptr[lrow] = (int32_t)(lrow * P);
+  const int64_t row = a.row0 + lrow;
+  const int Nx = a.Nx, Ny = a.Ny, Nz = a.Nz;
+  const int x = (int)(row % Nx), y = (int)((row / Nx) % Ny), z = (int)(row / ((int64_t)Nx * Ny));
+  int64_t c[P];
   double v[P];
   int cnt = 0;
   for (int dz = -1; dz <= 1; ++dz)
@@ -350,13 +353,21 @@ __global__ __launch_bounds__(kTPB) void k_build_stencil3d(int N, double tf, doub
       for (int dx = -1; dx <= 1; ++dx) {
         const int nz = (dx != 0) + (dy != 0) + (dz != 0);
         if (P == 7 && nz > 1) continue;
-        const int xx = (x + dx + N) % N, yy = (y + dy + N) % N, zz = (z + dz + N) % N;
-        const int32_t col = (int32_t)(xx + (int64_t)yy * N + (int64_t)zz * N * N);
-        const double w = nz == 0 ? w0 : (nz == 1 ? w1 : (nz == 2 ? w2 : w3));
-        double t = tf * w;
-        if (negate) t = -t;
-        if (nz == 0 && pot) t = t + pot[row];
-        // insertion sort by column (P <= 27)
+        const int xx = (x + dx + Nx) % Nx, yy = (y + dy + Ny) % Ny, zz = (z + dz + Nz) % Nz;
+        const int64_t col = xx + (int64_t)yy * Nx + (int64_t)zz * Nx * Ny;
+        const double w = nz == 0 ? a.w[0] : (nz == 1 ? a.w[1] : (nz == 2 ? a.w[2] : a.w[3]));
+        double t = a.tf * w;
+        if (a.negate) t = -t;
+        if (nz == 0) {
+          if (a.pot_kind == 1) t = t + pot[lrow];
+          if (a.pot_kind == 2) {
+            const double px = -a.par[5] / 2 + x * (a.par[5] / (Nx - 1)), py = -a.par[6] / 2 + y * (a.par[6] / (Ny - 1)),
+                         pz = -a.par[7] / 2 + z * (a.par[7] / (Nz - 1));
+            const double r = sqrt(px * px + py * py + pz * pz);
+            t = t + (a.par[0] * exp(-pow(r / a.par[1], a.par[4])) - a.par[2] * exp(-pow(r / a.par[3], a.par[4])));
+          }
+        }
+        // insertion sort by global column (P <= 27)
         int k = cnt++;
         while (k > 0 && c[k - 1] > col) {
           c[k] = c[k - 1];
@@ -368,19 +379,29 @@ __global__ __launch_bounds__(kTPB) void k_build_stencil3d(int N, double tf, doub
       }
 #pragma unroll 1
   for (int k = 0; k < P; ++k) {
-    colidx[row * P + k] = c[k];
-    vals[row * P + k] = v[k];
+    int64_t col = c[k];
+    if (a.renumber) {
+      if (col >= a.row0 && col < a.row0 + a.rows_local) {
+        col -= a.row0;
+      } else {
+        int64_t ext = 0;  // every remote column of a well-formed plan lies in exactly one range
+        for (int q = 0; q < a.nranges; ++q)
+          if (col >= a.gstart[q] && col < a.gstart[q] + a.glen[q]) ext = a.gext[q] + (col - a.gstart[q]);
+        col = ext;
+      }
+    }
+    colidx[lrow * P + k] = (int32_t)col;
+    vals[lrow * P + k] = v[k];
   }
 }
 
-void launch_build_stencil3d(int N, int points, double tf, const double* w, int negate, const double* pot, int32_t* rowptr,
-                            int32_t* colidx, double* vals, hipStream_t s) {
-  const int64_t M = (int64_t)N * N * N;
-  const unsigned grid = (unsigned)((M + 1 + kTPB - 1) / kTPB);
+void launch_build_stencil3d(const StencilArgs& a, int points, const double* pot, int32_t* rowptr, int32_t* colidx, double* vals,
+                            hipStream_t s) {
+  const unsigned grid = (unsigned)((a.rows_local + 1 + kTPB - 1) / kTPB);
   if (points == 7)
-    hipLaunchKernelGGL(k_build_stencil3d<7>, dim3(grid), dim3(kTPB), 0, s, N, tf, w[0], w[1], w[2], w[3], negate, pot, rowptr, colidx, vals);
+    hipLaunchKernelGGL(k_build_stencil3d<7>, dim3(grid), dim3(kTPB), 0, s, a, pot, rowptr, colidx, vals);
   else
-    hipLaunchKernelGGL(k_build_stencil3d<27>, dim3(grid), dim3(kTPB), 0, s, N, tf, w[0], w[1], w[2], w[3], negate, pot, rowptr, colidx, vals);
+    hipLaunchKernelGGL(k_build_stencil3d<27>, dim3(grid), dim3(kTPB), 0, s, a, pot, rowptr, colidx, vals);
 }
 
 }  // namespace lz

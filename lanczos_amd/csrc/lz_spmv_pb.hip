@@ -30,13 +30,14 @@
 namespace lz {
 
 constexpr int kPbThreads = 1024;
-constexpr int kPbCap = 16384;      // products per row block: 128 KiB of LDS in phase 2
+constexpr int kPbCapMax = 16384;   // products per row block and LDS tile of phase 2 (128 KiB); default 8192: two workgroups per CU
 constexpr int kPbMaxRows = 8192;   // rows per row block
 constexpr int kPbMaxW = 19968;     // doubles of v per column block: 156 KiB of LDS in phase 1
 
 struct PbDev {
   int nCB = 0, nRB = 0;
   int W = 0;
+  int cap = 0;                 // products per row block
   int64_t nnz = 0;
   int32_t* rbptr = nullptr;    // nRB + 1 row-block boundaries
   int32_t* cbptr = nullptr;    // nCB + 1: T range of each column block
@@ -46,7 +47,8 @@ struct PbDev {
   uint16_t* pcol = nullptr;    // nnz (T order): column - cb * W
   double* pvals = nullptr;     // nnz (T order)
   double* T = nullptr;         // nnz products
-  bool wide_runs = false;      // tiles average more than 20 products: 32 lanes copy a tile (else 16)
+  bool wide_runs = false;      // tiles average more than 20 products: 16 lanes x 3 slots copy a tile (else 8 x 3)
+  size_t lds2 = 0;             // dynamic LDS of phase 2: the product tile + this row block's tile table
 };
 
 namespace {
@@ -156,61 +158,86 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
 }
 
 // ---- phase 2: row sums out of LDS in CSR order, alpha partial per row block
-template <int GS>  // lanes that copy one tile together
+// The workgroup's life is two memory round trips and no more (it is latency-, not bandwidth-critical: 16 K products per
+// workgroup): (1) the tile table of this row block -> LDS, each thread's row bounds; (2) ALL product runs (GS lanes per
+// tile, every tile's first load issued before the first LDS store) and the row's first 8 perm entries; then one barrier
+// and the sums out of LDS.  Two workgroups per CU (cap = 8192 products = 64 KiB) overlap each other's round trips.
+template <int GS, int TPG>  // lanes that copy one tile together; tiles per lane group and trip
 __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restrict__ rbptr, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ toff, const uint16_t* __restrict__ lstart,
-                                                       const uint16_t* __restrict__ perm, const double* __restrict__ T, int nCB,
+                                                       const uint16_t* __restrict__ perm, const double* __restrict__ T, int nCB, int cap,
                                                        const double* __restrict__ xown, double* __restrict__ y,
                                                        double* __restrict__ part) {
-  extern __shared__ double seg[];
+  extern __shared__ double seg[];  // cap products, then the tile table
   __shared__ double red[kPbThreads / 64];
+  int* to_s = reinterpret_cast<int*>(seg + cap);
+  uint16_t* ls_s = reinterpret_cast<uint16_t*>(to_s + nCB);
   const int rb = blockIdx.x;
-  const int32_t* to = toff + (int64_t)rb * nCB;
-  const uint16_t* ls = lstart + (int64_t)rb * (nCB + 1);
-  constexpr int NG = kPbThreads / GS;
-  const int g = threadIdx.x / GS, l = threadIdx.x % GS;
-  // four tiles per trip: all their first loads are issued before the first LDS store
-  for (int cb0 = g; cb0 < nCB; cb0 += 4 * NG) {
-    int off[4], a[4], len[4];
-    double v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cb = cb0 + q * NG;
-      const bool ok = cb < nCB;
-      off[q] = ok ? to[cb] : 0;
-      a[q] = ok ? ls[cb] : 0;
-      len[q] = ok ? ls[cb + 1] - a[q] : 0;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = l < len[q] ? __builtin_nontemporal_load(T + off[q] + l) : 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (l < len[q]) seg[a[q] + l] = v[q];
-      for (int t = l + GS; t < len[q]; t += GS) seg[a[q] + t] = __builtin_nontemporal_load(T + off[q] + t);
-    }
+  {
+    const int32_t* to = toff + (int64_t)rb * nCB;
+    const uint16_t* ls = lstart + (int64_t)rb * (nCB + 1);
+    for (int c = threadIdx.x; c < nCB; c += kPbThreads) to_s[c] = __builtin_nontemporal_load(to + c);
+    for (int c = threadIdx.x; c <= nCB; c += kPbThreads) ls_s[c] = __builtin_nontemporal_load(ls + c);
+  }
+  const int r0 = rbptr[rb], r1 = rbptr[rb + 1];
+  // this thread's first row (row blocks hold <= kPbMaxRows rows: the others are handled after the barrier)
+  const int row = r0 + threadIdx.x;
+  int ka = 0, kb = 0;
+  if (row < r1) {
+    ka = rowptr[row];
+    kb = rowptr[row + 1];
   }
   __syncthreads();
-  const int r0 = rbptr[rb], r1 = rbptr[rb + 1];
-  const int k0 = rowptr[r0];
-  double d = 0.0;
-  for (int row = r0 + threadIdx.x; row < r1; row += kPbThreads) {
-    const int ka = rowptr[row], kb = rowptr[row + 1];
-    const uint16_t* pp = perm + ka;
-    double sum = 0.0;
-    int k = 0;
-    const int n = kb - ka;
-    for (; k + 4 <= n; k += 4) {  // four LDS reads in flight; the adds stay in CSR order
-      const double p0 = seg[pp[k]], p1 = seg[pp[k + 1]], p2 = seg[pp[k + 2]], p3 = seg[pp[k + 3]];
-      sum += p0;
-      sum += p1;
-      sum += p2;
-      sum += p3;
+  // Tile lengths scatter around their mean (Poisson): every lane takes THREE slots of a tile (t = l, l + GS, l + 2 GS),
+  // all loads of a trip issued before the first LDS store - a tile longer than 3 GS (1e-4 of them) takes the slow loop.
+  constexpr int NG = kPbThreads / GS, S = 3;
+  const int g = threadIdx.x / GS, l = threadIdx.x % GS;
+  for (int cb0 = g; cb0 < nCB; cb0 += TPG * NG) {
+    int off[TPG], a[TPG], len[TPG];
+    double v[TPG][S];
+#pragma unroll
+    for (int q = 0; q < TPG; ++q) {
+      const int cb = cb0 + q * NG;
+      const bool ok = cb < nCB;
+      off[q] = ok ? to_s[cb] : 0;
+      a[q] = ok ? ls_s[cb] : 0;
+      len[q] = ok ? ls_s[cb + 1] - a[q] : 0;
     }
-    for (; k < n; ++k) sum += seg[pp[k]];
-    y[row] = sum;
-    d += xown[row] * sum;
+#pragma unroll
+    for (int q = 0; q < TPG; ++q)
+#pragma unroll
+      for (int u = 0; u < S; ++u) v[q][u] = l + u * GS < len[q] ? __builtin_nontemporal_load(T + off[q] + l + u * GS) : 0.0;
+#pragma unroll
+    for (int q = 0; q < TPG; ++q) {
+#pragma unroll
+      for (int u = 0; u < S; ++u)
+        if (l + u * GS < len[q]) seg[a[q] + l + u * GS] = v[q][u];
+      for (int t = l + S * GS; t < len[q]; t += GS) seg[a[q] + t] = __builtin_nontemporal_load(T + off[q] + t);
+    }
   }
-  (void)k0;
+  // the row's first perm entries travel with the product loads (same round trip)
+  uint16_t pf[8];
+  const int n0 = kb - ka;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pf[k] = k < n0 ? __builtin_nontemporal_load(perm + ka + k) : (uint16_t)0;
+  __syncthreads();
+  double d = 0.0;
+  if (row < r1) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < n0) sum += seg[pf[k]];  // CSR order, one rounding per add
+    for (int k = 8; k < n0; ++k) sum += seg[perm[ka + k]];
+    y[row] = sum;
+    d = xown[row] * sum;
+  }
+  for (int rw = row + kPbThreads; rw < r1; rw += kPbThreads) {  // row blocks of more than 1024 (short) rows
+    const int a2 = rowptr[rw], b2 = rowptr[rw + 1];
+    double sum = 0.0;
+    for (int k = a2; k < b2; ++k) sum += seg[perm[k]];
+    y[rw] = sum;
+    d += xown[rw] * sum;
+  }
   d = wave_sum(d);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
   __syncthreads();
@@ -248,9 +275,12 @@ void pb_free(PbDev*& pb) {
 
 // Build the two-phase layout for the device CSR matrix A.  Returns hipSuccess with *out == nullptr when the matrix does
 // not qualify (a single row longer than the LDS tile, or too few columns to be worth blocking).
-hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s) {
+hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob) {
   *out = nullptr;
-  if (A.rows <= 0 || A.nnz <= 0 || A.max_row_nnz > kPbCap) return hipSuccess;
+  // products per row block: 8192 by default; rows longer than that (up to 16384 entries) get the larger tile
+  int cap = cap_knob > 0 ? std::min(std::max(cap_knob, 1024), kPbCapMax) : 8192;
+  if (A.max_row_nnz > cap) cap = kPbCapMax;
+  if (A.rows <= 0 || A.nnz <= 0 || A.max_row_nnz > cap) return hipSuccess;
   // Column blocks: as few as the LDS allows (a tile run is ~kPbCap / nCB products: fewer blocks, longer runs), and a
   // multiple of 256 workgroups where that matters for balance.
   int64_t W = round_up((A.ncols + 511) / 512, kPadDoubles);
@@ -263,8 +293,8 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   for (int64_t r = 0; r < A.rows;) {
     int64_t e = r;
     const int64_t k0 = rowptr_host[r];
-    while (e < A.rows && e - r < kPbMaxRows && (int64_t)rowptr_host[e + 1] - k0 <= kPbCap) ++e;
-    rb.push_back((int32_t)e);  // e > r: no row is longer than kPbCap
+    while (e < A.rows && e - r < kPbMaxRows && (int64_t)rowptr_host[e + 1] - k0 <= cap) ++e;
+    rb.push_back((int32_t)e);  // e > r: no row is longer than cap
     r = e;
   }
   const int nRB = (int)rb.size() - 1;
@@ -272,6 +302,7 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   pb->nCB = nCB;
   pb->nRB = nRB;
   pb->W = (int)W;
+  pb->cap = cap;
   pb->nnz = A.nnz;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t x) {
@@ -311,14 +342,15 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   }
   hipFree(tot);
   pb->wide_runs = (double)pb->nnz / ((double)nRB * (double)nCB) > 20.0;
+  pb->lds2 = (size_t)cap * sizeof(double) + (size_t)nCB * sizeof(int) + ((size_t)nCB + 2) * sizeof(uint16_t);
   // both phases may need more than the default 64 KiB of dynamic LDS: allowed once per kernel, here, so that the
   // launches themselves have no failure mode
+  if (e == hipSuccess && pb->lds2 > 160 * 1024) e = hipErrorInvalidValue;  // only with thousands of column blocks AND the large tile
   if (e == hipSuccess && W * sizeof(double) > 65536)
     chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_products<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W * sizeof(double))));
-  if (e == hipSuccess) {
-    const int lds2 = kPbCap * (int)sizeof(double);
-    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
-    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2));
+  if (e == hipSuccess && pb->lds2 > 65536) {
+    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pb->lds2));
+    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pb->lds2));
   }
   if (e != hipSuccess) {
     pb_free(pb);
@@ -334,14 +366,13 @@ int pb_num_partials(const PbDev* pb) { return pb->nRB; }
 // Returns the number of partials.
 int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s) {
   const size_t lds1 = (size_t)pb->W * sizeof(double);
-  const size_t lds2 = (size_t)kPbCap * sizeof(double);
   hipLaunchKernelGGL(k_pb_products<8>, dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, x, A.ncols, pb->W, pb->T);
   if (pb->wide_runs)
-    hipLaunchKernelGGL(k_pb_rows<32>, dim3(pb->nRB), dim3(kPbThreads), lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T,
-                       pb->nCB, x_own, y, part);
+    hipLaunchKernelGGL((k_pb_rows<16, 4>), dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm,
+                       pb->T, pb->nCB, pb->cap, x_own, y, part);
   else
-    hipLaunchKernelGGL(k_pb_rows<16>, dim3(pb->nRB), dim3(kPbThreads), lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T,
-                       pb->nCB, x_own, y, part);
+    hipLaunchKernelGGL((k_pb_rows<8, 4>), dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm,
+                       pb->T, pb->nCB, pb->cap, x_own, y, part);
   return pb->nRB;
 }
 

@@ -363,6 +363,45 @@ class DistributedLanczos:
             self.h.set_allgather(self.plan.chunk)
         self.executed = False
 
+    @classmethod
+    def from_stencil(cls, dims, points, boot=None, device_id=0, backend="rccl", options=0, fused_norm=True, one_reduce=False,
+                     tuning=None, T_factor=1.0, weights4=(-6.0, 1.0, 0.0, 0.0), negate_T=True, potential_params=None):
+        """This rank's slab of the periodic ``Nx x Ny x Nz`` 7-/27-point stencil operator assembled DIRECTLY ON THE DEVICE
+        (no host matrix at any size: BASELINE config C4's 1e8-row Laplacian is 8.4 GB of CSR): the halo plan comes from
+        the slab's boundary rows alone (``partition.plan_stencil_slab``), the kernel renumbers the columns itself.
+        Defaults give ``synthetic.laplacian_3d_7pt`` (6 on the diagonal, -1 on the six neighbours), bit for bit."""
+        self = cls.__new__(cls)
+        self.boot = boot or Bootstrap()
+        Nx, Ny, Nz = (int(d) for d in dims)
+        self.M = Nx * Ny * Nz
+        self.rank, self.world = self.boot.rank, self.boot.world
+        bounds = partition.row_bounds(self.M, self.world)
+        self.lo, self.hi = bounds[self.rank], bounds[self.rank + 1]
+        self.dense = False
+        self._tuning = dict(tuning or {})
+        self.plan, ranges = partition.plan_stencil_slab(dims, points, self.world, self.rank)
+        if self.plan.mode == "halo":
+            gathered = self.boot.allgather_obj((self.plan.peers, self.plan.send_counts, self.plan.recv_counts))
+            partition.check_plans(self.plan, self.rank, gathered)
+        if one_reduce:
+            options |= _capi.FLAG_ONE_REDUCE
+            fused_norm = True
+        if fused_norm:
+            options |= _capi.FLAG_FUSED_NORM
+        self.options = options
+        self.h = _capi.Handle(device_id)
+        self.h.set_options(options)
+        for k, v in self._tuning.items():
+            self.h.set_tuning(k, v)
+        self.backend = backend
+        self._init_comm(backend)
+        self.h.build_stencil3d_block(dims, points, T_factor, weights4, self.lo, self.hi - self.lo, ranges,
+                                     potential_params=potential_params, negate_T=negate_T)
+        if self.plan.mode == "halo":
+            self.h.set_halo(self.plan.peers, self.plan.send_counts, self.plan.send_idx, self.plan.recv_counts)
+        self.executed = False
+        return self
+
     def _init_dense(self, block, device_id, backend, options, fused_norm):
         """Dense row block: columns keep their global index (every rank starts at rank * chunk, so the all-gathered
         padded vector is the global numbering followed by zero padding up to world * chunk)."""

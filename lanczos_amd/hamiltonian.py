@@ -24,6 +24,9 @@ class Hamiltonian:
     verbose = True
     device_id = 0
     vectorize_potential = False  # see potential_on_grid
+    device_potential = False     # build_H: evaluate a potential that exposes ``device_params(L)`` (synthetic.DeuteronPotential)
+                                 # inside the assembly kernel - no N^3 host array at all; last-bit differences from NumPy's
+                                 # exp/pow, so the default stays the host evaluation that reproduces the reference bit for bit
 
     def __init__(self, N, L, potential, T_factor):
         self.N = N
@@ -83,11 +86,16 @@ class Hamiltonian:
             return np.array([-6.0, 1.0, 0.0, 0.0])
         return np.array([-44 / 3, 1.0, 1.0 / 2, 1.0 / 3]) * 3.0 / 13  # centre, face, edge, corner (Hamiltonian.py:117-127)
 
-    def _device_csr(self, points, potential, negate):
+    def _device_csr(self, points, potential, negate, potential_params=None):
         if self._handle is None:
             self._handle = _capi.Handle(self.device_id)
         h = self._handle
-        h.build_stencil3d(self.N, int(points), self.T_factor, self._weights4(points), potential, negate)
+        if potential_params is not None:
+            N = self.N
+            h.build_stencil3d_block((N, N, N), int(points), self.T_factor, self._weights4(points), 0, N**3, (),
+                                    potential_params=potential_params, negate_T=negate)
+        else:
+            h.build_stencil3d(self.N, int(points), self.T_factor, self._weights4(points), potential, negate)
         rowptr, colidx, vals = h.get_csr()
         M = self.N**3
         return scipy.sparse.csr_matrix((vals, colidx, rowptr), shape=(M, M))
@@ -108,6 +116,8 @@ class Hamiltonian:
     def build_H(self, points="27"):
         """``H = -T + V`` with sorted indices (3Ddeuteron.py:80-81), assembled in one kernel on the device.
         The handle keeps the matrix resident: ``Lanczos``-style runs can start from it without a re-upload."""
+        if self.device_potential and hasattr(self.potential, "device_params"):
+            return self._device_csr(points, None, True, potential_params=self.potential.device_params(self.L))
         return self._device_csr(points, self.potential_on_grid(), True)
 
     # ------------------------------------------------------------------ index helpers (Hamiltonian.py:73-128)

@@ -52,7 +52,51 @@ class ExchangePlan:
     ghost_cols: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int64))  # global ids of the ghost tail, in order
 
 
-def plan_exchange(rowptr, colidx_global, M, world, rank, mode="auto", allgather_threshold=0.25):
+def stencil3d_columns(dims, points, rows):
+    """Global column ids of the periodic 7-/27-point stencil rows ``rows`` of a ``Nx x Ny x Nz`` grid, ``(len(rows), points)``,
+    unsorted (flat index ``x + Nx*y + Nx*Ny*z``, neighbours wrap: Hamiltonian.py:73-99)."""
+    Nx, Ny, Nz = (int(d) for d in dims)
+    r = np.asarray(rows, dtype=np.int64)
+    x, y, z = r % Nx, (r // Nx) % Ny, r // (Nx * Ny)
+    offs = [(dx, dy, dz) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)
+            if int(points) == 27 or abs(dx) + abs(dy) + abs(dz) <= 1]
+    return np.stack([((x + dx) % Nx) + ((y + dy) % Ny) * Nx + ((z + dz) % Nz) * (Nx * Ny) for dx, dy, dz in offs], axis=1)
+
+
+def plan_stencil_slab(dims, points, world, rank):
+    """Halo plan of one rank's row block of the periodic 3-D stencil operator WITHOUT building the matrix: only rows within
+    one stencil reach of either end of the block can touch another rank's rows (``2*Nx*Ny``: a z-neighbour combined with
+    an in-plane periodic wrap moves a column by less than two planes), so the planner of ``plan_exchange`` runs on those
+    boundary rows alone.  Returns ``(plan, ghost_ranges)``: ``plan.colidx`` is ``None`` (the
+    device assembles the renumbered columns itself, lz_build_stencil3d_block) and ``ghost_ranges`` lists the ghost tail as
+    contiguous ``(global_start, length)`` runs, in tail order."""
+    Nx, Ny, Nz = (int(d) for d in dims)
+    M = Nx * Ny * Nz
+    chunk = chunk_size(M, world)
+    lo, hi = min(M, rank * chunk), min(M, (rank + 1) * chunk)
+    rows = hi - lo
+    if world == 1:
+        return ExchangePlan("none", rows, round_up(rows, PAD), M, None), []
+    reach = 2 * Nx * Ny
+    ids = np.arange(rows, dtype=np.int64)
+    ids = ids if rows <= 2 * reach else np.concatenate([ids[:reach], ids[rows - reach:]])
+    cols = stencil3d_columns(dims, points, lo + ids)
+    k = cols.shape[1]
+    plan = plan_exchange(np.arange(len(ids) + 1, dtype=np.int64) * k, cols.reshape(-1), M, world, rank, mode="halo", row_ids=ids)
+    plan.colidx = None
+    g = plan.ghost_cols
+    if len(g) == 0:
+        return plan, []
+    cut = np.flatnonzero(np.diff(g) != 1) + 1
+    starts = np.concatenate([[0], cut])
+    ends = np.concatenate([cut, [len(g)]])
+    ranges = [(int(g[a]), int(b - a)) for a, b in zip(starts, ends)]
+    if len(ranges) > 16:
+        raise ValueError("the ghost tail of this block is not a handful of contiguous runs (block boundaries cut through too many planes)")
+    return plan, ranges
+
+
+def plan_exchange(rowptr, colidx_global, M, world, rank, mode="auto", allgather_threshold=0.25, row_ids=None):
     """Plan the SpMV input exchange for this rank's row block.
 
     ``rowptr`` / ``colidx_global``: CSR of the owned rows with GLOBAL column ids.
@@ -66,7 +110,9 @@ def plan_exchange(rowptr, colidx_global, M, world, rank, mode="auto", allgather_
     lo, hi = min(M, rank * chunk), min(M, (rank + 1) * chunk)
     rows = hi - lo
     rows_pad = round_up(rows, PAD)
-    assert len(rowptr) == rows + 1
+    # row_ids: the CSR holds only these local rows (a stencil's boundary rows, plan_stencil_slab); default: all owned rows
+    row_ids = np.arange(rows, dtype=np.int64) if row_ids is None else np.asarray(row_ids, dtype=np.int64)
+    assert len(rowptr) == len(row_ids) + 1
     if world == 1:
         return ExchangePlan("none", rows, rows_pad, int(M), cols.astype(np.int32))
     own = (cols >= lo) & (cols < hi)
@@ -83,7 +129,7 @@ def plan_exchange(rowptr, colidx_global, M, world, rank, mode="auto", allgather_
     owner = ghost_cols // chunk
     peers, recv_counts = np.unique(owner, return_counts=True)
     # rows of mine that touch a column owned by q -> q needs those x entries (structural symmetry)
-    row_of = np.repeat(np.arange(rows, dtype=np.int64), np.diff(rowptr))
+    row_of = np.repeat(row_ids, np.diff(rowptr))
     pair = np.unique((cols[~own] // chunk) * rows_pad + row_of[~own])
     send_owner, send_row = pair // rows_pad, pair % rows_pad
     speers, send_counts = np.unique(send_owner, return_counts=True)

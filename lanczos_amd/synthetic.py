@@ -22,6 +22,7 @@ __all__ = [
     "dense_symmetric",
     "dense_symmetric_hashed",
     "deuteron_potential",
+    "DeuteronPotential",
     "reference_start_vector",
 ]
 
@@ -148,6 +149,23 @@ def deuteron_potential(x, y, z):
     r = np.sqrt(x**2 + y**2 + z**2)
     eWell = 54.531
     return 40.0 * eWell * np.exp(-((r / 0.25) ** 4.0)) - 65.4823128982115 * np.exp(-((r / 1.7) ** 4.0))
+
+
+class DeuteronPotential:
+    """The same hard core + well as a callable with its constants exposed (``eCores exp(-(r/rCore)^fPow) - eWells
+    exp(-(r/rWell)^fPow)``, 3Ddeuteron.py:51-61): ``lanczos_amd.Hamiltonian`` can then evaluate it on the device instead
+    of point by point on the host (``Hamiltonian.device_potential = True``)."""
+
+    def __init__(self, eCores=40.0 * 54.531, rCore=0.25, eWells=65.4823128982115, rWell=1.7, fPow=4.0):
+        self.eCores, self.rCore, self.eWells, self.rWell, self.fPow = float(eCores), float(rCore), float(eWells), float(rWell), float(fPow)
+
+    def __call__(self, x, y, z):
+        r = np.sqrt(x**2 + y**2 + z**2)
+        return self.eCores * np.exp(-((r / self.rCore) ** self.fPow)) - self.eWells * np.exp(-((r / self.rWell) ** self.fPow))
+
+    def device_params(self, L):
+        """the 8 parameters lz_build_stencil3d_block takes for potential_kind 2 on a cubic box of side L"""
+        return np.array([self.eCores, self.rCore, self.eWells, self.rWell, self.fPow, L, L, L], dtype=np.float64)
 
 
 def reference_start_vector(M, seed=99):

@@ -54,6 +54,11 @@ WORKER = textwrap.dedent('''
             s.h.set_tuning(13, 1)
         a, bta = s.execute_Lanczos(n)
         sweeps = s.h.last_sweeps()
+        device_built_equal = None
+        if name == "c4_slab_k200":  # the same slab assembled on the device from the boundary-row plan: identical matrix, identical run
+            s2 = distributed.DistributedLanczos.from_stencil((24, 24, 32), 7, boot, device_id=0, backend="host")
+            a2, b2 = s2.execute_Lanczos(n)
+            device_built_equal = bool(np.array_equal(a2, a) and np.array_equal(b2, bta) and np.array_equal(s2.V_local, s.V_local))
         theta = s.get_H_eigs()
         V = s.V_local
         Y = s.H_eigvecs_local
@@ -71,7 +76,7 @@ WORKER = textwrap.dedent('''
                          scale=float(max(np.abs(ao).max(), np.abs(bo).max())),
                          dV=float(np.abs(V[:, :8] - Vo[:8, lo:hi].T).max()), dY=float(np.abs(Y - V @ S).max()),
                          orth=float(np.abs(boot.allreduce_sum(V.T @ V) - np.eye(n)).max()),
-                         comm_launches=s.timings()["comm"]["launches"], sweeps=sweeps, n=n)
+                         comm_launches=s.timings()["comm"]["launches"], sweeps=sweeps, n=n, device_built_equal=device_built_equal)
     res = boot.allgather_obj(out)
     if boot.rank == 0:
         import json
@@ -100,6 +105,7 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
         assert per_rank["graph"]["mode"] == "allgather" and per_rank["graph_halo"]["mode"] == "halo"
         assert per_rank["dense"]["mode"] == "allgather" and per_rank["dense_poison"]["mode"] == "allgather"
         assert per_rank["c4_slab_k200"]["mode"] == "halo" and per_rank["c5_k500"]["mode"] == "halo"
+        assert per_rank["c4_slab_k200"]["device_built_equal"] is True
         assert per_rank["c4_slab_k200"]["prefix"] >= 100 and per_rank["c5_k500"]["prefix"] >= 300, per_rank
         for name, r in per_rank.items():
             if name.endswith("_partial"):

@@ -405,3 +405,27 @@ def test_ablation_knobs_are_rejected_by_the_product_library(hip):
     for idx, val in [(1, 0), (1, 10), (1, 13), (8, 2), (7, 8), (13, 1), (13, 0)]:
         assert h.lib.lz_set_tuning(h._h, idx, val) == 0, (idx, val)
     h.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("dims,n", [((300, 250), 50), ((331, 211), 37), ((512, 256), 200)])
+def test_ritz_backtransform_kernels(hip, variant, dims, n):
+    """Y = V S (Lanczos.py:153-156) by the three FP64-MFMA kernels - 0: persistent, two waves per SIMD, S staged through
+    LDS (default above ~65 000 rows); 1: one workgroup per 128 rows (small problems; round-1 kernel); 2: persistent, one
+    wave per SIMD - against NumPy on the fetched basis, ragged row and column counts included."""
+    A = synthetic.laplacian_2d_5pt(*dims)
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    h = hip.Handle(0)
+    h.set_tuning(9, variant)
+    h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    a, b = h.run(n, v0)
+    V = h.get_basis()
+    T = np.diag(a) + np.diag(b, 1) + np.diag(b, -1)
+    S = np.linalg.eigh(T)[1]
+    Y = h.ritz_vectors(S)
+    np.testing.assert_allclose(Y, V.T @ S, rtol=0, atol=1e-13)
+    G = h.ritz_gram()
+    assert np.abs(G - np.eye(n)).max() < 1e-12
+    h.close()

@@ -93,3 +93,41 @@ def test_device_assembly_large_properties(tmp_path, monkeypatch):
     assert T.shape == (96**3, 96**3) and T.nnz == 27 * 96**3 and T.has_sorted_indices
     assert np.abs(np.asarray(T.sum(axis=1)).ravel()).max() < 1e-9 * abs(ham.T_factor)
     assert abs(T - T.T).max() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(9, 8, 7), (5, 12, 6)])
+def test_noncubic_stencil_assembly_is_bit_exact(dims):
+    """lz_build_stencil3d_block on a Nx x Ny x Nz grid (whole matrix on one rank) against the NumPy generator of the
+    BASELINE C4 matrix (synthetic.laplacian_3d_7pt: 6 on the diagonal, -1 on the six periodic neighbours)."""
+    from lanczos_amd import _capi, synthetic
+
+    A = synthetic.laplacian_3d_7pt(*dims)
+    h = _capi.Handle(0)
+    h.build_stencil3d_block(dims, 7, 1.0, [-6.0, 1.0, 0.0, 0.0], 0, A.shape[0], (), negate_T=True)
+    rowptr, colidx, vals = h.get_csr()
+    assert np.array_equal(rowptr, A.rowptr) and np.array_equal(colidx, A.colidx) and np.array_equal(vals, A.vals)
+    assert h.spmv_plan() == "fixed-k"
+    h.close()
+
+
+@pytest.mark.gpu
+def test_device_potential_matches_the_host_evaluation(tmp_path, monkeypatch):
+    """Hamiltonian.device_potential: the deuteron hard core + well evaluated inside the assembly kernel (no N^3 host
+    array) against the reference-faithful host evaluation - same structure, values within the libm difference."""
+    from lanczos_amd import Hamiltonian, synthetic
+
+    monkeypatch.chdir(tmp_path)
+    Hamiltonian.verbose = False
+    N, L = 14, 25
+    pot = synthetic.DeuteronPotential()
+    x = np.linspace(-3, 3, 7)
+    assert np.array_equal(pot(x, x[::-1], 0.3 * x), synthetic.deuteron_potential(x, x[::-1], 0.3 * x))
+    ham = Hamiltonian(N, L, pot, 197.327**2 / (2 * 469.4592) / (float(L) / N) ** 2)
+    H_host = ham.build_H("27")
+    ham.device_potential = True
+    H_dev = ham.build_H("27")
+    assert np.array_equal(H_host.indptr, H_dev.indptr) and np.array_equal(H_host.indices, H_dev.indices)
+    off = H_host.indices != np.repeat(np.arange(N**3), 27)
+    assert np.array_equal(H_host.data[off], H_dev.data[off])  # the kinetic part is the same arithmetic
+    np.testing.assert_allclose(H_dev.diagonal(), H_host.diagonal(), rtol=1e-12, atol=1e-12 * np.abs(H_host.diagonal()).max())

@@ -217,3 +217,25 @@ def test_headline_partition_plan(world):
         assert int(p.recv_counts.sum()) == total and int(p.send_counts.sum()) == total
         assert p.ncols_ext == p.rows_pad + total
         assert p.colidx.max() < p.ncols_ext and p.colidx.min() >= 0
+
+
+@pytest.mark.parametrize("points", [7, 27])
+@pytest.mark.parametrize("dims,world", [((12, 11, 10), 2), ((12, 11, 10), 3), ((9, 8, 16), 8), ((20, 18, 16), 5)])
+def test_stencil_slab_plan_equals_the_matrix_based_plan(dims, world, points):
+    """partition.plan_stencil_slab plans a slab's halo from its boundary rows alone (the device then assembles the slab's
+    CSR itself, lz_build_stencil3d_block): same peers, counts, send lists and ghost tail as plan_exchange on the host-built
+    row block, and the ghost tail is a handful of contiguous global ranges."""
+    M = int(np.prod(dims))
+    cols = np.sort(partition.stencil3d_columns(dims, points, np.arange(M)), axis=1)
+    if points == 7:
+        A = synthetic.laplacian_3d_7pt(*dims)
+        assert np.array_equal(cols.reshape(-1), A.colidx)
+    b = partition.row_bounds(M, world)
+    for r in range(world):
+        lo, hi = b[r], b[r + 1]
+        p0 = partition.plan_exchange(np.arange(hi - lo + 1) * points, cols[lo:hi].reshape(-1), M, world, r, "halo")
+        p1, ranges = partition.plan_stencil_slab(dims, points, world, r)
+        for k in ("peers", "send_counts", "send_idx", "recv_counts", "ghost_cols"):
+            assert np.array_equal(getattr(p0, k), getattr(p1, k)), (k, r)
+        assert p0.ncols_ext == p1.ncols_ext and p1.colidx is None
+        assert np.array_equal(np.concatenate([np.arange(s, s + n) for s, n in ranges]), p0.ghost_cols) and len(ranges) <= 16
