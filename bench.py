@@ -280,11 +280,14 @@ def main():
     # sanity of the result (cheap): Ritz values finite, extreme one inside the Gershgorin bound
     try:
         theta = solver.get_H_eigs(fetch=False)
+        tr_first = solver.timings()["ritz"]  # first call of the process: includes the kernel's code-object load
+        theta = solver.get_H_eigs(fetch=False)
         tr = solver.timings()["ritz"]
+        tr["ms_first_call"] = tr_first["ms"]
     except _capi.LanczosHipError as e:  # e.g. no room for a second M x k array next to the basis
         print(f"[rank {rank}] Ritz back-transform skipped: {e}", file=sys.stderr)
         theta = np.linalg.eigvalsh(solver.H_eff)
-        tr = {"ms": 0.0, "flops": 0.0}
+        tr = {"ms": 0.0, "flops": 0.0, "ms_first_call": 0.0}
     assert np.isfinite(theta).all()
 
     if rank == 0:
@@ -345,10 +348,10 @@ def main():
             "device": solver.h.device_name(),
             "ritz_min_max": [float(theta.min()), float(theta.max())],
             "partial_reorth": None,
-            "ritz_backtransform": {"ms": round(tr["ms"], 3), "tflops": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9, 2),
+            "ritz_backtransform": {"ms": round(tr["ms"], 3), "ms_first_call": round(tr.get("ms_first_call", 0.0), 3), "tflops": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9, 2),
                                    "bound": "mfma", "peak_tflops": FP64_MFMA_PEAK_TFLOPS,
                                    "frac": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 4),
-                                   "note": "Y = V^T-layout x S (M x k x k) FP64 MFMA GEMM, outside the timed steps"},
+                                   "note": "Y = V^T-layout x S (M x k x k) FP64 MFMA GEMM, outside the timed steps; second call of the process (ms_first_call: the first)"},
         }
     else:
         line = None

@@ -222,6 +222,11 @@ int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
 int lz_last_sweeps(lz_handle h, int* sweeps);
+/* 1 if the last lz_run ran as ONE cooperative kernel (small-problem engine, lz_small.hip: rows <= 1280 on one rank in
+ * fused-norm mode - the size of the reference's own scripts 1Dbox.py / 1Ddeuteron.py and of config C1; three grid
+ * barriers per step instead of six launches, results bit-identical to the multi-kernel path), else 0.
+ * lz_set_tuning(h, 15, 1) switches the engine off. */
+int lz_last_engine(lz_handle h, int* engine);
 
 /* ---- single steps (unit parity tests drive the kernels one by one) ------ */
 /* allocate a zeroed basis of n rows + r (what lz_run does first, Lanczos.py:104-107) */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "lz_ritz_quality": (C.c_int, [_P, _D]),
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
     "lz_last_sweeps": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "lz_last_engine": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_basis_alloc": (C.c_int, [_P, C.c_int]),
     "lz_basis_set_row": (C.c_int, [_P, C.c_int, _D]),
     "lz_basis_get_row": (C.c_int, [_P, C.c_int, _D]),
@@ -463,6 +464,12 @@ class Handle:
         k = C.c_int()
         self.check(self.lib.lz_last_sweeps(self._h, C.byref(k)))
         return k.value
+
+    def last_engine(self):
+        """"small" if the last run went through the one-kernel small-problem engine, else "kernels"."""
+        k = C.c_int()
+        self.check(self.lib.lz_last_engine(self._h, C.byref(k)))
+        return "small" if k.value else "kernels"
 
     def timings(self):
         t = LzTimings()

@@ -171,6 +171,7 @@ struct lz_context {
   hipEvent_t run_a = nullptr, run_b = nullptr;
   bool run_timed = false;
   int last_sweeps = 0;
+  int last_engine = 0;  // 1: the last lz_run went through the small-problem engine (one cooperative kernel)
   double* h_pinned = nullptr;  // 8 pinned doubles for the per-step scalar read-back of the partial-reorth mode
   bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
   lz_timings acc;
@@ -1338,11 +1339,53 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   const double t2 = now();
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
   const bool one_reduce = (h->flags & LZ_FLAG_ONE_REDUCE) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL) && h->qplan.family == 2;
+  // Small-problem engine (lz_small.hip): the whole run as one cooperative kernel, bit-identical to the multi-kernel path.
+  // Auto (tune[15] == 0) whenever it applies; tune[15] == 1 switches it off.
+  bool small = h->tune[15] != 1 && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
+               !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_SPMV_SCALAR | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->qplan.family == 2 &&
+               h->qplan.L == 512 && h->rows_pad <= kSmallMaxPadRows && h->tune[1] == 0 && h->tune[8] == 0 && n <= 4096;
+  SmallArgs sa;
+  memset(&sa, 0, sizeof sa);
+  if (small) {
+    sa.kind = h->kind;
+    if (h->kind == 2) {
+      sa.dense = h->d_dense;
+      sa.lda = h->dense_lda;
+      sa.nparts = (int)((h->rows + 3) / 4);
+    } else {
+      const CsrDev& A = h->csr;
+      const bool fixed = !(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7);
+      small = !A.pb && A.max_row_nnz <= A.blk_nnz_cap && (!fixed || A.fixed_rb == 512);
+      sa.rowptr = A.rowptr;
+      sa.colidx = A.colidx;
+      sa.vals = A.vals;
+      sa.rowblk = fixed ? nullptr : A.rowblk;
+      sa.nparts = fixed ? (int)((h->rows + 511) / 512) : A.n_rowblk;
+    }
+    small = small && sa.nparts <= 1024 && h->part_cap >= (size_t)h->rows;
+  }
+  if (small) {
+    sa.rows = (int)h->rows;
+    sa.rows_pad = (int)h->rows_pad;
+    sa.n = n;
+    sa.ldv = h->ldv;
+    sa.V = h->d_V;
+    sa.y = h->d_r;
+    sa.drow = h->d_part;
+    sa.pc = h->d_c;
+    sa.alpha = h->d_alpha;
+    sa.beta = h->d_beta;
+    sa.bar = reinterpret_cast<unsigned*>(h->d_nrm2);  // zeroed by basis_alloc
+    h->acc.launches[LZ_K_FINAL] += 1;
+    LZ_HIP(h, launch_small_run(sa, small_grid(sa.rows_pad), h->stream));
+    LZ_TRY(check_launch(h, "small_run"));
+  }
+  h->last_engine = small ? 1 : 0;
   if (one_reduce) LZ_TRY(run_loop_onereduce(h, n));
   // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
-  if (!one_reduce) LZ_TRY(step_spmv(h, 0));
+  if (!one_reduce && !small) LZ_TRY(step_spmv(h, 0));
   const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL);
-  if (!one_reduce) LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
+  if (!one_reduce && !small) LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
   const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
   const bool partial = (h->flags & LZ_FLAG_REORTH_PARTIAL) != 0;
   // Partial re-orthogonalisation (opt-in): Simon's omega-recurrence on the host, fed with alpha_j and beta_{j+1}
@@ -1364,7 +1407,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   bool force_next = false;
   double normA = 0.0;
   int sweeps = 0;
-  for (int j = 0; j < n && !one_reduce; ++j) {
+  for (int j = 0; j < n && !one_reduce && !small; ++j) {
     h->prof_iter = (j % pstride) == pstride / 2;  // centred sample: same mean j as the full run
     const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
     bool sweep = true;
@@ -1415,7 +1458,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
       normA = std::max(normA, std::fabs(two[0]) + hb[(size_t)j] + hb[(size_t)j + 1]);
     }
   }
-  h->last_sweeps = one_reduce ? n : sweeps;
+  h->last_sweeps = (one_reduce || small) ? n : sweeps;
   h->prof_iter = true;
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
   const double t3 = now();
@@ -1775,6 +1818,12 @@ int lz_ritz_quality(lz_handle h, double* out) {
   if (rc != LZ_OK) return rc;
   if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
   for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];
+  return LZ_OK;
+}
+
+int lz_last_engine(lz_handle h, int* engine) {
+  if (!h || !engine) return LZ_ERR_ARG;
+  *engine = h->last_engine;
   return LZ_OK;
 }
 

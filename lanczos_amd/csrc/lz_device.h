@@ -70,4 +70,50 @@ __device__ __forceinline__ int2 ld_stream(const int2* p) {
   return *p;
 }
 
+
+// One wave, one dense row (row-major, 16-byte aligned): 16-byte non-temporal loads of the row, x through L1/L2, four
+// independent accumulators per lane, wave-shuffle reduction; the sum is valid in lane 0.  Shared by k_gemv_dense and the
+// small-problem engine (lz_small.hip) - the SAME arithmetic, so both produce the same bits.
+__device__ __forceinline__ double gemv_row_wave(const double* __restrict__ a, const double* __restrict__ x, int64_t cols, int lane) {
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  int64_t c = 0;
+  {
+    const double2* a2 = reinterpret_cast<const double2*>(a);
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    const int64_t m2 = cols >> 1;
+    int64_t p = lane;
+    for (; p + 448 < m2; p += 512) {  // eight 16-byte row loads in flight per lane
+      double2 u[8], xv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) u[q] = ld_stream<1>(a2 + p + 64 * q);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xv[q] = x2[p + 64 * q];
+#pragma unroll
+      for (int q = 0; q < 8; q += 2) {
+        acc0 = fma(u[q].x, xv[q].x, acc0);
+        acc1 = fma(u[q].y, xv[q].y, acc1);
+        acc2 = fma(u[q + 1].x, xv[q + 1].x, acc2);
+        acc3 = fma(u[q + 1].y, xv[q + 1].y, acc3);
+      }
+    }
+    for (; p + 64 < m2; p += 128) {
+      const double2 u = ld_stream<1>(a2 + p), v = ld_stream<1>(a2 + p + 64);
+      const double2 xu = x2[p], xv = x2[p + 64];
+      acc0 = fma(u.x, xu.x, acc0);
+      acc1 = fma(u.y, xu.y, acc1);
+      acc2 = fma(v.x, xv.x, acc2);
+      acc3 = fma(v.y, xv.y, acc3);
+    }
+    for (; p < m2; p += 64) {
+      const double2 u = ld_stream<1>(a2 + p);
+      const double2 xu = x2[p];
+      acc0 = fma(u.x, xu.x, acc0);
+      acc1 = fma(u.y, xu.y, acc1);
+    }
+    c = 2 * m2;
+  }
+  for (c += lane; c < cols; c += 64) acc0 = fma(a[c], x[c], acc0);  // odd column count: the last column
+  return wave_sum((acc0 + acc1) + (acc2 + acc3));
+}
+
 }  // namespace lz

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kTPB) void k_gemm_tn_persist(const double* __restri
   }
 }
 
-// Ritz back-transform, default kernel: persistent waves, TWO per SIMD, S staged through LDS.
+// Ritz back-transform, A/B arm (variant 3): persistent waves, TWO per SIMD, S staged through LDS.
 // What the two earlier kernels taught (profiles/r02/ritz_gemm_ab.json): k_gemm_tn and its persistent-wave variant both sit at
 // MfmaUtil 65 % - so wave turnover was not the gap; what they share is ONE wave per SIMD (a 32-row x n tile needs ~330
 // registers), and a lone wave cannot keep the f64 matrix pipe issuing back to back.  Halving the tile to 16 rows (104
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kTPB) void k_gemm_tn_persist(const double* __restri
 // operands with ds_read_b64 (a quarter of the LDS bandwidth).  The only per-wave global traffic left in the loop is the
 // V stream itself: one 8-byte non-temporal load per lane per k-step, four steps ahead.
 // Every wave of a block runs the same number of tiles (surplus tiles are clamped and not stored): the barriers match.
-template <int NT>
+template <int NT, int ABL = 0>  // ABL (kernel-bench build only): 1 no result stores, 2 no V loads, 4 no MFMAs
 __global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
                                                     const double* __restrict__ B, int ldb, int ncols, double* __restrict__ C,
                                                     int64_t ldc) {
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ 
     m = m < mdim ? m : mdim - 1;
     int kr = 4 * ps + lk;
     kr = kr < kcount ? kr : kcount - 1;  // padding steps: finite values, multiplied by the zero rows of S
-    x0 = __builtin_nontemporal_load(A + (int64_t)kr * lda + m);
+    x0 = (ABL & 2) ? (double)(kr + m) : __builtin_nontemporal_load(A + (int64_t)kr * lda + m);
     if (++ps == KP * npanels) {
       ps = 0;
       ++pr;
@@ -296,7 +296,10 @@ __global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ 
 #pragma unroll
         for (int b = 0; b < NT; ++b) bv[b] = srow[colb[b]];
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv[b], acc[b], 0, 0, 0);
+        for (int b = 0; b < NT; ++b) {
+          if (ABL & 4) acc[b][0] += a0 * bv[b];
+          else acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv[b], acc[b], 0, 0, 0);
+        }
       }
       double2* dst = s2 + (size_t)(buf ^ 1) * panel_d2;
 #pragma unroll
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ 
       buf ^= 1;
     }
     const int64_t tile = wave + rd * nwaves;
+    if ((ABL & 1) && acc[0][0] != 1.2345e300) continue;
     if (tile < ntiles) {  // wave-uniform
       const int64_t m0 = tile * 16;
       if (m0 + 16 <= mdim) {
@@ -358,11 +362,27 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
                       int64_t ldy, hipStream_t s, int variant) {
   const int CT = (n + 15) / 16;
   const int64_t ntiles = (rows + 31) / 32;
-  if (variant == 1 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) {  // A/B arm, > 256 columns, or too few tiles to loop over
+  if (variant == 0 || variant == 1 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) {  // default; also > 256 columns or too few tiles to loop over
     launch_gemm_tn(V, ldv, rows, n, n, 1, Spad, npad, n, Y, ldy, 0, s);
     return;
   }
-  if (variant != 2) {  // default: two waves per SIMD, S through LDS
+#ifdef LZ_KBENCH
+  if (variant >= 10 && CT == 13) {  // timing-only ablation arms at n = 200
+    const size_t ldsk = (size_t)2 * 16 * npad * sizeof(double);
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(kNumCU), dim3(512), ldsk, s, V, ldv, rows, n, Spad, npad, n, Y, ldy); };
+    switch (variant - 10) {
+      case 1: go(k_gemm_tn_lds<13, 1>); break;
+      case 2: go(k_gemm_tn_lds<13, 2>); break;
+      case 3: go(k_gemm_tn_lds<13, 3>); break;
+      case 4: go(k_gemm_tn_lds<13, 4>); break;
+      case 5: go(k_gemm_tn_lds<13, 5>); break;
+      case 6: go(k_gemm_tn_lds<13, 6>); break;
+      default: go(k_gemm_tn_lds<13>); break;
+    }
+    return;
+  }
+#endif
+  if (variant == 3) {  // A/B arm: two waves per SIMD, S through LDS
     const size_t lds = (size_t)2 * 16 * npad * sizeof(double);
 #define LZ_TNL(nt)                                                                                                            \
   case nt:                                                                                                                    \

@@ -108,8 +108,9 @@ void launch_bi_two_term(int sub, int dots, double* r, double* sv, const double* 
 int bi_partials_needed();
 
 // Y(rows x n, row-major, ldy) = sum_k V[k][m] * S[k][i]   (FP64 MFMA)
-// variant 0: persistent waves, two per SIMD, S staged through LDS (default); 1: one workgroup per 128 rows, one wave per
-// SIMD (round-1 kernel, also used for small problems); 2: persistent waves, one per SIMD, S from L2 (A/B arms)
+// variant 0/1: one workgroup per 128 rows, one wave per SIMD owning 32 rows x all columns (default: the fastest of the
+// three on MI355X, profiles/r02/ablate_pb_rows_and_ritz.json); 2: the same tile walked by persistent waves; 3: persistent
+// waves, two per SIMD with 16-row tiles, S staged through LDS
 void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
                       int64_t ldy, hipStream_t s, int variant = 0);
 // G = Y^T Y as K-chunk partials (n x n each); returns the number of chunks (<= nz_max)
@@ -117,5 +118,30 @@ int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part,
 void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s);
 // per-block [s1 (n), s2 (n)] partials of the Ritz-vector quality sums; returns the number of blocks
 int launch_ritz_quality(const CsrDev& A, const double* Y, int64_t ldy, int n, double* part, hipStream_t s);
+
+// ---- small-problem engine (lz_small.hip): the whole run as one cooperative kernel
+struct SmallArgs {
+  int kind;  // 1 CSR, 2 dense
+  const int32_t* rowptr;
+  const int32_t* colidx;
+  const double* vals;
+  const int32_t* rowblk;  // CSR-stream row blocks (nparts + 1); nullptr: fixed blocks of 512 rows (fixed-K kernel)
+  int nparts;             // alpha partials of the multi-kernel path: row blocks (CSR) or ceil(rows / 4) (dense)
+  const double* dense;
+  int64_t lda;
+  int rows, rows_pad, n;
+  int64_t ldv;
+  double* V;
+  double* y;     // SpMV output (the handle's r vector)
+  double* drow;  // rows: V[j]_i * (A V[j])_i
+  double* pc;    // n + 1: raw re-orthogonalisation sums [V_i . r (i < j), r . r]
+  double* alpha;
+  double* beta;
+  unsigned* bar;  // grid barrier counter (zeroed before the launch)
+};
+
+constexpr int kSmallMaxPadRows = 1280;
+int small_grid(int rows_pad);
+hipError_t launch_small_run(const SmallArgs& a, int nb, hipStream_t s);
 
 }  // namespace lz

@@ -220,7 +220,7 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
     hipLaunchKernelGGL(k_spmv_scalar, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, x, x_own, y, A.rows, part);
     return grid;
   }
-  if (A.pb && !A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) return launch_spmv_pb(A, A.pb, x, y, x_own, part, s);
+  if (A.pb && !(flags & LZ_FLAG_SPMV_STREAM)) return launch_spmv_pb(A, A.pb, x, y, x_own, part, s);  // (A.ablation: kbench arms of phase 2)
   if (!A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) {  // A.ablation is always 0 in the product build
     if (A.fixed_k == 5) return launch_spmv_fixed<5>(A, x, y, x_own, part, A.fixed_rb, s);
     if (A.fixed_k == 7) return launch_spmv_fixed<7>(A, x, y, x_own, part, A.fixed_rb, s);
@@ -266,46 +266,7 @@ __global__ __launch_bounds__(kTPB) void k_gemv_dense(const double* __restrict__ 
   const int64_t row = (int64_t)blockIdx.x * (kTPB / 64) + w;
   double d = 0.0;
   if (row < M) {
-    const double* a = A + row * lda;  // lda is even: every row is 16-byte aligned
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int64_t c = 0;
-    {
-      const double2* a2 = reinterpret_cast<const double2*>(a);
-      const double2* x2 = reinterpret_cast<const double2*>(x);
-      const int64_t m2 = cols >> 1;
-      int64_t p = lane;
-      for (; p + 448 < m2; p += 512) {  // eight 16-byte row loads in flight per lane
-        double2 u[8], xv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) u[q] = ld_stream<1>(a2 + p + 64 * q);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) xv[q] = x2[p + 64 * q];
-#pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-          acc0 = fma(u[q].x, xv[q].x, acc0);
-          acc1 = fma(u[q].y, xv[q].y, acc1);
-          acc2 = fma(u[q + 1].x, xv[q + 1].x, acc2);
-          acc3 = fma(u[q + 1].y, xv[q + 1].y, acc3);
-        }
-      }
-      for (; p + 64 < m2; p += 128) {
-        const double2 u = ld_stream<1>(a2 + p), v = ld_stream<1>(a2 + p + 64);
-        const double2 xu = x2[p], xv = x2[p + 64];
-        acc0 = fma(u.x, xu.x, acc0);
-        acc1 = fma(u.y, xu.y, acc1);
-        acc2 = fma(v.x, xv.x, acc2);
-        acc3 = fma(v.y, xv.y, acc3);
-      }
-      for (; p < m2; p += 64) {
-        const double2 u = ld_stream<1>(a2 + p);
-        const double2 xu = x2[p];
-        acc0 = fma(u.x, xu.x, acc0);
-        acc1 = fma(u.y, xu.y, acc1);
-      }
-      c = 2 * m2;
-    }
-    for (c += lane; c < cols; c += 64) acc0 = fma(a[c], x[c], acc0);  // odd column count: the last column
-    const double acc = wave_sum((acc0 + acc1) + (acc2 + acc3));
+    const double acc = gemv_row_wave(A + row * lda, x, cols, lane);
     if (lane == 0) {
       y[row] = acc;
       d = x_own[row] * acc;

@@ -30,7 +30,7 @@
 namespace lz {
 
 constexpr int kPbThreads = 1024;
-constexpr int kPbCapMax = 16384;   // products per row block and LDS tile of phase 2 (128 KiB); default 8192: two workgroups per CU
+constexpr int kPbCapMax = 15360;   // products per row block and LDS tile of phase 2 (120 + 30 KiB); default 7168: two workgroups per CU
 constexpr int kPbMaxRows = 8192;   // rows per row block
 constexpr int kPbMaxW = 19968;     // doubles of v per column block: 156 KiB of LDS in phase 1
 
@@ -158,20 +158,25 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
 }
 
 // ---- phase 2: row sums out of LDS in CSR order, alpha partial per row block
-// The workgroup's life is two memory round trips and no more (it is latency-, not bandwidth-critical: 16 K products per
+// The workgroup's life is two memory round trips and no more (it is latency-, not bandwidth-critical: ~7 K products per
 // workgroup): (1) the tile table of this row block -> LDS, each thread's row bounds; (2) ALL product runs (GS lanes per
-// tile, every tile's first load issued before the first LDS store) and the row's first 8 perm entries; then one barrier
-// and the sums out of LDS.  Two workgroups per CU (cap = 8192 products = 64 KiB) overlap each other's round trips.
-template <int GS, int TPG>  // lanes that copy one tile together; tiles per lane group and trip
+// tile, three slots per lane, every load issued before the first LDS store) and the row block's whole `perm` segment,
+// coalesced, into LDS; then one barrier and the sums with both operands in LDS.  Nothing after the barrier touches
+// global memory except the y store: a first version fetched the perm entries of rows longer than 8 from global memory
+// inside the sum loop, and the workgroup then lived as long as its longest row's chain of dependent loads (45 us; the
+// timing ablations of profiles/r02/ablate_pb_rows_and_ritz.json showed 850 of its 1060 us left with every other access
+// removed).  Two workgroups per CU (cap = 7168 products: 56 + 14 + 3 KiB of LDS) overlap each other's round trips.
+template <int GS, int TPG, int ABL = 0>  // lanes that copy one tile together; tiles per lane group and trip; ABL: kernel-bench build only
 __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restrict__ rbptr, const int32_t* __restrict__ rowptr,
                                                        const int32_t* __restrict__ toff, const uint16_t* __restrict__ lstart,
                                                        const uint16_t* __restrict__ perm, const double* __restrict__ T, int nCB, int cap,
                                                        const double* __restrict__ xown, double* __restrict__ y,
                                                        double* __restrict__ part) {
-  extern __shared__ double seg[];  // cap products, then the tile table
+  extern __shared__ double seg[];  // cap products, the tile table, cap perm entries
   __shared__ double red[kPbThreads / 64];
   int* to_s = reinterpret_cast<int*>(seg + cap);
   uint16_t* ls_s = reinterpret_cast<uint16_t*>(to_s + nCB);
+  uint16_t* perm_s = ls_s + ((nCB + 2) & ~1);
   const int rb = blockIdx.x;
   {
     const int32_t* to = toff + (int64_t)rb * nCB;
@@ -180,18 +185,27 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restric
     for (int c = threadIdx.x; c <= nCB; c += kPbThreads) ls_s[c] = __builtin_nontemporal_load(ls + c);
   }
   const int r0 = rbptr[rb], r1 = rbptr[rb + 1];
+  const int k0 = rowptr[r0], cnt = rowptr[r1] - k0;
   // this thread's first row (row blocks hold <= kPbMaxRows rows: the others are handled after the barrier)
   const int row = r0 + threadIdx.x;
   int ka = 0, kb = 0;
   if (row < r1) {
-    ka = rowptr[row];
-    kb = rowptr[row + 1];
+    ka = rowptr[row] - k0;
+    kb = rowptr[row + 1] - k0;
   }
   __syncthreads();
   // Tile lengths scatter around their mean (Poisson): every lane takes THREE slots of a tile (t = l, l + GS, l + 2 GS),
   // all loads of a trip issued before the first LDS store - a tile longer than 3 GS (1e-4 of them) takes the slow loop.
   constexpr int NG = kPbThreads / GS, S = 3;
   const int g = threadIdx.x / GS, l = threadIdx.x % GS;
+  // the perm segment rides in the same round trip (8 coalesced 2-byte loads per thread at cap = 8192)
+  constexpr int PP = 8;
+  uint16_t pp[PP];
+#pragma unroll
+  for (int q = 0; q < PP; ++q) {
+    const int i = threadIdx.x + q * kPbThreads;
+    pp[q] = (!(ABL & 2) && i < cnt) ? __builtin_nontemporal_load(perm + k0 + i) : (uint16_t)(i & 1023);
+  }
   for (int cb0 = g; cb0 < nCB; cb0 += TPG * NG) {
     int off[TPG], a[TPG], len[TPG];
     double v[TPG][S];
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restric
 #pragma unroll
     for (int q = 0; q < TPG; ++q)
 #pragma unroll
-      for (int u = 0; u < S; ++u) v[q][u] = l + u * GS < len[q] ? __builtin_nontemporal_load(T + off[q] + l + u * GS) : 0.0;
+      for (int u = 0; u < S; ++u) v[q][u] = (!(ABL & 1) && l + u * GS < len[q]) ? __builtin_nontemporal_load(T + off[q] + l + u * GS) : 0.0;
 #pragma unroll
     for (int q = 0; q < TPG; ++q) {
 #pragma unroll
@@ -215,26 +229,30 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restric
       for (int t = l + S * GS; t < len[q]; t += GS) seg[a[q] + t] = __builtin_nontemporal_load(T + off[q] + t);
     }
   }
-  // the row's first perm entries travel with the product loads (same round trip)
-  uint16_t pf[8];
-  const int n0 = kb - ka;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) pf[k] = k < n0 ? __builtin_nontemporal_load(perm + ka + k) : (uint16_t)0;
+  for (int q = 0; q < PP; ++q) {
+    const int i = threadIdx.x + q * kPbThreads;
+    if (i < cnt) perm_s[i] = pp[q];
+  }
+  for (int i = threadIdx.x + PP * kPbThreads; i < cnt; i += kPbThreads) perm_s[i] = perm[k0 + i];  // cap > 8192 only
   __syncthreads();
   double d = 0.0;
-  if (row < r1) {
+  for (int rw = row; rw < r1; rw += kPbThreads) {  // one row per thread, except in row blocks of many short rows
+    if (rw != row) {
+      ka = rowptr[rw] - k0;
+      kb = rowptr[rw + 1] - k0;
+    }
     double sum = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < n0) sum += seg[pf[k]];  // CSR order, one rounding per add
-    for (int k = 8; k < n0; ++k) sum += seg[perm[ka + k]];
-    y[row] = sum;
-    d = xown[row] * sum;
-  }
-  for (int rw = row + kPbThreads; rw < r1; rw += kPbThreads) {  // row blocks of more than 1024 (short) rows
-    const int a2 = rowptr[rw], b2 = rowptr[rw + 1];
-    double sum = 0.0;
-    for (int k = a2; k < b2; ++k) sum += seg[perm[k]];
+    int k = ka;
+    for (; k + 4 <= kb; k += 4) {  // four LDS gathers in flight; the adds stay in CSR order, one rounding each
+      const double p0 = (ABL & 4) ? 1.0 : seg[perm_s[k]], p1 = (ABL & 4) ? 1.0 : seg[perm_s[k + 1]], p2 = (ABL & 4) ? 1.0 : seg[perm_s[k + 2]],
+                   p3 = (ABL & 4) ? 1.0 : seg[perm_s[k + 3]];
+      sum += p0;
+      sum += p1;
+      sum += p2;
+      sum += p3;
+    }
+    for (; k < kb; ++k) sum += (ABL & 4) ? 1.0 : seg[perm_s[k]];
     y[rw] = sum;
     d += xown[rw] * sum;
   }
@@ -277,8 +295,8 @@ void pb_free(PbDev*& pb) {
 // not qualify (a single row longer than the LDS tile, or too few columns to be worth blocking).
 hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob) {
   *out = nullptr;
-  // products per row block: 8192 by default; rows longer than that (up to 16384 entries) get the larger tile
-  int cap = cap_knob > 0 ? std::min(std::max(cap_knob, 1024), kPbCapMax) : 8192;
+  // products per row block: 7168 by default (two workgroups per CU); rows longer than that (up to 16384 entries) get the larger tile
+  int cap = cap_knob > 0 ? std::min(std::max(cap_knob, 1024), kPbCapMax) : 7168;
   if (A.max_row_nnz > cap) cap = kPbCapMax;
   if (A.rows <= 0 || A.nnz <= 0 || A.max_row_nnz > cap) return hipSuccess;
   // Column blocks: as few as the LDS allows (a tile run is ~kPbCap / nCB products: fewer blocks, longer runs), and a
@@ -342,7 +360,7 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   }
   hipFree(tot);
   pb->wide_runs = (double)pb->nnz / ((double)nRB * (double)nCB) > 20.0;
-  pb->lds2 = (size_t)cap * sizeof(double) + (size_t)nCB * sizeof(int) + ((size_t)nCB + 2) * sizeof(uint16_t);
+  pb->lds2 = (size_t)cap * sizeof(double) + (size_t)nCB * sizeof(int) + ((size_t)nCB + 4) * sizeof(uint16_t) + (size_t)cap * sizeof(uint16_t);
   // both phases may need more than the default 64 KiB of dynamic LDS: allowed once per kernel, here, so that the
   // launches themselves have no failure mode
   if (e == hipSuccess && pb->lds2 > 160 * 1024) e = hipErrorInvalidValue;  // only with thousands of column blocks AND the large tile
@@ -367,6 +385,23 @@ int pb_num_partials(const PbDev* pb) { return pb->nRB; }
 int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s) {
   const size_t lds1 = (size_t)pb->W * sizeof(double);
   hipLaunchKernelGGL(k_pb_products<8>, dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, x, A.ncols, pb->W, pb->T);
+#ifdef LZ_KBENCH  // timing-only ablation arms (wrong results): 1 no product loads, 2 no perm loads, 4 no LDS gathers
+  if (A.ablation && !pb->wide_runs) {
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T, pb->nCB,
+                         pb->cap, x_own, y, part);
+    };
+    switch (A.ablation) {
+      case 1: go(k_pb_rows<8, 4, 1>); break;
+      case 2: go(k_pb_rows<8, 4, 2>); break;
+      case 3: go(k_pb_rows<8, 4, 3>); break;
+      case 4: go(k_pb_rows<8, 4, 4>); break;
+      case 7: go(k_pb_rows<8, 4, 7>); break;
+      default: go(k_pb_rows<8, 4>); break;
+    }
+    return pb->nRB;
+  }
+#endif
   if (pb->wide_runs)
     hipLaunchKernelGGL((k_pb_rows<16, 4>), dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm,
                        pb->T, pb->nCB, pb->cap, x_own, y, part);

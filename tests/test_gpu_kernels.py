@@ -71,7 +71,7 @@ def _two_phase_matrices():
     vals = big.copy()
     vals.data = rng.standard_normal(big.nnz)  # non-integer values: products and partial sums really round
     too_long = scipy.sparse.random(40000, 40000, density=0.0002, random_state=rng, format="lil")
-    too_long[7, :] = 1.0  # 40000 entries > the 16384-product LDS tile: the layout does not apply, CSR-stream runs instead
+    too_long[7, :] = 1.0  # 40000 entries > the largest (15360-product) LDS tile: the layout does not apply, CSR-stream runs instead
     return {"graph_60000": big, "graph_60000_real": vals.tocsr(), "row_too_long": too_long.tocsr()}
 
 
@@ -80,7 +80,7 @@ def _two_phase_matrices():
 def test_spmv_two_phase_bit_exact(hip, name):
     """The column-blocked two-phase SpMV (lz_spmv_pb.hip; auto-selected for matrices without column locality, forced here
     with tuning knob 14 = 2): products staged through a column-block-major buffer, every row summed out of LDS in CSR
-    order - bit-identical to SciPy's csr_matvec, including rows of up to 16384 entries."""
+    order - bit-identical to SciPy's csr_matvec, including rows of up to 15360 entries."""
     H = MATS[name] if name in MATS else _two_phase_matrices()[name]
     M = H.shape[0]
     h = hip.Handle(0)

@@ -1,0 +1,87 @@
+"""The small-problem engine (lanczos_amd/csrc/lz_small.hip): the whole run as ONE cooperative kernel for the sizes of the
+reference's own scripts (1Dbox.py N = 500, 1Ddeuteron.py N = n = 1001) and BASELINE config C1 (dense 512, k = 20).
+It must reproduce the multi-kernel path BIT FOR BIT (same reduction trees, same MFMA sequence, same element-wise
+arithmetic) - and be several times faster, which is its whole point."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from lanczos_amd import Lanczos, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    d1, box = load_golden("box1d_N500_n50")
+    d2, deut = load_golden("deuteron1d_N1001_n1001")
+    d3, rag = load_golden("ragged_M700_n25")
+    return {
+        "c1_dense512_k20": (synthetic.dense_symmetric(512, seed=0), 20),
+        "box1d_dense_N500_n50": (box.toarray(), 50),
+        "deuteron1d_csr_N1001_n1001": (deut, 1001),
+        "lap2d_32x32_fixedk_n30": (synthetic.laplacian_2d_5pt(32, 32).to_scipy(), 30),
+        "lap3d_10x9x8_fixedk_n40": (synthetic.laplacian_3d_7pt(10, 9, 8).to_scipy(), 40),
+        "ragged_csr_M700_n25": (rag, 25),
+        "odd_dense_M333_n333": (synthetic.dense_symmetric(333, seed=3), 333),
+    }
+
+
+def _run(hip, H, n, engine_off, flags=None):
+    import scipy.sparse
+
+    h = hip.Handle(0)
+    h.set_options(hip.FLAG_FUSED_NORM if flags is None else flags)
+    if engine_off:
+        h.set_tuning(15, 1)
+    if scipy.sparse.issparse(H):
+        A = H.tocsr()
+        h.set_csr(A.shape[0], 0, A.indptr, A.indices, A.data)
+    else:
+        h.set_dense(H)
+    M = H.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    a, b = h.run(n, v0)  # first run: code-object load etc.
+    ts = []
+    for _ in range(5):
+        h.synchronize()
+        t0 = time.perf_counter()
+        a, b = h.run(n, v0)
+        ts.append(time.perf_counter() - t0)
+    out = (a, b, h.get_basis(), h.last_engine(), float(np.median(ts)))
+    h.close()
+    return out
+
+
+@pytest.mark.parametrize("name", list(_cases()))
+def test_engine_is_bit_identical_to_the_kernel_path(hip, name):
+    H, n = _cases()[name]
+    a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True)
+    a0, b0, V0, e0, t0 = _run(hip, H, n, engine_off=False)
+    assert e1 == "kernels" and e0 == "small"
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1), (np.abs(a0 - a1).max(), np.abs(b0 - b1).max())
+    assert np.array_equal(V0, V1), np.abs(V0 - V1).max()
+    print(f"\n[small-engine] {name}: kernels {1e3 * t1:.3f} ms, engine {1e3 * t0:.3f} ms, x{t1 / t0:.2f}")
+
+
+def test_engine_is_not_used_where_it_does_not_apply(hip):
+    H = synthetic.laplacian_2d_5pt(40, 40).to_scipy()  # 1600 rows > 1280
+    assert _run(hip, H, 10, engine_off=False)[3] == "kernels"
+    Hs = synthetic.laplacian_2d_5pt(20, 20).to_scipy()
+    assert _run(hip, Hs, 10, engine_off=False, flags=0)[3] == "kernels"  # not fused-norm mode
+    assert _run(hip, Hs, 10, engine_off=False, flags=hip.FLAG_FUSED_NORM | hip.FLAG_REORTH_PARTIAL)[3] == "kernels"
+    assert _run(hip, Hs, 10, engine_off=False)[3] == "small"
+
+
+def test_drop_in_class_uses_the_engine_on_the_reference_scripts_sizes():
+    """Through `Lanczos`: 1Dbox.py's N = 500 dense matrix; the golden coefficients still hold."""
+    d, H = load_golden("box1d_N500_n50")
+    Lanczos.verbose = False
+    s = Lanczos(H.toarray())
+    s.execute_Lanczos(50)
+    assert s._handle.last_engine() == "small"
+    scale = max(np.abs(d["alpha"]).max(), np.abs(d["beta"]).max())
+    assert np.abs(np.diag(s.H_eff) - d["alpha"]).max() <= 1e-10 * scale
+    assert np.abs(s.H_eigvals - d["H_eigvals"]).max() <= 1e-10 * np.abs(d["H_eigvals"]).max()
