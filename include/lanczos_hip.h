@@ -107,7 +107,7 @@ int lz_set_options(lz_handle h, int flags);
  * value-th iteration of lz_run, 8: update-kernel variant (1 cached loads, 2 one position per lane, 3/4/5 slice owner with
  * 8/4/1 positions per lane), 11: two-sided links (2 = single launch), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
  * fresh basis allocation before the required parts are cleared (test knob), 14: irregular SpMV plan (0 auto, 1 never
- * the column-blocked two-phase kernels, 2 always), 15: small-problem engine (0 auto, 1 off, 2 force)); they take effect
+ * the column-blocked two-phase kernels, 2 always), 15: small-problem engine (0 off, 2 on, 3 on with a plain grid)); they take effect
  * at the next lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order.  The
  * timing-only ablation arms (knob 1 values >= 20, knob 3) exist only in the kernel-bench build (make KBENCH=1,
  * liblanczos_kbench.so, tools/kbench.py); this library returns LZ_ERR_ARG for them. */
@@ -224,8 +224,8 @@ int lz_get_timings(lz_handle h, lz_timings* out);
 int lz_last_sweeps(lz_handle h, int* sweeps);
 /* 1 if the last lz_run ran as ONE cooperative kernel (small-problem engine, lz_small.hip: rows <= 1280 on one rank in
  * fused-norm mode - the size of the reference's own scripts 1Dbox.py / 1Ddeuteron.py and of config C1; three grid
- * barriers per step instead of six launches, results bit-identical to the multi-kernel path), else 0.
- * lz_set_tuning(h, 15, 1) switches the engine off. */
+ * barriers per step instead of six launches, results bit-identical to the multi-kernel path), else 0.  The engine is an
+ * opt-in experiment (lz_set_tuning(h, 15, 2)): on MI355X it is not faster than the launches it replaces. */
 int lz_last_engine(lz_handle h, int* engine);
 
 /* ---- single steps (unit parity tests drive the kernels one by one) ------ */

@@ -1340,8 +1340,10 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
   const bool one_reduce = (h->flags & LZ_FLAG_ONE_REDUCE) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL) && h->qplan.family == 2;
   // Small-problem engine (lz_small.hip): the whole run as one cooperative kernel, bit-identical to the multi-kernel path.
-  // Auto (tune[15] == 0) whenever it applies; tune[15] == 1 switches it off.
-  bool small = h->tune[15] != 1 && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
+  // Opt-in (tune[15] == 2, or 3 for the plain-grid arm): measured on MI355X it is NOT faster than the six launches per
+  // step it replaces (0.86-1.14x, profiles/r02/small_engine.json) - a device-coherent round trip costs ~2 us here, about
+  // what a kernel boundary costs, and a step needs a dozen of them.  Kept as a tested experiment, off by default.
+  bool small = h->tune[15] >= 2 && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
                !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_SPMV_SCALAR | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->qplan.family == 2 &&
                h->qplan.L == 512 && h->rows_pad <= kSmallMaxPadRows && h->tune[1] == 0 && h->tune[8] == 0 && n <= 4096;
   SmallArgs sa;
@@ -1355,14 +1357,15 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     } else {
       const CsrDev& A = h->csr;
       const bool fixed = !(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7);
-      small = !A.pb && A.max_row_nnz <= A.blk_nnz_cap && (!fixed || A.fixed_rb == 512);
+      // (one lane walks one row in the engine: rows of more than 32 entries would turn into a chain of dependent loads)
+      small = !A.pb && A.max_row_nnz <= 32 && (!fixed || A.fixed_rb == 512);
       sa.rowptr = A.rowptr;
       sa.colidx = A.colidx;
       sa.vals = A.vals;
       sa.rowblk = fixed ? nullptr : A.rowblk;
       sa.nparts = fixed ? (int)((h->rows + 511) / 512) : A.n_rowblk;
     }
-    small = small && sa.nparts <= 1024 && h->part_cap >= (size_t)h->rows;
+    small = small && sa.nparts <= 1024 && h->part_cap >= (size_t)(2048 + h->rows_pad) && n <= kSmallMaxPadRows;
   }
   if (small) {
     sa.rows = (int)h->rows;
@@ -1372,13 +1375,29 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     sa.V = h->d_V;
     sa.y = h->d_r;
     sa.drow = h->d_part;
+    sa.x0 = h->d_part + 2048;  // d_part holds >= 4096 doubles; rows_pad <= 1280
+    LZ_HIP(h, hipMemcpyAsync(h->d_part + 2048, h->d_V, (size_t)h->rows_pad * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     sa.pc = h->d_c;
     sa.alpha = h->d_alpha;
     sa.beta = h->d_beta;
-    sa.bar = reinterpret_cast<unsigned*>(h->d_nrm2);  // zeroed by basis_alloc
+    sa.bar = reinterpret_cast<unsigned*>(h->d_nrm2);  // 16 bytes, zeroed by basis_alloc
+    sa.xcc = reinterpret_cast<unsigned*>(h->d_part + 3400);
     h->acc.launches[LZ_K_FINAL] += 1;
-    LZ_HIP(h, launch_small_run(sa, small_grid(sa.rows_pad), h->stream));
+    // tune[15] == 2: the participating blocks share one XCD (every eighth block of the grid); 3: plain grid over all XCDs
+    LZ_HIP(h, launch_small_run(sa, small_grid(sa.rows_pad), h->tune[15] == 2, h->stream));
     LZ_TRY(check_launch(h, "small_run"));
+    unsigned status = 0;
+    LZ_HIP(h, hipMemcpyAsync(&status, sa.bar + 2, sizeof status, hipMemcpyDeviceToHost, h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    if (status != 0) {
+      // the engine refused (its blocks were not dealt to one XCD) or a barrier timed out: nothing is lost, the run is
+      // repeated on the multi-kernel path
+      if (getenv("LZ_DEBUG_TIMING")) fprintf(stderr, "[lz_run] small-problem engine gave up (status %u): multi-kernel path\n", status);
+      small = false;
+      LZ_TRY(basis_alloc(h, n, 1));
+      LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+    }
   }
   h->last_engine = small ? 1 : 0;
   if (one_reduce) LZ_TRY(run_loop_onereduce(h, n));

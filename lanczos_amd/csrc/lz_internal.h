@@ -132,16 +132,19 @@ struct SmallArgs {
   int rows, rows_pad, n;
   int64_t ldv;
   double* V;
+  const double* x0;  // scratch copy of the start vector (rows_pad doubles)
   double* y;     // SpMV output (the handle's r vector)
   double* drow;  // rows: V[j]_i * (A V[j])_i
   double* pc;    // n + 1: raw re-orthogonalisation sums [V_i . r (i < j), r . r]
   double* alpha;
   double* beta;
-  unsigned* bar;  // grid barrier counter (zeroed before the launch)
+  unsigned* bar;  // 4 zeroed words: [0] device-scope barrier, [1] XCD-local barrier, [2] status (0 ok, 2 placement, 3 barrier timeout)
+  unsigned* xcc;  // one word per participating block: the XCD it found itself on (+ 1)
+  unsigned long long zero;  // 0 (a run-time value: the addend of the L2-atomic "loads", see ld_sh)
 };
 
 constexpr int kSmallMaxPadRows = 1280;
 int small_grid(int rows_pad);
-hipError_t launch_small_run(const SmallArgs& a, int nb, hipStream_t s);
+hipError_t launch_small_run(const SmallArgs& a, int nb, bool local, hipStream_t s);
 
 }  // namespace lz

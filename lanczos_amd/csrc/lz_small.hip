@@ -27,32 +27,73 @@ constexpr int kSmallMaxParts = 1024; // alpha partials (k_final_sum takes them i
 
 namespace {
 
-// Monotonic-counter grid barrier.  Every block calls it the same number of times (all loop bounds are grid-uniform), so
-// every wave reaches the end of the kernel.  Release: the block's writes are made visible device-wide before its
-// arrival; acquire: caches are invalidated after the last arrival is seen.
-__device__ __forceinline__ void grid_sync(unsigned* bar, unsigned nb) {
+// Data that one block writes and OTHER blocks read within the kernel (they may sit on other XCDs, i.e. behind other,
+// mutually incoherent L2s):
+//   * rewritten every step (SpMV output y, per-row products, raw coefficient sums): written with agent-scope atomic stores
+//     (write-through to the memory side) and read with agent-scope atomic loads (served from there, past L1 and L2);
+//   * written once (a basis row): atomic stores, then PLAIN loads - no reader can hold a stale copy of a row that did not
+//     exist before (rows are 256-byte aligned; the start vector lives in a scratch vector, so row 0 is not read before
+//     step 0 writes it).
+// With that no cache has to be written back or invalidated at a barrier - the agent-scope release/acquire fences that
+// would do it (buffer_wbl2 / buffer_inv over a whole L2) cost ~8 us per barrier here, more than the kernel launches
+// the engine replaces.
+// LOCAL only changes WHERE the participating blocks run (all on one XCD); the accesses stay device-scope.  Tried and
+// measured (profiles/r02/small_engine.json): workgroup-scope atomics are served by the CU's own L1 outside threadgroup-
+// split mode (a polling load spins on a stale line: the bounded spin below turned that into a clean fallback, not a
+// hang), sc0 buffer loads likewise, L2 atomics used as loads (fetch_add 0) are coherent but serialise (tens of thousands
+// per step), release/acquire fences cost ~8 us per barrier.  Device-scope loads and write-through stores are the
+// cheapest correct protocol - ~2 us per dependent round trip, wherever the blocks sit.
+template <bool LOCAL>
+__device__ __forceinline__ double ld_sh(const double* base, int idx) {
+  return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LOCAL>
+__device__ __forceinline__ void st_sh(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Monotonic-counter grid barrier over the nb participating blocks.  Every participant calls it the same number of times
+// (all loop bounds are grid-uniform).  Each wave first waits for its own write-through stores to be acknowledged.  The
+// spin is BOUNDED: if the count is not reached within ~4 M polls the block gives up, flags the run as failed (the host
+// then repeats it on the multi-kernel path) and returns false - and so does, one by one, every other block, so the grid
+// always drains.
+template <bool LOCAL>
+__device__ __forceinline__ bool grid_sync(unsigned* bar, unsigned nb, unsigned* status, unsigned zero) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  __shared__ int ok_s;
   if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned old = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned target = (old / nb + 1u) * nb;
-    while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    __threadfence();
+    unsigned old, target, seen = 0;
+    old = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    target = (old / nb + 1u) * nb;
+    int ok = 0;
+    for (int it = 0; it < (1 << 22); ++it) {
+      seen = __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + zero;
+      if (seen >= target) {
+        ok = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) __hip_atomic_store(status, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok_s = ok;
   }
   __syncthreads();
+  return ok_s != 0;
 }
 
 // alpha = V[j] . (A V[j]) from the per-row products, by the partial-sum tree of the multi-kernel path:
 //   dense : k_gemv_dense   - blocks of 4 rows, part = (((0 + d0) + d1) + d2) + d3
 //   CSR   : k_spmv_stream / k_spmv_fixed - thread t of a row block adds its rows r0 + t + 256 q, block_sum over 4 waves
 //   then k_final_sum over the partials (1024 threads = 16 waves, one partial per thread, shuffle tree, 16 sequential adds).
+template <bool LOCAL>
 __device__ double small_alpha(const SmallArgs& a, double* parts, double* sm16) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (a.kind == 2) {
     for (int b = threadIdx.x; b < a.nparts; b += kTPB) {
       double t = 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) t += (4 * b + q < a.rows) ? a.drow[4 * b + q] : 0.0;
+      for (int q = 0; q < 4; ++q) t += (4 * b + q < a.rows) ? ld_sh<LOCAL>(a.drow, 4 * b + q) : 0.0;
       parts[b] = t;
     }
   } else {
@@ -63,7 +104,7 @@ __device__ double small_alpha(const SmallArgs& a, double* parts, double* sm16) {
       double t = 0.0;
       for (int vw = 0; vw < kTPB / 64; ++vw) {
         double d = 0.0;
-        for (int row = r0 + vw * 64 + lane; row < r1; row += kTPB) d += a.drow[row];
+        for (int row = r0 + vw * 64 + lane; row < r1; row += kTPB) d += ld_sh<LOCAL>(a.drow, row);
         t += wave_sum(d);  // lane 0: ((0 + s0) + s1) + s2) + s3
       }
       if (lane == 0) parts[b] = t;
@@ -84,55 +125,82 @@ __device__ double small_alpha(const SmallArgs& a, double* parts, double* sm16) {
 }
 
 // r = A V[j] on the rows dealt to this block, per-row products for alpha
-__device__ void small_spmv(const SmallArgs& a, const double* __restrict__ x) {
+template <bool LOCAL>
+__device__ void small_spmv(const SmallArgs& a, const double* __restrict__ x, int bid, int nb) {
   const int lane = threadIdx.x & 63;
   if (a.kind == 2) {
-    const int gw = blockIdx.x * (kTPB / 64) + (threadIdx.x >> 6), nw = gridDim.x * (kTPB / 64);
+    const int gw = bid * (kTPB / 64) + (threadIdx.x >> 6), nw = nb * (kTPB / 64);
     for (int row = gw; row < a.rows; row += nw) {
       const double acc = gemv_row_wave(a.dense + (int64_t)row * a.lda, x, a.rows, lane);
       if (lane == 0) {
-        a.y[row] = acc;
-        a.drow[row] = x[row] * acc;
+        st_sh<LOCAL>(a.y + row, acc);
+        st_sh<LOCAL>(a.drow + row, x[row] * acc);
       }
     }
   } else {
-    for (int row = blockIdx.x * kTPB + threadIdx.x; row < a.rows; row += gridDim.x * kTPB) {
+    for (int row = bid * kTPB + threadIdx.x; row < a.rows; row += nb * kTPB) {
       double sum = 0.0;
       for (int k = a.rowptr[row]; k < a.rowptr[row + 1]; ++k) sum += a.vals[k] * x[a.colidx[k]];  // SciPy's csr_matvec order
-      a.y[row] = sum;
-      a.drow[row] = x[row] * sum;
+      st_sh<LOCAL>(a.y + row, sum);
+      st_sh<LOCAL>(a.drow + row, x[row] * sum);
     }
   }
 }
 
 }  // namespace
 
+template <bool LOCAL>
 __global__ __launch_bounds__(kTPB) void k_small_run(SmallArgs a) {
   __shared__ double2 sw[kSmallMaxPad / 2 + 64];  // this block's copy of the residual r (all positions; + slack for masked-off steps)
   __shared__ double parts[kSmallMaxParts];
   __shared__ double sm16[16];
   __shared__ double selfw[kTPB / 64];
+  __shared__ double pcs[kSmallMaxPad];  // the raw coefficient sums of the current step
+  __shared__ int same_s;
+  // LOCAL: the grid has 8 x nb blocks and only every eighth takes part - workgroups are dealt to the 8 XCDs round-robin,
+  // so those nb blocks share one XCD and its L2.  That is verified before anything depends on it (over device-scope
+  // atomics): every participant publishes the XCC_ID it runs on; unless all are equal the run is flagged and left.
+  if (LOCAL && (blockIdx.x & 7) != 0) return;
+  const int bid = LOCAL ? blockIdx.x >> 3 : blockIdx.x;
+  const unsigned nb = LOCAL ? gridDim.x >> 3 : gridDim.x;
+  unsigned* bar_dev = a.bar;       // device-scope counter (placement handshake; every barrier when !LOCAL)
+  unsigned* bar = LOCAL ? a.bar + 1 : a.bar;
+  unsigned* status = a.bar + 2;
+  if (LOCAL) {
+    if (threadIdx.x == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // HW_REG_XCC_ID[3:0]
+      __hip_atomic_store(a.xcc + bid, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!grid_sync<false>(bar_dev, nb, status, 0u)) return;
+    if (threadIdx.x == 0) {
+      const unsigned first = __hip_atomic_load(a.xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int same = 1;
+      for (unsigned q = 1; q < nb; ++q) same &= __hip_atomic_load(a.xcc + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == first;
+      if (!same && bid == 0) __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      same_s = same;
+    }
+    __syncthreads();
+    if (!same_s) return;  // every participant read the same list: a uniform decision
+  }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned nb = gridDim.x;
   const int n = a.n, cnt2 = a.rows_pad >> 1;
   const int64_t ld2 = a.ldv >> 1;
   double2* V2 = reinterpret_cast<double2*>(a.V);
   // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r . v0; r = r - alpha0 v0
-  small_spmv(a, a.V);
-  grid_sync(a.bar, nb);
+  small_spmv<LOCAL>(a, a.x0, bid, (int)nb);  // the start vector's scratch copy: basis row 0 itself is not read before step 0 rewrites it
+  if (!grid_sync<LOCAL>(bar, nb, status, (unsigned)a.zero)) return;
   double beta_prev = 0.0;
   for (int j = -1; j < n; ++j) {
     // ---- alpha of the vector just multiplied (j == -1: the warm-up's v0), three-term recurrence into LDS
     const int vj = j < 0 ? 0 : j;
-    const double al = small_alpha(a, parts, sm16);
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.alpha[vj] = al;
+    const double al = small_alpha<LOCAL>(a, parts, sm16);
+    if (bid == 0 && threadIdx.x == 0) a.alpha[vj] = al;
     if (j == n - 1) break;  // the reference forms one more residual after the last alpha; nothing reads it
     {
-      const double2* y2 = reinterpret_cast<const double2*>(a.y);
-      const double2* v2 = V2 + (int64_t)vj * ld2;
+      const double2* v2 = j < 0 ? reinterpret_cast<const double2*>(a.x0) : V2 + (int64_t)vj * ld2;
       const double2* m2 = j > 0 ? V2 + (int64_t)(j - 1) * ld2 : nullptr;  // j == 0: the reference's V[-1] is the zero row
       for (int p = threadIdx.x; p < cnt2; p += kTPB) {
-        double2 x = y2[p];
+        double2 x = make_double2(ld_sh<LOCAL>(a.y, 2 * p), ld_sh<LOCAL>(a.y, 2 * p + 1));
         const double2 v = v2[p];
         x.x = x.x - v.x * al;
         x.y = x.y - v.y * al;
@@ -170,8 +238,8 @@ __global__ __launch_bounds__(kTPB) void k_small_run(SmallArgs a) {
     {
       const int li = lane & 3, blk = (lane >> 2) & 3, lk = lane >> 4;
       const int eoff = 8 * blk + 2 * lk;
-      const int gw = blockIdx.x * (kTPB / 64) + w, nw = nb * (kTPB / 64);
-      const int ntiles = (nrows + 7) >> 3;
+      const int gw = bid * (kTPB / 64) + w, nw = (int)nb * (kTPB / 64);
+      const int ntiles = jn > 0 ? (nrows + 7) >> 3 : 0;  // step 0: no rows yet (and basis row 0 must not be read, see ld_sh)
       for (int k = gw; k < ntiles; k += nw) {
         const int i0 = 8 * k;
         const double* rowp[2];
@@ -221,18 +289,20 @@ __global__ __launch_bounds__(kTPB) void k_small_run(SmallArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int row = i0 + 4 * t + lk;
-          if ((lane & 15) == 0 && row < nrows && row != jn) a.pc[row] = c[t];
+          if ((lane & 15) == 0 && row < nrows && row != jn) st_sh<LOCAL>(a.pc + row, c[t]);
         }
       }
     }
-    grid_sync(a.bar, nb);
+    if (!grid_sync<LOCAL>(bar, nb, status, (unsigned)a.zero)) return;
     // ---- pass 2: beta, V[jn] = 2 r/beta - sum_{i <= jn} c_i V[i]  (k_update_slice<FUSED, raw sums>: NumPy's order)
     const double bnorm = sqrt(rr);
     const int bidx = (jn + n - 2) % (n - 1);  // beta[jn - 1] with Python's negative index at jn = 0
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.beta[bidx] = bnorm;
+    if (bid == 0 && threadIdx.x == 0) a.beta[bidx] = bnorm;
+    for (int k = threadIdx.x; k < jn; k += kTPB) pcs[k] = ld_sh<LOCAL>(a.pc, k);
+    __syncthreads();
     {
       const double* sr = reinterpret_cast<const double*>(sw);
-      const int e = blockIdx.x * kTPB + threadIdx.x;  // one ELEMENT per thread: 64 basis rows in flight per lane
+      const int e = bid * kTPB + threadIdx.x;  // one ELEMENT per thread: 64 basis rows in flight per lane
       if (e < a.rows_pad) {
         const double wv = sr[e] / bnorm;
         double tx = 0.0;
@@ -245,34 +315,36 @@ __global__ __launch_bounds__(kTPB) void k_small_run(SmallArgs a) {
 #pragma unroll
           for (int u = 0; u < RU; ++u)
             if (k + u < nrows) {
-              double ck = (k + u == jn) ? rr : a.pc[k + u];
+              double ck = (k + u == jn) ? rr : pcs[k + u];
               ck = (k + u == jn) ? ck / (bnorm * bnorm) : ck / bnorm;
               tx = tx + ck * q[u];
             }
         }
-        a.V[(int64_t)jn * a.ldv + e] = 2.0 * wv - tx;
+        st_sh<LOCAL>(a.V + (int64_t)jn * a.ldv + e, 2.0 * wv - tx);
       }
     }
     beta_prev = bnorm;
-    grid_sync(a.bar, nb);
+    if (!grid_sync<LOCAL>(bar, nb, status, (unsigned)a.zero)) return;
     // ---- r = A V[jn], per-row products
-    small_spmv(a, a.V + (int64_t)jn * a.ldv);
-    grid_sync(a.bar, nb);
+    small_spmv<LOCAL>(a, a.V + (int64_t)jn * a.ldv, bid, (int)nb);
+    if (!grid_sync<LOCAL>(bar, nb, status, (unsigned)a.zero)) return;
   }
 }
 
-// blocks of the cooperative grid: enough waves for the dense rows / the update's elements, few enough for a cheap barrier
+// participating blocks: one per CU of the one XCD they share (32 CUs; the cooperative grid of 8 x 32 blocks is the most
+// this kernel's registers allow) - every phase is a latency chain per wave (a dense row, an 8-row tile, an element's walk
+// over the basis), so what counts is the number of waves
 int small_grid(int rows_pad) {
-  int nb = (rows_pad + kTPB - 1) / kTPB;  // the update needs one thread per element
-  if (nb < 16) nb = 16;
-  if (nb > 64) nb = 64;
-  return nb;
+  (void)rows_pad;
+  return 32;
 }
 
-hipError_t launch_small_run(const SmallArgs& a, int nb, hipStream_t s) {
+// local: nb participants out of a grid of 8 nb blocks (one XCD); else a grid of nb blocks with device-scope coherence
+hipError_t launch_small_run(const SmallArgs& a, int nb, bool local, hipStream_t s) {
   SmallArgs copy = a;
   void* args[] = {&copy};
-  return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_small_run), dim3(nb), dim3(kTPB), args, 0, s);
+  if (local) return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_small_run<true>), dim3(8 * nb), dim3(kTPB), args, 0, s);
+  return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_small_run<false>), dim3(nb), dim3(kTPB), args, 0, s);
 }
 
 }  // namespace lz

@@ -40,6 +40,7 @@ struct PbDev {
   int cap = 0;                 // products per row block
   int64_t nnz = 0;
   int32_t* rbptr = nullptr;    // nRB + 1 row-block boundaries
+  int4* rbhead = nullptr;      // nRB: {first row, rows, first entry, entries} of every row block
   int32_t* cbptr = nullptr;    // nCB + 1: T range of each column block
   int32_t* toff = nullptr;     // [nRB][nCB]: T offset of tile (cb, rb)
   uint16_t* lstart = nullptr;  // [nRB][nCB + 1]: LDS slot where tile (rb, cb) starts in phase 2
@@ -167,38 +168,38 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
 // timing ablations of profiles/r02/ablate_pb_rows_and_ritz.json showed 850 of its 1060 us left with every other access
 // removed).  Two workgroups per CU (cap = 7168 products: 56 + 14 + 3 KiB of LDS) overlap each other's round trips.
 template <int GS, int TPG, int ABL = 0>  // lanes that copy one tile together; tiles per lane group and trip; ABL: kernel-bench build only
-__global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restrict__ rbptr, const int32_t* __restrict__ rowptr,
-                                                       const int32_t* __restrict__ toff, const uint16_t* __restrict__ lstart,
-                                                       const uint16_t* __restrict__ perm, const double* __restrict__ T, int nCB, int cap,
-                                                       const double* __restrict__ xown, double* __restrict__ y,
-                                                       double* __restrict__ part) {
-  extern __shared__ double seg[];  // cap products, the tile table, cap perm entries
+__global__ __launch_bounds__(kPbThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: two workgroups per CU
+void k_pb_rows(const int4* __restrict__ rbhead, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ toff,
+               const uint16_t* __restrict__ lstart, const uint16_t* __restrict__ perm, const double* __restrict__ T, int nCB, int cap,
+               const double* __restrict__ xown, double* __restrict__ y, double* __restrict__ part) {
+  extern __shared__ double seg[];  // cap products, cap perm entries
   __shared__ double red[kPbThreads / 64];
-  int* to_s = reinterpret_cast<int*>(seg + cap);
-  uint16_t* ls_s = reinterpret_cast<uint16_t*>(to_s + nCB);
-  uint16_t* perm_s = ls_s + ((nCB + 2) & ~1);
+  uint16_t* perm_s = reinterpret_cast<uint16_t*>(seg + cap);
   const int rb = blockIdx.x;
-  {
-    const int32_t* to = toff + (int64_t)rb * nCB;
-    const uint16_t* ls = lstart + (int64_t)rb * (nCB + 1);
-    for (int c = threadIdx.x; c < nCB; c += kPbThreads) to_s[c] = __builtin_nontemporal_load(to + c);
-    for (int c = threadIdx.x; c <= nCB; c += kPbThreads) ls_s[c] = __builtin_nontemporal_load(ls + c);
+  const int4 hd = rbhead[rb];  // {first row, rows, first entry, entries}: one (scalar) load instead of a chain of four
+  const int r0 = hd.x, r1 = hd.x + hd.y, k0 = hd.z, cnt = hd.w;
+  // ---- round trip 1: everything whose address is known now
+  constexpr int NG = kPbThreads / GS, S = 3;
+  const int g = threadIdx.x / GS, l = threadIdx.x % GS;
+  const int32_t* to = toff + (int64_t)rb * nCB;
+  const uint16_t* ls = lstart + (int64_t)rb * (nCB + 1);
+  int off[TPG], a[TPG], len[TPG];
+#pragma unroll
+  for (int q = 0; q < TPG; ++q) {  // this lane group's tiles of the first (for nCB <= TPG * NG: the only) trip
+    const int cb = g + q * NG;
+    const bool ok = cb < nCB;
+    off[q] = ok ? __builtin_nontemporal_load(to + cb) : 0;
+    a[q] = ok ? __builtin_nontemporal_load(ls + cb) : 0;
+    len[q] = ok ? __builtin_nontemporal_load(ls + cb + 1) - a[q] : 0;
   }
-  const int r0 = rbptr[rb], r1 = rbptr[rb + 1];
-  const int k0 = rowptr[r0], cnt = rowptr[r1] - k0;
-  // this thread's first row (row blocks hold <= kPbMaxRows rows: the others are handled after the barrier)
   const int row = r0 + threadIdx.x;
   int ka = 0, kb = 0;
+  double xo = 0.0;
   if (row < r1) {
     ka = rowptr[row] - k0;
     kb = rowptr[row + 1] - k0;
+    xo = xown[row];
   }
-  __syncthreads();
-  // Tile lengths scatter around their mean (Poisson): every lane takes THREE slots of a tile (t = l, l + GS, l + 2 GS),
-  // all loads of a trip issued before the first LDS store - a tile longer than 3 GS (1e-4 of them) takes the slow loop.
-  constexpr int NG = kPbThreads / GS, S = 3;
-  const int g = threadIdx.x / GS, l = threadIdx.x % GS;
-  // the perm segment rides in the same round trip (8 coalesced 2-byte loads per thread at cap = 8192)
   constexpr int PP = 8;
   uint16_t pp[PP];
 #pragma unroll
@@ -206,17 +207,11 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restric
     const int i = threadIdx.x + q * kPbThreads;
     pp[q] = (!(ABL & 2) && i < cnt) ? __builtin_nontemporal_load(perm + k0 + i) : (uint16_t)(i & 1023);
   }
-  for (int cb0 = g; cb0 < nCB; cb0 += TPG * NG) {
-    int off[TPG], a[TPG], len[TPG];
+  // ---- round trip 2: the product runs.  Tile lengths scatter around their mean (Poisson): every lane takes THREE slots of
+  // a tile (t = l, l + GS, l + 2 GS), all loads issued before the first LDS store; a tile longer than 3 GS (1e-4 of them)
+  // takes the slow loop.
+  for (int cb0 = g;; cb0 += TPG * NG) {
     double v[TPG][S];
-#pragma unroll
-    for (int q = 0; q < TPG; ++q) {
-      const int cb = cb0 + q * NG;
-      const bool ok = cb < nCB;
-      off[q] = ok ? to_s[cb] : 0;
-      a[q] = ok ? ls_s[cb] : 0;
-      len[q] = ok ? ls_s[cb + 1] - a[q] : 0;
-    }
 #pragma unroll
     for (int q = 0; q < TPG; ++q)
 #pragma unroll
@@ -228,6 +223,15 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restric
         if (l + u * GS < len[q]) seg[a[q] + l + u * GS] = v[q][u];
       for (int t = l + S * GS; t < len[q]; t += GS) seg[a[q] + t] = __builtin_nontemporal_load(T + off[q] + t);
     }
+    if (cb0 + TPG * NG >= nCB) break;
+#pragma unroll
+    for (int q = 0; q < TPG; ++q) {  // more column blocks than one trip covers (wide matrices): next trip's table entries
+      const int cb = cb0 + TPG * NG + q * NG;
+      const bool ok = cb < nCB;
+      off[q] = ok ? to[cb] : 0;
+      a[q] = ok ? ls[cb] : 0;
+      len[q] = ok ? ls[cb + 1] - a[q] : 0;
+    }
   }
 #pragma unroll
   for (int q = 0; q < PP; ++q) {
@@ -236,15 +240,17 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restric
   }
   for (int i = threadIdx.x + PP * kPbThreads; i < cnt; i += kPbThreads) perm_s[i] = perm[k0 + i];  // cap > 8192 only
   __syncthreads();
+  // ---- sums: both operands in LDS, CSR order, one rounding per add
   double d = 0.0;
   for (int rw = row; rw < r1; rw += kPbThreads) {  // one row per thread, except in row blocks of many short rows
     if (rw != row) {
       ka = rowptr[rw] - k0;
       kb = rowptr[rw + 1] - k0;
+      xo = xown[rw];
     }
     double sum = 0.0;
     int k = ka;
-    for (; k + 4 <= kb; k += 4) {  // four LDS gathers in flight; the adds stay in CSR order, one rounding each
+    for (; k + 4 <= kb; k += 4) {  // four LDS gathers in flight
       const double p0 = (ABL & 4) ? 1.0 : seg[perm_s[k]], p1 = (ABL & 4) ? 1.0 : seg[perm_s[k + 1]], p2 = (ABL & 4) ? 1.0 : seg[perm_s[k + 2]],
                    p3 = (ABL & 4) ? 1.0 : seg[perm_s[k + 3]];
       sum += p0;
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int32_t* __restric
     }
     for (; k < kb; ++k) sum += (ABL & 4) ? 1.0 : seg[perm_s[k]];
     y[rw] = sum;
-    d += xown[rw] * sum;
+    d += xo * sum;
   }
   d = wave_sum(d);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
@@ -280,6 +286,7 @@ hipError_t pb_alloc(T*& p, size_t count) {
 void pb_free(PbDev*& pb) {
   if (!pb) return;
   hipFree(pb->rbptr);
+  hipFree(pb->rbhead);
   hipFree(pb->cbptr);
   hipFree(pb->toff);
   hipFree(pb->lstart);
@@ -328,6 +335,11 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   };
   int32_t* tot = nullptr;
   chk(pb_alloc(pb->rbptr, (size_t)nRB + 1));
+  chk(pb_alloc(pb->rbhead, (size_t)nRB));
+  std::vector<int4> head((size_t)nRB);
+  for (int b = 0; b < nRB; ++b)
+    head[(size_t)b] = make_int4(rb[(size_t)b], rb[(size_t)b + 1] - rb[(size_t)b], rowptr_host[rb[(size_t)b]], rowptr_host[rb[(size_t)b + 1]] - rowptr_host[rb[(size_t)b]]);
+  if (e == hipSuccess) chk(hipMemcpyAsync(pb->rbhead, head.data(), head.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   chk(pb_alloc(pb->cbptr, (size_t)nCB + 1));
   chk(pb_alloc(pb->toff, (size_t)nRB * nCB));
   chk(pb_alloc(pb->lstart, (size_t)nRB * (nCB + 1)));
@@ -360,7 +372,7 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   }
   hipFree(tot);
   pb->wide_runs = (double)pb->nnz / ((double)nRB * (double)nCB) > 20.0;
-  pb->lds2 = (size_t)cap * sizeof(double) + (size_t)nCB * sizeof(int) + ((size_t)nCB + 4) * sizeof(uint16_t) + (size_t)cap * sizeof(uint16_t);
+  pb->lds2 = (size_t)cap * sizeof(double) + (size_t)cap * sizeof(uint16_t);
   // both phases may need more than the default 64 KiB of dynamic LDS: allowed once per kernel, here, so that the
   // launches themselves have no failure mode
   if (e == hipSuccess && pb->lds2 > 160 * 1024) e = hipErrorInvalidValue;  // only with thousands of column blocks AND the large tile
@@ -388,7 +400,7 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
 #ifdef LZ_KBENCH  // timing-only ablation arms (wrong results): 1 no product loads, 2 no perm loads, 4 no LDS gathers
   if (A.ablation && !pb->wide_runs) {
     auto go = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T, pb->nCB,
+      hipLaunchKernelGGL(kern, dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbhead, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T, pb->nCB,
                          pb->cap, x_own, y, part);
     };
     switch (A.ablation) {
@@ -403,10 +415,10 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
   }
 #endif
   if (pb->wide_runs)
-    hipLaunchKernelGGL((k_pb_rows<16, 4>), dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm,
+    hipLaunchKernelGGL((k_pb_rows<16, 4>), dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbhead, A.rowptr, pb->toff, pb->lstart, pb->perm,
                        pb->T, pb->nCB, pb->cap, x_own, y, part);
   else
-    hipLaunchKernelGGL((k_pb_rows<8, 4>), dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbptr, A.rowptr, pb->toff, pb->lstart, pb->perm,
+    hipLaunchKernelGGL((k_pb_rows<8, 4>), dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbhead, A.rowptr, pb->toff, pb->lstart, pb->perm,
                        pb->T, pb->nCB, pb->cap, x_own, y, part);
   return pb->nRB;
 }
