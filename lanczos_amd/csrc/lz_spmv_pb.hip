@@ -23,6 +23,7 @@
 // gets inside its (row block, column block) tile depends on atomic order, which is harmless: `perm` is a bijection onto
 // the tile whatever that order is, so every run produces the same bits.
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 #include "lz_device.h"
@@ -167,6 +168,14 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
 // inside the sum loop, and the workgroup then lived as long as its longest row's chain of dependent loads (45 us; the
 // timing ablations of profiles/r02/ablate_pb_rows_and_ritz.json showed 850 of its 1060 us left with every other access
 // removed).  Two workgroups per CU (cap = 7168 products: 56 + 14 + 3 KiB of LDS) overlap each other's round trips.
+__device__ unsigned long long g_pb_dbg[8];  // kernel-bench build: per-phase wall-clock sums (ABL & 16), 10 ns ticks
+#define LZ_PB_STAMP(i)                                                                                   \
+  if (ABL & 16) {                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+    const unsigned long long tn_ = wall_clock64();                                                       \
+    if (threadIdx.x == 0) atomicAdd(&g_pb_dbg[i], tn_ - tprev_);                                         \
+    tprev_ = tn_;                                                                                        \
+  }
 template <int GS, int TPG, int ABL = 0>  // lanes that copy one tile together; tiles per lane group and trip; ABL: kernel-bench build only
 __global__ __launch_bounds__(kPbThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))  // <= 64 VGPRs: two workgroups per CU
 void k_pb_rows(const int4* __restrict__ rbhead, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ toff,
@@ -176,8 +185,13 @@ void k_pb_rows(const int4* __restrict__ rbhead, const int32_t* __restrict__ rowp
   __shared__ double red[kPbThreads / 64];
   uint16_t* perm_s = reinterpret_cast<uint16_t*>(seg + cap);
   const int rb = blockIdx.x;
+  unsigned long long tprev_ = (ABL & 16) ? wall_clock64() : 0ull;
   const int4 hd = rbhead[rb];  // {first row, rows, first entry, entries}: one (scalar) load instead of a chain of four
   const int r0 = hd.x, r1 = hd.x + hd.y, k0 = hd.z, cnt = hd.w;
+  if (ABL & 8) {  // kernel-bench arm: nothing but the dispatch of the workgroup
+    if (cnt == -12345) part[rb] = 0.0;
+    return;
+  }
   // ---- round trip 1: everything whose address is known now
   constexpr int NG = kPbThreads / GS, S = 3;
   const int g = threadIdx.x / GS, l = threadIdx.x % GS;
@@ -207,6 +221,7 @@ void k_pb_rows(const int4* __restrict__ rbhead, const int32_t* __restrict__ rowp
     const int i = threadIdx.x + q * kPbThreads;
     pp[q] = (!(ABL & 2) && i < cnt) ? __builtin_nontemporal_load(perm + k0 + i) : (uint16_t)(i & 1023);
   }
+  LZ_PB_STAMP(0)  // round trip 1 complete (tables, row bounds, x_own, perm)
   // ---- round trip 2: the product runs.  Tile lengths scatter around their mean (Poisson): every lane takes THREE slots of
   // a tile (t = l, l + GS, l + 2 GS), all loads issued before the first LDS store; a tile longer than 3 GS (1e-4 of them)
   // takes the slow loop.
@@ -239,7 +254,9 @@ void k_pb_rows(const int4* __restrict__ rbhead, const int32_t* __restrict__ rowp
     if (i < cnt) perm_s[i] = pp[q];
   }
   for (int i = threadIdx.x + PP * kPbThreads; i < cnt; i += kPbThreads) perm_s[i] = perm[k0 + i];  // cap > 8192 only
+  LZ_PB_STAMP(1)  // round trip 2 complete, LDS filled
   __syncthreads();
+  LZ_PB_STAMP(2)  // barrier
   // ---- sums: both operands in LDS, CSR order, one rounding per add
   double d = 0.0;
   for (int rw = row; rw < r1; rw += kPbThreads) {  // one row per thread, except in row blocks of many short rows
@@ -262,6 +279,7 @@ void k_pb_rows(const int4* __restrict__ rbhead, const int32_t* __restrict__ rowp
     y[rw] = sum;
     d += xo * sum;
   }
+  LZ_PB_STAMP(3)  // sums + y store
   d = wave_sum(d);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
   __syncthreads();
@@ -271,6 +289,7 @@ void k_pb_rows(const int4* __restrict__ rbhead, const int32_t* __restrict__ rowp
     for (int i = 0; i < kPbThreads / 64; ++i) t += red[i];
     part[rb] = t;
   }
+  LZ_PB_STAMP(4)  // block reduction
 }
 
 template <class T>
@@ -409,6 +428,21 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
       case 3: go(k_pb_rows<8, 4, 3>); break;
       case 4: go(k_pb_rows<8, 4, 4>); break;
       case 7: go(k_pb_rows<8, 4, 7>); break;
+      case 8: go(k_pb_rows<8, 4, 8>); break;
+      case 16: {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pb_dbg), z, sizeof z, 0, hipMemcpyHostToDevice, s);
+        go(k_pb_rows<8, 4, 16>);
+        hipMemcpyFromSymbolAsync(z, HIP_SYMBOL(g_pb_dbg), sizeof z, 0, hipMemcpyDeviceToHost, s);
+        hipStreamSynchronize(s);
+        fprintf(stderr, "[k_pb_rows phases, us per workgroup (wave 0)] rt1 %.2f  rt2+lds %.2f  barrier %.2f  sums %.2f  reduce %.2f  (%d workgroups)\n",
+                z[0] * 0.01 / pb->nRB, z[1] * 0.01 / pb->nRB, z[2] * 0.01 / pb->nRB, z[3] * 0.01 / pb->nRB, z[4] * 0.01 / pb->nRB, pb->nRB);
+        break;
+      }
+      case 9: hipLaunchKernelGGL((k_pb_rows<8, 4, 8>), dim3(pb->nRB), dim3(kPbThreads), 0, s, pb->rbhead, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T, pb->nCB,
+                                 pb->cap, x_own, y, part); break;  // ... without the 72 KiB of LDS
+      case 10: hipLaunchKernelGGL((k_pb_rows<8, 4, 8>), dim3(pb->nRB * 4), dim3(256), 0, s, pb->rbhead, A.rowptr, pb->toff, pb->lstart, pb->perm, pb->T, pb->nCB,
+                                  pb->cap, x_own, y, part); break;  // ... as four times as many 256-thread workgroups
       default: go(k_pb_rows<8, 4>); break;
     }
     return pb->nRB;

@@ -78,8 +78,7 @@ def _two_phase_matrices():
 @pytest.mark.parametrize("name", ["graph_5000", "ragged_3000", "longrow_9000", "empty_rows", "lap2d_37x29", "lap2d_400x300",
                                   "graph_60000", "graph_60000_real", "row_too_long"])
 def test_spmv_two_phase_bit_exact(hip, name):
-    """The column-blocked two-phase SpMV (lz_spmv_pb.hip; auto-selected for matrices without column locality, forced here
-    with tuning knob 14 = 2): products staged through a column-block-major buffer, every row summed out of LDS in CSR
+    """The column-blocked two-phase SpMV (lz_spmv_pb.hip; opt-in with tuning knob 14 = 2): products staged through a column-block-major buffer, every row summed out of LDS in CSR
     order - bit-identical to SciPy's csr_matvec, including rows of up to 15360 entries."""
     H = MATS[name] if name in MATS else _two_phase_matrices()[name]
     M = H.shape[0]
@@ -117,7 +116,7 @@ def test_two_phase_spmv_in_the_run_loop(hip):
     v0 = synthetic.reference_start_vector(M)
     v0 /= np.linalg.norm(v0)
     out = []
-    for knob in (1, 2):
+    for knob in (0, 2):
         h = hip.Handle(0)
         h.set_tuning(14, knob)
         h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
