@@ -107,7 +107,7 @@ int lz_set_options(lz_handle h, int flags);
  * value-th iteration of lz_run, 8: update-kernel variant (1 cached loads, 2 one position per lane, 3/4/5 slice owner with
  * 8/4/1 positions per lane), 11: two-sided links (2 = single launch), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
  * fresh basis allocation before the required parts are cleared (test knob), 14: 2 = build and use the column-blocked
- * two-phase SpMV kernels (opt-in experiment for matrices without column locality), 10: its products per row block, 15: small-problem engine (0 off, 2 on, 3 on with a plain grid)); they take effect
+ * two-phase SpMV kernels (opt-in experiment for matrices without column locality), 10: its products per row block, 15: small problems (0 fused-launch path, 1 plain six-launch path, 2 one-kernel engine, 3 engine on a plain grid)); they take effect
  * at the next lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order.  The
  * timing-only ablation arms (knob 1 values >= 20, knob 3) exist only in the kernel-bench build (make KBENCH=1,
  * liblanczos_kbench.so, tools/kbench.py); this library returns LZ_ERR_ARG for them. */
@@ -222,10 +222,11 @@ int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
 int lz_last_sweeps(lz_handle h, int* sweeps);
-/* 1 if the last lz_run ran as ONE cooperative kernel (small-problem engine, lz_small.hip: rows <= 1280 on one rank in
- * fused-norm mode - the size of the reference's own scripts 1Dbox.py / 1Ddeuteron.py and of config C1; three grid
- * barriers per step instead of six launches, results bit-identical to the multi-kernel path), else 0.  The engine is an
- * opt-in experiment (lz_set_tuning(h, 15, 2)): on MI355X it is not faster than the launches it replaces. */
+/* How the last lz_run was executed.  0: six launches per step.  2: the fused-launch path of small problems (a vector of at
+ * most eight pass-1 slices, one rank, fused-norm mode): the second-stage reductions and the three-term recurrence ride
+ * in the prologue of their consumer kernels - three launches per step, bit-identical results; lz_set_tuning(h, 15, 1)
+ * switches it off.  1: the opt-in one-kernel engine (lz_small.hip, lz_set_tuning(h, 15, 2): rows <= 1280; correct and
+ * bit-identical, but on MI355X no faster than the launches it replaces - DESIGN.md section 4). */
 int lz_last_engine(lz_handle h, int* engine);
 
 /* ---- single steps (unit parity tests drive the kernels one by one) ------ */

@@ -466,10 +466,11 @@ class Handle:
         return k.value
 
     def last_engine(self):
-        """"small" if the last run went through the one-kernel small-problem engine, else "kernels"."""
+        """"kernels": six launches per step; "fused": the three-launch path of small problems (second-stage reductions
+        and the three-term recurrence folded into their consumer kernels); "small": the opt-in one-kernel engine."""
         k = C.c_int()
         self.check(self.lib.lz_last_engine(self._h, C.byref(k)))
-        return "small" if k.value else "kernels"
+        return ("kernels", "small", "fused")[k.value]
 
     def timings(self):
         t = LzTimings()

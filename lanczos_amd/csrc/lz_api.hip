@@ -419,7 +419,7 @@ double spmv_flops(lz_handle h) { return h->kind == 1 ? 2.0 * h->csr.nnz : 2.0 * 
 
 // r = A V[j]; alpha_dst[0] = V[j] . r, summed over ranks unless reduce == false (one-reduce mode: the partial sum rides
 // in the next all-reduce)
-int step_spmv(lz_handle h, int j, double* alpha_dst = nullptr, bool reduce = true) {
+int step_spmv(lz_handle h, int j, double* alpha_dst = nullptr, bool reduce = true, int* np_out = nullptr) {
   if (!alpha_dst) alpha_dst = h->d_alpha + j;
   const double* x = nullptr;
   if (h->halo_inflight_j == j) {  // exchange already issued on the comm stream behind the boundary update
@@ -438,6 +438,10 @@ int step_spmv(lz_handle h, int j, double* alpha_dst = nullptr, bool reduce = tru
     else
       np = launch_gemv_dense(h->d_dense, h->rows, h->ncols_ext, h->dense_lda, x, xown, h->d_r, h->d_part, h->stream);
     LZ_TRY(check_launch(h, "spmv"));
+  }
+  if (np_out) {  // fused small-problem mode: the consumer kernel adds the block partials itself
+    *np_out = np;
+    return LZ_OK;
   }
   {
     Scope sc(h, LZ_K_FINAL, 0, 0);
@@ -594,6 +598,55 @@ int run_loop_onereduce(lz_handle h, int n) {
       launch_three_term(h->d_r, h->d_V + (int64_t)(j - 1) * h->ldv, nullptr, h->d_beta + bidx, nullptr, h->rows_pad, h->d_part, h->stream);
       LZ_TRY(check_launch(h, "three_term(beta)"));  // r'' = A V[j] - beta V[j-1]; at j = 0 the reference's V[-1] is the zero row
     }
+  }
+  return LZ_OK;
+}
+
+// ---- small problems: three launches per step instead of six ---------------------------------------------------------------
+// When a vector is a handful of pass-1 slices, every kernel of a step does microseconds of work and the step costs what
+// its six dependent launches cost.  Here the two second-stage reductions and the three-term recurrence ride in the
+// prologue of their consumer: [pass 1: alpha from the SpMV's block partials, r = (y - alpha v) - beta v', stage, dots]
+// [pass 2: coefficients from pass 1's block partials, update] [SpMV].  Same arithmetic, same summation trees: bit-identical
+// to the six-launch path (tests/test_gpu_small.py).
+inline size_t fused_coff(lz_handle h) {  // where pass 1's partials start in d_part (behind the SpMV's alpha partials)
+  const size_t npmax = std::max<size_t>((size_t)h->rows / 4 + 2, (size_t)std::max(h->csr.n_rowblk, 1)) + 64;
+  return (npmax + 63) / 64 * 64;
+}
+
+int run_loop_fused_small(lz_handle h, int n) {
+  const double M = (double)h->rows;
+  const size_t coff = fused_coff(h);
+  int np = 0;
+  LZ_TRY(step_spmv(h, 0, nullptr, false, &np));  // warm-up: y = A v0 (Lanczos.py:108)
+  for (int j = 0; j < n; ++j) {
+    const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+    h->prof_iter = (j % pstride) == pstride / 2;
+    const int bidx = (j + n - 2) % (n - 1);
+    QtwFuse fz;
+    fz.apart = h->d_part;
+    fz.np = np;
+    fz.jprev = j > 0 ? j - 1 : 0;   // j == 0: the warm-up's alpha0 and r = A v0 - alpha0 v0 (Lanczos.py:109-110)
+    fz.jprev2 = j >= 2 ? j - 2 : -1;  // the reference's V[-1] term at its step 0 is the zero row
+    fz.beta_prev = h->d_beta + (j >= 2 ? j - 2 : 0);
+    fz.alpha_out = h->d_alpha + fz.jprev;
+    h->qplan.variant = 0;
+    {
+      Scope sc(h, LZ_K_QTW, 8.0 * j * M + 40.0 * M, 2.0 * (j + 1) * M + 4.0 * M);
+      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_r, nullptr, nullptr, h->qplan, h->d_part + coff, 4, h->stream, &fz));
+      LZ_TRY(check_launch(h, "qtw(fused three-term)"));
+    }
+    {
+      Scope sc(h, LZ_K_UPDATE, 8.0 * j * M + 16.0 * M, 2.0 * (j + 1) * M);
+      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_part + coff, h->d_r, h->d_beta + bidx, 0, h->stream, 0, -1, 2, 0, 0, h->qplan.G,
+                    qtw_ldp(j + 1));
+      LZ_TRY(check_launch(h, "update(fused reduction)"));
+    }
+    LZ_TRY(step_spmv(h, j, nullptr, false, &np));
+  }
+  {
+    Scope sc(h, LZ_K_FINAL, 0, 0);
+    launch_final_sum(h->d_part, np, h->d_alpha + (n - 1), h->stream);  // the last alpha has no consumer kernel to ride in
+    LZ_TRY(check_launch(h, "final_sum(alpha)"));
   }
   return LZ_OK;
 }
@@ -1206,6 +1259,7 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
   h->qplan = plan_qtw(h->rows_pad, h->flags, h->tune, n);
   size_t need = (size_t)(n + 16) * (size_t)h->qplan.P;
   if (h->flags & LZ_FLAG_ONE_REDUCE) need = (size_t)2 * qtw_ldp(n + 2) * (size_t)h->qplan.P;
+  if (h->qplan.G <= 8) need = std::max<size_t>(need, fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G);  // fused small-problem path
   need = std::max<size_t>(need, 4096);
   need = std::max<size_t>(need, (size_t)(h->rows / 4 + 64));                     // dense gemv / scalar spmv partials
   need = std::max<size_t>(need, (size_t)h->csr.n_rowblk + 64);
@@ -1401,6 +1455,15 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     }
   }
   h->last_engine = small ? 1 : 0;
+  // fused-launch path for small problems (tune[15] == 1 switches it off): see run_loop_fused_small
+  const bool fsmall = !small && h->tune[15] == 0 && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
+                      !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->qplan.family == 2 && h->qplan.G <= 8 &&
+                      h->tune[1] == 0 && h->tune[8] == 0 && h->part_cap >= fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G;
+  if (fsmall) {
+    LZ_TRY(run_loop_fused_small(h, n));
+    h->last_engine = 2;
+    small = true;  // (skips the six-launch loop below)
+  }
   if (one_reduce) LZ_TRY(run_loop_onereduce(h, n));
   // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
   if (!one_reduce && !small) LZ_TRY(step_spmv(h, 0));

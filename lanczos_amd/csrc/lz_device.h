@@ -71,6 +71,34 @@ __device__ __forceinline__ int2 ld_stream(const int2* p) {
 }
 
 
+// out = sum(part[0..n)) with EXACTLY the grouping of k_final_sum (1024 threads: four strided accumulators per thread,
+// wave shuffle tree, 16 wave sums added in order), evaluated by a 256-thread block: every real thread plays four of the
+// 1024 virtual ones.  Used where a consumer kernel folds the second-stage reduction into its prologue (small problems:
+// one launch less per reduction, same bits).  sm16: 16 doubles of LDS.  Every thread returns the sum.
+__device__ __forceinline__ double final_sum_emulated(const double* __restrict__ part, int n, double* sm16) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int FT = 1024;
+  for (int vw = w; vw < FT / 64; vw += kTPB / 64) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int i = vw * 64 + lane;
+    for (; i + 3 * FT < n; i += 4 * FT) {
+      a0 += part[i];
+      a1 += part[i + FT];
+      a2 += part[i + 2 * FT];
+      a3 += part[i + 3 * FT];
+    }
+    for (; i < n; i += FT) a0 += part[i];
+    const double acc = wave_sum((a0 + a1) + (a2 + a3));
+    if (lane == 0) sm16[vw] = acc;
+  }
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int k = 0; k < FT / 64; ++k) t += sm16[k];
+  __syncthreads();
+  return t;
+}
+
 // One wave, one dense row (row-major, 16-byte aligned): 16-byte non-temporal loads of the row, x through L1/L2, four
 // independent accumulators per lane, wave-shuffle reduction; the sum is valid in lane 0.  Shared by k_gemv_dense and the
 // small-problem engine (lz_small.hip) - the SAME arithmetic, so both produce the same bits.

@@ -77,14 +77,27 @@ struct QtwPlan {
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max);
 // pass 1 of the re-orthogonalisation (+ optional v_j = r / sqrt(nrm2)):
 //   part[i*G + b] = sum_{m in block b} V[i][m] * V[j][m],  i in [0, nrows)
+// Fused small-problem mode of pass 1 (mode 4): the kernel's prologue finishes the previous step itself - alpha from the
+// SpMV's block partials (k_final_sum's grouping), r = (y - alpha v_prev) - beta v_prev2 on its own slice - before it
+// stages and dots r.  Three launches per Lanczos step instead of six, same bits.
+struct QtwFuse {
+  const double* apart = nullptr;  // alpha partials of the SpMV that produced y
+  int np = 0;
+  int jprev = 0, jprev2 = -1;     // basis rows of v_prev (the vector just multiplied) and v_prev2 (-1: none)
+  const double* beta_prev = nullptr;
+  double* alpha_out = nullptr;
+};
 // returns the error of the per-kernel LDS-limit raise (hipFuncSetAttribute), if that was needed and failed
 hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                      double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s);
+                      double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s, const QtwFuse* fuse = nullptr);
 // pass 2: V[j] = 2 V[j] - sum_{i<nrows} c[i] V[i] (sequential, unfused: bitwise NumPy order)
 // raw_c (fused mode only): c holds the reduced sums, beta = sqrt(c[j]) is formed and stored by the kernel itself
+// raw_c == 2 (fused small-problem mode): c points at pass 1's block partials, cG runs of cldp doubles; the kernel adds
+// them in k_final_rows_t's order itself
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
                    double* beta, int variant, hipStream_t s, int64_t pos_lo = 0, int64_t pos_hi = -1, int raw_c = 0,
-                   int64_t pos_lo_b = 0, int64_t pos_hi_b = 0);  // second range: only with the small-range (face) kernel
+                   int64_t pos_lo_b = 0, int64_t pos_hi_b = 0,  // second range: only with the small-range (face) kernel
+                   int cG = 0, int cldp = 0);
 void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s);
 void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s);
 void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, hipStream_t s);

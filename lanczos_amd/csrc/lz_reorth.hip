@@ -323,7 +323,7 @@ template <int SCALE, int U, int T, int ABL = 0>  // ABL: timing-only ablation ar
 __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                    const double* __restrict__ r, const double* __restrict__ nrm2,
                                                    double* __restrict__ beta_slot, int64_t L, int ldp,
-                                                   double* __restrict__ part) {
+                                                   double* __restrict__ part, QtwFuse fz) {
   extern __shared__ double2 sw[];
   // Per-wave coefficients are parked in LDS (after the slice of w) and written when the wave is done, as one contiguous
   // run part[pid][0..nrows): 8-byte partial stores trickling into the read stream cost 6 % of the pass
@@ -340,6 +340,44 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
     qtw_stage_two(r, V + (int64_t)j * ldv, base, cnt >> 1, sw, sw + (L >> 1), self3);
 #pragma unroll
     for (int q = 0; q < 3; ++q) self3[q] = wave_sum(self3[q]);
+  } else if constexpr (SCALE == 4) {
+    // fused small-problem mode: finish the previous step here (see QtwFuse), then stage and dot r like SCALE == 2
+    __shared__ double sm16[16];
+    const double al = final_sum_emulated(fz.apart, fz.np, sm16);
+    if (blockIdx.x == 0 && threadIdx.x == 0) fz.alpha_out[0] = al;
+    const double be = fz.jprev2 >= 0 ? fz.beta_prev[0] : 0.0;
+    double2* y2 = reinterpret_cast<double2*>(const_cast<double*>(r) + base);
+    const double2* v2 = reinterpret_cast<const double2*>(V + (int64_t)fz.jprev * ldv + base);
+    const double2* m2 = fz.jprev2 >= 0 ? reinterpret_cast<const double2*>(V + (int64_t)fz.jprev2 * ldv + base) : nullptr;
+    const int cnt2 = cnt >> 1;
+    for (int t0 = threadIdx.x; t0 < cnt2; t0 += 5 * kTPB) {
+      double2 x[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int t = t0 + u * kTPB;
+        x[u] = make_double2(0.0, 0.0);
+        if (t < cnt2) {
+          x[u] = y2[t];
+          const double2 v = v2[t];
+          x[u].x = x[u].x - v.x * al;  // k_three_term's expression, element for element
+          x[u].y = x[u].y - v.y * al;
+          if (m2) {
+            const double2 m = m2[t];
+            x[u].x = x[u].x - m.x * be;
+            x[u].y = x[u].y - m.y * be;
+          }
+          y2[t] = x[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 5; ++u)
+        if (t0 + u * kTPB < cnt2) {
+          sw[t0 + u * kTPB] = x[u];
+          self = fma(x[u].x, x[u].x, self);
+          self = fma(x[u].y, x[u].y, self);
+        }
+    }
+    self = wave_sum(self);
   } else {
     self = ABL == 4 ? 0.0 : qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
     self = wave_sum(self);  // this wave's share of w.w (lane 0); replaces the streamed row-j result below
@@ -501,7 +539,7 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
 
 template <int SCALE>
 static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                         double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s) {
+                         double* beta_slot, const QtwPlan& plan, double* part, hipStream_t s, const QtwFuse& fz) {
   const size_t lds = (size_t)plan.L * sizeof(double);
   const dim3 grid(plan.G), block(kTPB);
 #define LZ_QTW_ARGS V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, plan.P, part
@@ -515,7 +553,7 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
       if (lds4 > 65536)
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
       if (err == hipSuccess)
-        hipLaunchKernelGGL(kern, grid, block, lds4, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, ldp, part);
+        hipLaunchKernelGGL(kern, grid, block, lds4, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, ldp, part, fz);
     };
     switch (plan.variant) {
       case 10: go(k_qtw_mfma4<SCALE, 4, 4>); break;
@@ -534,8 +572,8 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
     }
     return err;
   }
-  if constexpr (SCALE == 3) return hipErrorInvalidValue;  // one-reduce mode exists for the default (4x4x4 MFMA) family only
-  if constexpr (SCALE != 2 && SCALE != 3) {
+  if constexpr (SCALE == 3 || SCALE == 4) return hipErrorInvalidValue;  // these modes exist for the default (4x4x4 MFMA) family only
+  if constexpr (SCALE != 2 && SCALE != 3 && SCALE != 4) {
     if (plan.family == 1) {
       switch (plan.variant) {
         case 1: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
@@ -568,11 +606,13 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
 }
 
 hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
-                      double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s) {
-  if (mode == 3) return launch_qtw_t<3>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
-  if (mode == 2) return launch_qtw_t<2>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
-  if (mode == 1) return launch_qtw_t<1>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
-  return launch_qtw_t<0>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
+                      double* beta_slot, const QtwPlan& plan, double* part, int mode, hipStream_t s, const QtwFuse* fuse) {
+  const QtwFuse fz = fuse ? *fuse : QtwFuse();
+  if (mode == 4) return launch_qtw_t<4>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s, fz);
+  if (mode == 3) return launch_qtw_t<3>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s, fz);
+  if (mode == 2) return launch_qtw_t<2>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s, fz);
+  if (mode == 1) return launch_qtw_t<1>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s, fz);
+  return launch_qtw_t<0>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s, fz);
 }
 
 // ------------------------------------------------------------------ re-orthogonalisation pass 2
@@ -637,7 +677,7 @@ template <bool FUSED, int P, int RU>
 __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, int64_t ldv, int64_t p0, int64_t n2, int nrows,
                                                       int j, const double* __restrict__ c, const double* __restrict__ r,
                                                       double* __restrict__ beta, int raw_c, int nblk_a, int64_t p0b,
-                                                      int64_t n2b) {
+                                                      int64_t n2b, int cG, int cldp) {
   // blocks [0, nblk_a) cover positions [p0, n2); any further blocks cover a second range [p0b, n2b) (the two faces of a
   // slab in overlap mode leave in one launch)
   int bx = blockIdx.x;
@@ -662,9 +702,16 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
   for (int p = 0; p < P; ++p) w[p] = make_double2(0.0, 0.0);
   // raw_c (fused-norm mode inside lz_run): c still holds the reduced sums [V_0.r, ..., V_{j-1}.r, r.r]; beta and the
   // coefficients of w = r / beta are formed here with k_fused_prepare's arithmetic (one tiny launch less per step).
+  // raw_c == 2 (fused small-problem mode): c is pass 1's block partials (cG runs of cldp doubles); a coefficient is their
+  // sum in k_final_rows_t's order (from 0.0, block by block) - the second-stage launch is folded in here.
+  auto csum = [&](int k) {
+    double t = 0.0;
+    for (int b = 0; b < cG; ++b) t += c[(int64_t)b * cldp + k];
+    return t;
+  };
   double bnorm = 1.0;
   if (FUSED && raw_c) {
-    bnorm = sqrt(c[j]);
+    bnorm = sqrt(raw_c == 2 ? csum(j) : c[j]);
     if (blockIdx.x == 0 && threadIdx.x == 0) beta[0] = bnorm;
   }
   if (FUSED) {
@@ -691,7 +738,7 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
 #pragma unroll
     for (int u = 0; u < RU; ++u)
       if (k + u < nrows) {
-        double ck = c[k + u];
+        double ck = (FUSED && raw_c == 2) ? csum(k + u) : c[k + u];
         if (FUSED && raw_c) ck = (k + u == j) ? ck / (bnorm * bnorm) : ck / bnorm;
         if (!FUSED && k + u == j) {  // row j is V[j] itself (j < nrows): keep it for the final 2 v - t instead of re-reading it
 #pragma unroll
@@ -712,16 +759,16 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
 
 template <bool FUSED, int P, int RU>
 static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, int nrows, int j, const double* c, const double* r,
-                                double* beta, int raw_c, hipStream_t s, int64_t p0b = 0, int64_t n2b = 0) {
+                                double* beta, int raw_c, hipStream_t s, int64_t p0b = 0, int64_t n2b = 0, int cG = 0, int cldp = 0) {
   const int grid = (int)((n2 - p0 + kTPB * P - 1) / (kTPB * P));
   const int grid_b = n2b > p0b ? (int)((n2b - p0b + kTPB * P - 1) / (kTPB * P)) : 0;
   hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid + grid_b), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r, beta, raw_c,
-                     grid, p0b, n2b);
+                     grid, p0b, n2b, cG, cldp);
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
                    double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi, int raw_c, int64_t pos_lo_b,
-                   int64_t pos_hi_b) {
+                   int64_t pos_hi_b, int cG, int cldp) {
   // double2 positions [pos_lo, pos_hi) of the row (default: the whole row)
   const int64_t n2 = pos_hi >= 0 ? pos_hi : (len >> 1);
   const int64_t p0 = pos_lo > 0 ? pos_lo : 0;
@@ -762,23 +809,23 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
   if (variant == 6 || (variant == 0 && P == 16 && span > 16384)) {
     // 16 positions per lane, one row per trip (still 16 loads in flight): half as many, longer-lived blocks - fewer
     // residency rounds, so V[j] leaves in fewer, larger write bursts (1250 -> 1218 us at the headline)
-    if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
+    if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
     else launch_update_slice<false, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
     return;
   }
   if ((variant == 0 && span <= 16384) || variant == 5) {
     // a face of the slab (overlap mode) or a tiny vector: a handful of blocks walk all rows, which is a latency chain,
     // not a bandwidth problem - one position per lane (most blocks) and 32 rows in flight per lane
-    if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, pos_lo_b, pos_hi_b);
+    if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, pos_lo_b, pos_hi_b, cG, cldp);
     else launch_update_slice<false, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, pos_lo_b, pos_hi_b);
   } else if (P == 8) {
-    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
+    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
     else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
   } else if (P == 4) {
-    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
+    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
     else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
   } else {
-    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s);
+    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
     else launch_update_slice<false, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
   }
 }

@@ -26,12 +26,13 @@ def _cases():
     }
 
 
-def _run(hip, H, n, engine_off, flags=None):
+def _run(hip, H, n, engine_off, flags=None, knob=None):
     import scipy.sparse
 
     h = hip.Handle(0)
     h.set_options(hip.FLAG_FUSED_NORM if flags is None else flags)
-    h.set_tuning(15, 0 if engine_off else 2)  # the engine is opt-in (knob 15 = 2)
+    # knob 15: 0 = default (fused three-launch path where it applies), 1 = plain six-launch path, 2 = one-kernel engine (opt-in)
+    h.set_tuning(15, knob if knob is not None else (1 if engine_off else 2))
     if scipy.sparse.issparse(H):
         A = H.tocsr()
         h.set_csr(A.shape[0], 0, A.indptr, A.indices, A.data)
@@ -63,6 +64,28 @@ def test_engine_is_bit_identical_to_the_kernel_path(hip, name):
     print(f"\n[small-engine] {name}: kernels {1e3 * t1:.3f} ms, engine {1e3 * t0:.3f} ms, x{t1 / t0:.2f}")
 
 
+def _fused_cases():
+    c = dict(_cases())
+    c["lap2d_64x64_n60"] = (synthetic.laplacian_2d_5pt(64, 64).to_scipy(), 60)           # 4096 rows: 8 pass-1 slices
+    c["graph_M3000_n50"] = (synthetic.random_graph_laplacian(3000, 10000, seed=7).to_scipy(), 50)
+    c["ragged_M700_n25"] = (load_golden("ragged_M700_n25")[1], 25)                         # a 700-entry row
+    c["dense_M2047_n30"] = (synthetic.dense_symmetric(2047, seed=5), 30)
+    return c
+
+
+@pytest.mark.parametrize("name", list(_fused_cases()))
+def test_fused_launch_path_is_bit_identical_and_faster(hip, name):
+    """Default path of small problems: three launches per step (second-stage reductions and the three-term recurrence
+    folded into their consumer kernels) against the plain six-launch path: same bits, fewer microseconds."""
+    H, n = _fused_cases()[name]
+    a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True, knob=1)
+    a0, b0, V0, e0, t0 = _run(hip, H, n, engine_off=False, knob=0)
+    assert e1 == "kernels" and e0 == "fused"
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1), (np.abs(a0 - a1).max(), np.abs(b0 - b1).max())
+    assert np.array_equal(V0, V1), np.abs(V0 - V1).max()
+    print(f"\n[fused-launch] {name}: six launches {1e3 * t1:.3f} ms, three launches {1e3 * t0:.3f} ms, x{t1 / t0:.2f}")
+
+
 def test_device_scope_arm_is_bit_identical_too(hip):
     """tuning knob 15 = 3: the same kernel on a plain grid with device-scope coherence (what it costs when the blocks do
     NOT share an XCD) - an A/B arm, same bits."""
@@ -86,18 +109,20 @@ def test_engine_is_not_used_where_it_does_not_apply(hip):
     assert _run(hip, H, 10, engine_off=False)[3] == "kernels"
     Hs = synthetic.laplacian_2d_5pt(20, 20).to_scipy()
     assert _run(hip, Hs, 10, engine_off=False, flags=0)[3] == "kernels"  # not fused-norm mode
-    assert _run(hip, Hs, 10, engine_off=True)[3] == "kernels"  # knob 15 = 0: the default
+    assert _run(hip, Hs, 10, engine_off=True)[3] == "kernels"  # knob 15 = 1: the plain path
+    assert _run(hip, Hs, 10, engine_off=False, knob=0)[3] == "fused"  # the default for small problems
+    assert _run(hip, synthetic.laplacian_2d_5pt(80, 80).to_scipy(), 10, engine_off=False, knob=0)[3] == "kernels"  # 6400 rows: 13 slices
     assert _run(hip, Hs, 10, engine_off=False, flags=hip.FLAG_FUSED_NORM | hip.FLAG_REORTH_PARTIAL)[3] == "kernels"
     assert _run(hip, Hs, 10, engine_off=False)[3] == "small"
 
 
 def test_drop_in_class_on_the_reference_scripts_sizes():
-    """Through `Lanczos`: 1Dbox.py's N = 500 dense matrix (multi-kernel path by default); the golden coefficients hold."""
+    """Through `Lanczos`: 1Dbox.py's N = 500 dense matrix (fused-launch path by default); the golden coefficients hold."""
     d, H = load_golden("box1d_N500_n50")
     Lanczos.verbose = False
     s = Lanczos(H.toarray())
     s.execute_Lanczos(50)
-    assert s._handle.last_engine() == "kernels"
+    assert s._handle.last_engine() == "fused"
     scale = max(np.abs(d["alpha"]).max(), np.abs(d["beta"]).max())
     assert np.abs(np.diag(s.H_eff) - d["alpha"]).max() <= 1e-10 * scale
     assert np.abs(s.H_eigvals - d["H_eigvals"]).max() <= 1e-10 * np.abs(d["H_eigvals"]).max()
