@@ -1458,7 +1458,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   // fused-launch path for small problems (tune[15] == 1 switches it off): see run_loop_fused_small
   const bool fsmall = !small && h->tune[15] == 0 && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
                       !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->qplan.family == 2 && h->qplan.G <= 8 &&
-                      h->tune[1] == 0 && h->tune[8] == 0 && h->part_cap >= fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G;
+                      h->tune[1] == 0 && h->tune[8] == 0 && n <= 4096 && h->part_cap >= fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G;
   if (fsmall) {
     LZ_TRY(run_loop_fused_small(h, n));
     h->last_engine = 2;

@@ -703,15 +703,20 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
   // raw_c (fused-norm mode inside lz_run): c still holds the reduced sums [V_0.r, ..., V_{j-1}.r, r.r]; beta and the
   // coefficients of w = r / beta are formed here with k_fused_prepare's arithmetic (one tiny launch less per step).
   // raw_c == 2 (fused small-problem mode): c is pass 1's block partials (cG runs of cldp doubles); a coefficient is their
-  // sum in k_final_rows_t's order (from 0.0, block by block) - the second-stage launch is folded in here.
-  auto csum = [&](int k) {
-    double t = 0.0;
-    for (int b = 0; b < cG; ++b) t += c[(int64_t)b * cldp + k];
-    return t;
-  };
+  // sum in k_final_rows_t's order (from 0.0, block by block) - the second-stage launch is folded in here: the block adds
+  // them up once, into LDS (nrows doubles of dynamic shared memory).
+  extern __shared__ double cs[];
+  if (FUSED && raw_c == 2) {
+    for (int k = threadIdx.x; k < nrows; k += kTPB) {
+      double t = 0.0;
+      for (int b = 0; b < cG; ++b) t += c[(int64_t)b * cldp + k];
+      cs[k] = t;
+    }
+    __syncthreads();
+  }
   double bnorm = 1.0;
   if (FUSED && raw_c) {
-    bnorm = sqrt(raw_c == 2 ? csum(j) : c[j]);
+    bnorm = sqrt(raw_c == 2 ? cs[j] : c[j]);
     if (blockIdx.x == 0 && threadIdx.x == 0) beta[0] = bnorm;
   }
   if (FUSED) {
@@ -738,7 +743,7 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
 #pragma unroll
     for (int u = 0; u < RU; ++u)
       if (k + u < nrows) {
-        double ck = (FUSED && raw_c == 2) ? csum(k + u) : c[k + u];
+        double ck = (FUSED && raw_c == 2) ? cs[k + u] : c[k + u];
         if (FUSED && raw_c) ck = (k + u == j) ? ck / (bnorm * bnorm) : ck / bnorm;
         if (!FUSED && k + u == j) {  // row j is V[j] itself (j < nrows): keep it for the final 2 v - t instead of re-reading it
 #pragma unroll
@@ -762,8 +767,8 @@ static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, 
                                 double* beta, int raw_c, hipStream_t s, int64_t p0b = 0, int64_t n2b = 0, int cG = 0, int cldp = 0) {
   const int grid = (int)((n2 - p0 + kTPB * P - 1) / (kTPB * P));
   const int grid_b = n2b > p0b ? (int)((n2b - p0b + kTPB * P - 1) / (kTPB * P)) : 0;
-  hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid + grid_b), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r, beta, raw_c,
-                     grid, p0b, n2b, cG, cldp);
+  hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid + grid_b), dim3(kTPB), raw_c == 2 ? (size_t)nrows * sizeof(double) : 0, s, V, ldv, p0,
+                     n2, nrows, j, c, r, beta, raw_c, grid, p0b, n2b, cG, cldp);
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
