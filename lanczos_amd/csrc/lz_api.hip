@@ -115,6 +115,7 @@ struct lz_context {
   int n = 0;
   double* d_V = nullptr;
   double* d_r = nullptr;
+  double* d_r2 = nullptr;     // fused small-problem path: r of the three-term recurrence (d_r then holds the SpMV output)
   double* d_alpha = nullptr;  // n
   double* d_beta = nullptr;   // n
   double* d_c = nullptr;      // n + 1
@@ -629,6 +630,7 @@ int run_loop_fused_small(lz_handle h, int n) {
     fz.jprev2 = j >= 2 ? j - 2 : -1;  // the reference's V[-1] term at its step 0 is the zero row
     fz.beta_prev = h->d_beta + (j >= 2 ? j - 2 : 0);
     fz.alpha_out = h->d_alpha + fz.jprev;
+    fz.r_out = h->d_r2;
     h->qplan.variant = 0;
     {
       Scope sc(h, LZ_K_QTW, 8.0 * j * M + 40.0 * M, 2.0 * (j + 1) * M + 4.0 * M);
@@ -637,7 +639,7 @@ int run_loop_fused_small(lz_handle h, int n) {
     }
     {
       Scope sc(h, LZ_K_UPDATE, 8.0 * j * M + 16.0 * M, 2.0 * (j + 1) * M);
-      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_part + coff, h->d_r, h->d_beta + bidx, 0, h->stream, 0, -1, 2, 0, 0, h->qplan.G,
+      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_part + coff, h->d_r2, h->d_beta + bidx, 0, h->stream, 0, -1, 2, 0, 0, h->qplan.G,
                     qtw_ldp(j + 1));
       LZ_TRY(check_launch(h, "update(fused reduction)"));
     }
@@ -824,6 +826,7 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_dense);
   hipFree(h->d_V);
   hipFree(h->d_r);
+  hipFree(h->d_r2);
   hipFree(h->d_alpha);
   hipFree(h->d_beta);
   hipFree(h->d_c);
@@ -1241,6 +1244,7 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
     LZ_TRY(dev_alloc(h, h->d_V, vsz));
     if (getenv("LZ_DEBUG_PTR")) fprintf(stderr, "[lz] basis %p (%zu bytes, ld %lld)\n", (void*)h->d_V, vsz * sizeof(double), (long long)h->ldv);
     LZ_TRY(dev_alloc(h, h->d_r, (size_t)h->ldv));
+    LZ_TRY(dev_alloc(h, h->d_r2, (size_t)h->ldv));
     LZ_TRY(dev_alloc(h, h->d_alpha, (size_t)n + 1));
     LZ_TRY(dev_alloc(h, h->d_beta, (size_t)n + 1));
     LZ_TRY(dev_alloc(h, h->d_c, (size_t)2 * qtw_ldp(n + 2) + 8));  // n + 1 coefficients; one-reduce mode: two runs + alpha
@@ -1268,6 +1272,7 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
   LZ_TRY(ensure_part(h, need));
   LZ_HIP(h, hipMemsetAsync(h->d_V, 0, (size_t)std::min(zero_rows, n) * (size_t)h->ldv * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_r, 0, (size_t)h->ldv * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_r2, 0, (size_t)h->ldv * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_alpha, 0, ((size_t)n + 1) * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_beta, 0, ((size_t)n + 1) * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_c, 0, ((size_t)2 * qtw_ldp(n + 2) + 8) * sizeof(double), h->stream));

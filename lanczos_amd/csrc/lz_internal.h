@@ -86,6 +86,7 @@ struct QtwFuse {
   int jprev = 0, jprev2 = -1;     // basis rows of v_prev (the vector just multiplied) and v_prev2 (-1: none)
   const double* beta_prev = nullptr;
   double* alpha_out = nullptr;
+  double* r_out = nullptr;        // where r goes (NOT y itself: with the row split several blocks read the same slice of y)
 };
 // returns the error of the per-kernel LDS-limit raise (hipFuncSetAttribute), if that was needed and failed
 hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,

@@ -344,9 +344,10 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
     // fused small-problem mode: finish the previous step here (see QtwFuse), then stage and dot r like SCALE == 2
     __shared__ double sm16[16];
     const double al = final_sum_emulated(fz.apart, fz.np, sm16);
-    if (blockIdx.x == 0 && threadIdx.x == 0) fz.alpha_out[0] = al;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fz.alpha_out[0] = al;
     const double be = fz.jprev2 >= 0 ? fz.beta_prev[0] : 0.0;
-    double2* y2 = reinterpret_cast<double2*>(const_cast<double*>(r) + base);
+    const double2* y2 = reinterpret_cast<const double2*>(r + base);
+    double2* ro2 = reinterpret_cast<double2*>(fz.r_out + base);
     const double2* v2 = reinterpret_cast<const double2*>(V + (int64_t)fz.jprev * ldv + base);
     const double2* m2 = fz.jprev2 >= 0 ? reinterpret_cast<const double2*>(V + (int64_t)fz.jprev2 * ldv + base) : nullptr;
     const int cnt2 = cnt >> 1;
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
             x[u].x = x[u].x - m.x * be;
             x[u].y = x[u].y - m.y * be;
           }
-          y2[t] = x[u];
+          if (blockIdx.y == 0) ro2[t] = x[u];  // (row split: every block of the slice computes it, one stores it)
         }
       }
 #pragma unroll
@@ -431,13 +432,18 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   // end of a tile otherwise drains the wave's whole load queue (s_waitcnt 0 before the cross-lane adds), a bubble that
   // cost 6 % of the pass (profiles/r01/ab_qtw_tile_epilogue.json).  ABL 6: the old, unpipelined order.
   const int ntiles = nrows > 0 ? i_top / (4 * T) + 1 : 0;  // one-reduce mode at j = 0: no rows yet, only the self terms
+  // Row split (gridDim.y > 1, short vectors with many basis rows - 1Ddeuteron.py: M = n = 1001): the blocks
+  // (blockIdx.x, 0..Y-1) share slice blockIdx.x and deal its row tiles round-robin; every (row, slice, quarter) dot is
+  // still one wave's same MFMA sequence and every block writes exactly its own rows of the slice's run: same bits, Y
+  // times the parallelism.
+  const int ky = blockIdx.y, kstep = gridDim.y;
   const double2* a[T];
   double2 av0[T][U];
-  if (ntiles > 0) {
-    tile_rows(ABL == 3 ? 0 : i_top, a);
+  if (ky < ntiles) {
+    tile_rows(ABL == 3 ? ky * 4 * T : i_top - ky * 4 * T, a);
     if (ABL != 6) load_batch(a, 0, av0);
   }
-  for (int k = 0; k < ntiles; ++k) {
+  for (int k = ky; k < ntiles; k += kstep) {
     const int i0 = ABL == 3 ? k * 4 * T : i_top - k * 4 * T;
     double acc[T];
 #pragma unroll
@@ -449,8 +455,8 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
       load_batch(a, s0, av);
       mma_batch(s0, av, acc);
     }
-    if (k + 1 < ntiles) {
-      tile_rows(ABL == 3 ? (k + 1) * 4 * T : i_top - (k + 1) * 4 * T, a);
+    if (k + kstep < ntiles) {
+      tile_rows(ABL == 3 ? (k + kstep) * 4 * T : i_top - (k + kstep) * 4 * T, a);
       if (ABL != 6) load_batch(a, 0, av0);
     }
     if (ABL == 5) {  // ABL 5: no per-tile epilogue (nothing reduced or stored)
@@ -487,8 +493,14 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   const int nout = SCALE == 3 ? ldp + nrows + 2 : nrows;
   const double* k0 = reinterpret_cast<const double*>(sw) + NCOL * L;
   double* mine = part + (int64_t)blockIdx.x * run;
-  for (int i = threadIdx.x; i < nout; i += kTPB)
+  const int t_top = i_top / (4 * T);
+  for (int i = threadIdx.x; i < nout; i += kTPB) {
+    if (kstep > 1) {  // row split: this block owns the tiles k == ky (mod Y) counted from the top, and block 0 row j's self term
+      const bool mine_row = i == j ? ky == 0 : (ABL == 3 ? i / (4 * T) : t_top - i / (4 * T)) % kstep == ky;
+      if (!mine_row) continue;
+    }
     __builtin_nontemporal_store(((k0[i] + k0[run + i]) + k0[2 * run + i]) + k0[3 * run + i], mine + i);
+  }
 }
 
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
@@ -547,13 +559,22 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
     const int ncol = SCALE == 3 ? 2 : 1;
     const int ldp = qtw_ldp(SCALE == 3 ? nrows + 2 : nrows);
     const size_t lds4 = ncol * (lds + (size_t)(kTPB / 64) * ldp * sizeof(double));  // slice(s) of w + the four waves' coefficient runs
+    // row split for short vectors (see the kernel): only where the slices alone leave most of the chip idle, and only in
+    // the modes whose staging stores nothing that other blocks of the same slice would race on
+    dim3 grid2 = grid;
+    if ((SCALE == 2 || SCALE == 4) && plan.G <= 64 && nrows > 8) {
+      const int ntiles = (nrows + 7) / 8;
+      int Y = 256 / plan.G;
+      if (Y > ntiles) Y = ntiles;
+      if (Y > 1) grid2 = dim3(plan.G, Y);
+    }
     hipError_t err = hipSuccess;
     auto go = [&](auto kern) {
       // more than 64 KiB of dynamic LDS (long slices with many hundred basis rows) has to be allowed per kernel
       if (lds4 > 65536)
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
       if (err == hipSuccess)
-        hipLaunchKernelGGL(kern, grid, block, lds4, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, ldp, part, fz);
+        hipLaunchKernelGGL(kern, grid2, block, lds4, s, V, ldv, len, nrows, j, r, nrm2, beta_slot, plan.L, ldp, part, fz);
     };
     switch (plan.variant) {
       case 10: go(k_qtw_mfma4<SCALE, 4, 4>); break;
@@ -762,6 +783,60 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
     if (ok[p]) st_stream<1>(out + pos[p], make_double2(2.0 * w[p].x - tx[p], 2.0 * w[p].y - ty[p]));
 }
 
+// Pass 2 for SHORT vectors with many basis rows (1Ddeuteron.py: M = n = 1001): the walk over the rows is a latency chain
+// per element and there are only len elements to overlap chains with, so one ELEMENT (not a double2) per lane, 32 rows per
+// trip, and the next trip's loads in flight while the current one is added up (two register buffers): four times the
+// loads in flight of k_update_slice<.., 1, 32>.  Same per-element arithmetic and order (NumPy's), fused-norm mode only.
+__global__ __launch_bounds__(kTPB) void k_update_elem(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
+                                                     const double* __restrict__ c, const double* __restrict__ r,
+                                                     double* __restrict__ beta, int raw_c, int cG, int cldp) {
+  extern __shared__ double cs[];
+  if (raw_c == 2) {  // fused small-problem mode: add pass 1's block partials in k_final_rows_t's order, once per block
+    for (int k = threadIdx.x; k < nrows; k += kTPB) {
+      double t = 0.0;
+      for (int b = 0; b < cG; ++b) t += c[(int64_t)b * cldp + k];
+      cs[k] = t;
+    }
+    __syncthreads();
+  }
+  const double* cc = raw_c == 2 ? cs : c;
+  double bnorm = 1.0;
+  if (raw_c) {
+    bnorm = sqrt(cc[j]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) beta[0] = bnorm;
+  }
+  const int64_t e0 = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  const bool ok = e0 < len;
+  const int64_t e = ok ? e0 : len - 1;  // valid address, result discarded
+  const double b = raw_c ? bnorm : beta[0];
+  const double w = r[e] / b;
+  constexpr int RU = 32;
+  double q[2][RU];
+  auto load = [&](int k, double (&dst)[RU]) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (k + u < nrows) dst[u] = (k + u == j) ? w : __builtin_nontemporal_load(V + (int64_t)(k + u) * ldv + e);
+  };
+  double tx = 0.0;
+  auto add = [&](int k, const double (&src)[RU]) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u)
+      if (k + u < nrows) {
+        double ck = cc[k + u];
+        if (raw_c) ck = (k + u == j) ? ck / (bnorm * bnorm) : ck / bnorm;
+        tx = tx + ck * src[u];
+      }
+  };
+  load(0, q[0]);
+  for (int k = 0; k < nrows; k += 2 * RU) {
+    if (k + RU < nrows) load(k + RU, q[1]);
+    add(k, q[0]);
+    if (k + 2 * RU < nrows) load(k + 2 * RU, q[0]);
+    if (k + RU < nrows) add(k + RU, q[1]);
+  }
+  if (ok) V[(int64_t)j * ldv + e] = 2.0 * w - tx;
+}
+
 template <bool FUSED, int P, int RU>
 static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, int nrows, int j, const double* c, const double* r,
                                 double* beta, int raw_c, hipStream_t s, int64_t p0b = 0, int64_t n2b = 0, int cG = 0, int cldp = 0) {
@@ -816,6 +891,13 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
     // residency rounds, so V[j] leaves in fewer, larger write bursts (1250 -> 1218 us at the headline)
     if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
     else launch_update_slice<false, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
+    return;
+  }
+  if (variant == 0 && span <= 4096 && r_fused && nrows > 64 && pos_hi < 0 && pos_lo <= 0) {
+    // a short vector against many rows: the element-per-lane, double-buffered kernel (see k_update_elem)
+    const int grid_e = (int)((len + kTPB - 1) / kTPB);
+    hipLaunchKernelGGL(k_update_elem, dim3(grid_e), dim3(kTPB), raw_c == 2 ? (size_t)nrows * sizeof(double) : 0, s, V, ldv, len, nrows, j, c, r_fused,
+                       beta, raw_c, cG, cldp);
     return;
   }
   if ((variant == 0 && span <= 16384) || variant == 5) {
