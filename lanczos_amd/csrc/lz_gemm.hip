@@ -228,22 +228,25 @@ __global__ __launch_bounds__(kTPB) void k_gemm_tn_persist(const double* __restri
 // operands with ds_read_b64 (a quarter of the LDS bandwidth).  The only per-wave global traffic left in the loop is the
 // V stream itself: one 8-byte non-temporal load per lane per k-step, four steps ahead.
 // Every wave of a block runs the same number of tiles (surplus tiles are clamped and not stored): the barriers match.
-template <int NT, int ABL = 0>  // ABL (kernel-bench build only): 1 no result stores, 2 no V loads, 4 no MFMAs
-__global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
-                                                    const double* __restrict__ B, int ldb, int ncols, double* __restrict__ C,
-                                                    int64_t ldc) {
+template <int NT, int ABL = 0, int NA = 1>  // ABL (kernel-bench build only): 1 no result stores, 2 no V loads, 4 no MFMAs
+__global__ __launch_bounds__(NA == 2 ? 256 : 512) void k_gemm_tn_lds(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
+                                                                   const double* __restrict__ B, int ldb, int ncols,
+                                                                   double* __restrict__ C, int64_t ldc) {
+  // NA = 1: two waves per SIMD (512 threads), a wave owns 16 rows; NA = 2: one wave per SIMD (256 threads), 32 rows -
+  // each staged S fragment then feeds two MFMAs (the operand probe's best case: 72.9 TF, tools/probes/mfma_f64_operands)
   constexpr int KP = 4;       // k-steps per panel = turns of the A ring
-  constexpr int NTHR = 512;
+  constexpr int NTHR = NA == 2 ? 256 : 512;
+  constexpr int TR = 16 * NA;  // rows per wave tile
   extern __shared__ double sB[];  // 2 panels of 16 rows x ldb doubles
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  const int64_t ntiles = (mdim + 15) / 16;
+  const int64_t ntiles = (mdim + TR - 1) / TR;
   const int64_t nwaves = (int64_t)gridDim.x * (NTHR / 64);
   const int64_t wave = (int64_t)blockIdx.x * (NTHR / 64) + w;
   const int64_t rounds = (ntiles + nwaves - 1) / nwaves;
   const int npanels = ((kcount + 3) / 4 + KP - 1) / KP;  // 16 * npanels == ldb rows of the zero-padded S
   const int panel_d2 = 16 * ldb / 2;                     // double2 elements per panel
-  constexpr int PF = 4;                                  // double2 loads per thread per panel (ldb <= 256: 16 * 256 / 2 / 512 = 4)
+  constexpr int PF = NA == 2 ? 8 : 4;                    // double2 loads per thread per panel (ldb <= 256: 16 * 256 / 2 / NTHR)
   const int CT = (ncols + 15) / 16;
   int colb[NT];
 #pragma unroll
@@ -255,27 +258,32 @@ __global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ 
   // A cursor: (round, step) of the next load
   int64_t pr = 0;
   int ps = 0;
-  auto issue_a = [&](double& x0) {
+  auto issue_a = [&](double (&x)[NA]) {
     int64_t t = wave + pr * nwaves;
     t = t < ntiles ? t : ntiles - 1;
-    int64_t m = t * 16 + lr;
-    m = m < mdim ? m : mdim - 1;
     int kr = 4 * ps + lk;
     kr = kr < kcount ? kr : kcount - 1;  // padding steps: finite values, multiplied by the zero rows of S
-    x0 = (ABL & 2) ? (double)(kr + m) : __builtin_nontemporal_load(A + (int64_t)kr * lda + m);
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+      int64_t m = t * TR + 16 * a + lr;
+      m = m < mdim ? m : mdim - 1;
+      x[a] = (ABL & 2) ? (double)(kr + m) : __builtin_nontemporal_load(A + (int64_t)kr * lda + m);
+    }
     if (++ps == KP * npanels) {
       ps = 0;
       ++pr;
     }
   };
-  double ra[KP];
+  double ra[KP][NA];
 #pragma unroll
   for (int p = 0; p < KP; ++p) issue_a(ra[p]);
   int buf = 0;
   for (int64_t rd = 0; rd < rounds; ++rd) {
-    double4_t acc[NT];
+    double4_t acc[NA][NT];
 #pragma unroll
-    for (int b = 0; b < NT; ++b) acc[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
     for (int pn = 0; pn < npanels; ++pn) {
       __syncthreads();  // panel `pn` is complete in buffer `buf`; nobody reads buffer buf^1 any more
       // prefetch the next panel of S (wrapping to panel 0 for the next tile) into registers
@@ -289,17 +297,21 @@ __global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ 
       const double* sb = sB + (size_t)buf * 16 * ldb;
 #pragma unroll
       for (int p = 0; p < KP; ++p) {
-        const double a0 = ra[p];
+        double a0[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) a0[a] = ra[p][a];
         issue_a(ra[p]);
         const double* srow = sb + (4 * p + lk) * ldb;
         double bv[NT];
 #pragma unroll
         for (int b = 0; b < NT; ++b) bv[b] = srow[colb[b]];
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
-          if (ABL & 4) acc[b][0] += a0 * bv[b];
-          else acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv[b], acc[b], 0, 0, 0);
-        }
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+            if (ABL & 4) acc[a][b][0] += a0[a] * bv[b];
+            else acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[a], bv[b], acc[a][b], 0, 0, 0);
+          }
       }
       double2* dst = s2 + (size_t)(buf ^ 1) * panel_d2;
 #pragma unroll
@@ -310,31 +322,35 @@ __global__ __launch_bounds__(512) void k_gemm_tn_lds(const double* __restrict__ 
       buf ^= 1;
     }
     const int64_t tile = wave + rd * nwaves;
-    if ((ABL & 1) && acc[0][0] != 1.2345e300) continue;
+    if ((ABL & 1) && acc[0][0][0] != 1.2345e300) continue;
     if (tile < ntiles) {  // wave-uniform
-      const int64_t m0 = tile * 16;
-      if (m0 + 16 <= mdim) {
+      const int64_t m0 = tile * TR;
+      if (m0 + TR <= mdim) {
         double* cbase = C + (m0 + lk) * ldc + lr;
 #pragma unroll
         for (int b = 0; b < NT; ++b) {
           const bool colok = b + 1 < CT || 16 * b + lr < ncols;
           if (b < CT && colok) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) cbase[(int64_t)(4 * g) * ldc + 16 * b] = acc[b][g];
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) cbase[(int64_t)(16 * a + 4 * g) * ldc + 16 * b] = acc[a][b][g];
           }
         }
       } else {
 #pragma unroll
-        for (int b = 0; b < NT; ++b) {
-          if (b >= CT) continue;
-          const int col = 16 * b + lr;
-          if (col >= ncols) continue;
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int64_t m = m0 + lk + 4 * g;
-            if (m < mdim) C[m * ldc + col] = acc[b][g];
+          for (int b = 0; b < NT; ++b) {
+            if (b >= CT) continue;
+            const int col = 16 * b + lr;
+            if (col >= ncols) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int64_t m = m0 + 16 * a + lk + 4 * g;
+              if (m < mdim) C[m * ldc + col] = acc[a][b][g];
+            }
           }
-        }
       }
     }
   }
@@ -382,6 +398,20 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
     return;
   }
 #endif
+  if (variant == 4) {  // one wave per SIMD with a 32-row tile, S through LDS: every staged fragment feeds two MFMAs
+    const size_t lds = (size_t)2 * 16 * npad * sizeof(double);
+#define LZ_TNL2(nt)                                                                                                           \
+  case nt:                                                                                                                    \
+    hipLaunchKernelGGL((k_gemm_tn_lds<nt, 0, 2>), dim3(kNumCU), dim3(256), lds, s, V, ldv, rows, n, Spad, npad, n, Y, ldy);    \
+    break;
+    switch (CT) {
+      LZ_TNL2(1) LZ_TNL2(2) LZ_TNL2(3) LZ_TNL2(4) LZ_TNL2(5) LZ_TNL2(6) LZ_TNL2(7) LZ_TNL2(8)
+      LZ_TNL2(9) LZ_TNL2(10) LZ_TNL2(11) LZ_TNL2(12) LZ_TNL2(13) LZ_TNL2(14) LZ_TNL2(15) LZ_TNL2(16)
+      default: break;
+    }
+#undef LZ_TNL2
+    return;
+  }
   if (variant == 3) {  // A/B arm: two waves per SIMD, S through LDS
     const size_t lds = (size_t)2 * 16 * npad * sizeof(double);
 #define LZ_TNL(nt)                                                                                                            \

@@ -124,7 +124,7 @@ int bi_partials_needed();
 // Y(rows x n, row-major, ldy) = sum_k V[k][m] * S[k][i]   (FP64 MFMA)
 // variant 0/1: one workgroup per 128 rows, one wave per SIMD owning 32 rows x all columns (default: the fastest of the
 // three on MI355X, profiles/r02/ablate_pb_rows_and_ritz.json); 2: the same tile walked by persistent waves; 3: persistent
-// waves, two per SIMD with 16-row tiles, S staged through LDS
+// waves, two per SIMD with 16-row tiles, S staged through LDS; 4: the LDS kernel with one wave per SIMD and 32-row tiles
 void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
                       int64_t ldy, hipStream_t s, int variant = 0);
 // G = Y^T Y as K-chunk partials (n x n each); returns the number of chunks (<= nz_max)
