@@ -106,8 +106,8 @@ int lz_set_options(lz_handle h, int flags);
  * entries per block, 5: fixed-K rows per block, 6: issue the collectives even when world == 1, 7: profile only every
  * value-th iteration of lz_run, 8: update-kernel variant (1 cached loads, 2 one position per lane, 3/4/5 slice owner with
  * 8/4/1 positions per lane), 11: two-sided links (2 = single launch), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
- * fresh basis allocation before the required parts are cleared (test knob), 14: 2 = build and use the column-blocked
- * two-phase SpMV kernels (opt-in experiment for matrices without column locality), 10: its products per row block, 15: small problems (0 fused-launch path, 1 plain six-launch path, 2 one-kernel engine, 3 engine on a plain grid)); they take effect
+ * fresh basis allocation before the required parts are cleared (test knob), 14: irregular SpMV plan (0 auto: the column-blocked
+ * two-phase kernels for matrices without column locality, 1 never, 2 always), 10: its products per row block, 15: small problems (0 fused-launch path, 1 plain six-launch path, 2 one-kernel engine, 3 engine on a plain grid)); they take effect
  * at the next lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order.  The
  * timing-only ablation arms (knob 1 values >= 20, knob 3) exist only in the kernel-bench build (make KBENCH=1,
  * liblanczos_kbench.so, tools/kbench.py); this library returns LZ_ERR_ARG for them. */

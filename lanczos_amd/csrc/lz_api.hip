@@ -715,13 +715,13 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   A.fixed_k = fixed_k;
   A.max_row_nnz = max_nnz;
   A.avg_row_nnz = (double)nnz / (double)rows_local;
-  // Matrices without column locality (random graphs): the SpMV is bound by cache-missing 8-byte gathers.  The
-  // column-blocked two-phase kernel pair that gathers out of LDS only (lz_spmv_pb.hip) is built on request
-  // (tune[14] == 2); measured on MI355X it does not beat the gather kernel yet, so it is not
-  // selected automatically.  A.far_frac (share of entries further than 2^18 columns from the diagonal) is kept as the
-  // criterion an automatic choice would use.
+  // Matrices without column locality (random graphs): the SpMV is bound by cache-missing 8-byte gathers, so it runs as
+  // the column-blocked two-phase kernel pair that gathers out of LDS only (lz_spmv_pb.hip; 1.4-1.6x on config C3, same
+  // bits).  Auto: the vector is larger than the L2s can hold (>= 2^20 columns), rows are not a fixed-K stencil, and more
+  // than a quarter of the entries sit further than 2^18 columns from the diagonal.  tune[14]: 1 = never, 2 = always
+  // (tests run it on small matrices).
   pb_free(A.pb);
-  const bool want = h->tune[14] == 2;
+  const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
     LZ_HIP(h, pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]));
   }
