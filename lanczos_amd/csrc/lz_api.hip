@@ -716,7 +716,7 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   A.max_row_nnz = max_nnz;
   A.avg_row_nnz = (double)nnz / (double)rows_local;
   // Matrices without column locality (random graphs): the SpMV is bound by cache-missing 8-byte gathers, so it runs as
-  // the column-blocked two-phase kernel pair that gathers out of LDS only (lz_spmv_pb.hip; 1.4-1.6x on config C3, same
+  // the column-blocked two-phase kernel pair that gathers out of LDS only (lz_spmv_pb.hip; 2.5x on config C3, same
   // bits).  Auto: the vector is larger than the L2s can hold (>= 2^20 columns), rows are not a fixed-K stencil, and more
   // than a quarter of the entries sit further than 2^18 columns from the diagonal.  tune[14]: 1 = never, 2 = always
   // (tests run it on small matrices).
@@ -1824,7 +1824,7 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
   LZ_TRY(dev_alloc(h, dS, Sp.size()));
   hipError_t e = hipMemcpyAsync(dS, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess && (!h->d_Y || h->y_rows != h->rows || h->y_n != n)) {
-    int rc = dev_alloc(h, h->d_Y, (size_t)h->rows * n + 64);  // + slack: the Gram kernel reads 16-wide column tiles
+    int rc = dev_alloc(h, h->d_Y, (size_t)(round_up(h->rows, 16) + 16) * n + 64);  // + slack: the S-stationary GEMM stores whole 16-row tiles (and 16 scratch rows), the Gram kernel reads 16-wide column tiles
     if (rc != LZ_OK) {
       hipFree(dS);
       return rc;

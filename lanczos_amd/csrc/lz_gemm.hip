@@ -356,6 +356,218 @@ __global__ __launch_bounds__(NA == 2 ? 256 : 512) void k_gemm_tn_lds(const doubl
   }
 }
 
+// Ritz back-transform, S-STATIONARY kernel (variant 5; n in 193..208): S lives in registers, V streams through LDS.
+// Why.  The kernels above keep a tile of Y in the accumulators and re-read S every k-step: 13 operand fetches per 26 MFMAs,
+// and the MFMA stream with that fetch is what takes the time (15.5 of 16.1 ms).  Turned around, the
+// stationary operand is S: one workgroup of EIGHT waves (two per SIMD, 256 registers each) holds all of S in registers.
+// Waves (s, 0) and (s, 1) share SIMD s and the column panels s, s+4, s+8: wave (s, h) keeps their k-steps
+// [h KS/2, (h+1) KS/2) (3 x 25 doubles per lane at n = 200); wave (s, 1) also keeps the k-steps [KS s/4, KS (s+1)/4) of
+// the 13th panel (a K-split: every SIMD gets 3.25 panel-products per row tile, so the four MFMA pipes carry equal work).
+// The only operand that moves is a 16-row tile of V (25.6 KB): one LDS-DMA copy per workgroup into a double-buffered LDS
+// tile in MFMA-fragment order (a k-step's fragment is 64 consecutive doubles: conflict-free ds_read_b64); every fragment
+// read feeds three or four MFMAs.
+// Why two waves per SIMD: a vector-memory instruction costs the issuing wave 160-280 cycles among FP64 MFMAs
+// (profiles/r02/ritz_sreg_ablation.json: with one wave per SIMD the 20 loads and stores of a tile cost 3 300 of 14 000
+// cycles whatever their width, placement or cache policy), and the only thing that keeps the MFMA pipe fed meanwhile is
+// a second wave.  So the memory work is split by kind: the (s, 1) waves issue the LDS-DMA of the next tile and hand
+// their partial tiles over through LDS; the (s, 0) waves add them to their own partial tiles and store the previous
+// tile's results, one store per k-step, between their MFMAs.  One raw barrier per tile with counted waits.
+// Stores are unconditional: C needs (round_up(mdim, 16) + 16) rows (the last 16 take the "previous tile" of a
+// workgroup's first trip).
+template <int NT, int KS, int ABL = 0>  // ABL (kernel-bench build only): 1 no V loads, 2 no result stores
+__global__ __launch_bounds__(512) void k_gemm_tn_sreg(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
+                                                     const double* __restrict__ B, int64_t ldb, int ncols,
+                                                     double* __restrict__ C, int64_t ldc) {
+  constexpr int FULL = NT / 4, REM = NT % 4, KH = KS / 2, KQ = (KS + 3) / 4;
+  constexpr int TILE = 64 * KS;                  // doubles per staged tile: 4 KS basis rows x 16 matrix rows
+  constexpr int NPC = TILE / 2 / 64;             // LDS-DMA instructions (64 x 16 bytes) per tile
+  constexpr int NLD = (NPC + 3) / 4;             // per loader wave
+  constexpr int IMG = FULL * 4 * 256;            // doubles per partial image: [wave s][panel j][reg g][lane]
+  constexpr int PART = (REM > 0 ? REM : 1) * 4 * 256;  // K-split partials: [panel][wave s][reg][lane]
+  static_assert(KS % 2 == 0 && FULL >= 1 && 4 * FULL + REM + 4 < KH, "shape");
+  extern __shared__ double lds_sreg[];
+  double* vt = lds_sreg;
+  double* img = lds_sreg + 2 * TILE;
+  double* part = img + 2 * IMG;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, s = w & 3, h = w >> 2;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int kh0 = h * KH;
+  double sf[FULL][KH];
+#pragma unroll
+  for (int j = 0; j < FULL; ++j)
+#pragma unroll
+    for (int t = 0; t < KH; ++t) sf[j][t] = B[(int64_t)(4 * (kh0 + t) + lk) * ldb + 16 * (s + 4 * j) + lr];
+  const int64_t ntiles = (mdim + 15) / 16;
+  const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int64_t first = (int64_t)blockIdx.x * per;
+  const int64_t last = first + per < ntiles ? first + per : ntiles;
+  if (first >= last) return;  // uniform over the block
+#ifdef LZ_KBENCH
+  const uint64_t kb_c0 = clock64(), kb_t0 = wall_clock64();  // shader-clock cycles vs the constant 100 MHz counter
+#endif
+  constexpr int PF = 4;  // fragments are read from LDS PF k-steps ahead of their MFMAs (explicit ring, fully unrolled loops)
+  if (h == 1) {
+    // ---------------- loader waves: second K half, the K-split panels, the LDS-DMA
+    const int q0 = KS * s / 4, q1 = KS * (s + 1) / 4;
+    double sr[REM > 0 ? REM : 1][KQ];
+#pragma unroll
+    for (int i = 0; i < REM; ++i)
+#pragma unroll
+      for (int t = 0; t < KQ; ++t) sr[i][t] = q0 + t < q1 ? B[(int64_t)(4 * (q0 + t) + lk) * ldb + 16 * (4 * FULL + i) + lr] : 0.0;
+    // LDS-DMA map: instruction p = s + 4 i moves the 16-byte pieces [64 p, 64 p + 64) of the tile: lane -> basis row
+    // 8 p + lane / 8 (clamped: S has zero rows past kcount), chunk lane % 8 of that row's 128 bytes.  Addresses are
+    // formed when used (no registers held across the MFMA loop).
+    // LDS-DMA map: instruction p = s + 4 i moves the 16-byte pieces [64 p, 64 p + 64) of the tile: lane -> basis row
+    // 8 p + lane / 8 (clamped: S has zero rows past kcount), chunk lane % 8 of that row's 128 bytes.  Addresses are
+    // formed when used (no registers held across the MFMA loop).
+    auto issue = [&](int64_t tile, double* buf) {
+      const double* base = A + tile * 16 + 2 * (lane & 7);
+      int lrow = lane >> 3;
+      asm volatile("" : "+v"(lrow));  // keeps the per-piece addresses from being hoisted out of the tile loop (registers)
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        if (!(ABL & 1) && s + 4 * i < NPC) {
+          int row = 8 * (s + 4 * i) + lrow;
+          if (row >= kcount) row = kcount - 1;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (int64_t)row * lda),
+                                           (__attribute__((address_space(3))) void*)(buf + 128 * (s + 4 * i)), 16, 0, 0);
+        }
+    };
+    issue(first, vt);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    int it = 0;
+    for (int64_t tile = first; tile < last; ++tile, ++it) {
+      const double* vb = vt + (it & 1) * TILE;
+      double* ib = img + (it & 1) * IMG;
+      double* pb = part + (it & 1) * PART;
+      double fr[PF];
+#pragma unroll
+      for (int p = 0; p < PF; ++p) fr[p] = vb[64 * (kh0 + (p < KH ? p : KH - 1)) + lane];
+      double ar = REM > 0 ? vb[64 * q0 + lane] : 0.0;
+      __builtin_amdgcn_sched_barrier(0);
+      issue(tile + 1 < last ? tile + 1 : last - 1, vt + ((it + 1) & 1) * TILE);  // all at once, first thing: measured no slower than spread over the k-steps or issued two tiles ahead
+      __builtin_amdgcn_sched_barrier(0);
+      double4_t acc[FULL], accr[REM > 0 ? REM : 1];
+#pragma unroll
+      for (int j = 0; j < FULL; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < REM; ++i) accr[i] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < KH; ++t) {
+        const double a = fr[t % PF];
+        if (t + PF < KH) fr[t % PF] = vb[64 * (kh0 + t + PF) + lane];
+        __builtin_amdgcn_sched_barrier(0);  // the scheduler would sink the LDS read down to its use, PF k-steps later
+#pragma unroll
+        for (int j = 0; j < FULL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sf[j][t], acc[j], 0, 0, 0);
+        if (REM > 0 && (t & 1) == 0 && (t >> 1) < KQ) {  // the K-split panel rides along: one more independent chain
+          const double arc = ar;
+          if ((t >> 1) + 1 < KQ) ar = vb[64 * (q0 + (t >> 1) + 1) + lane];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < REM; ++i) accr[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(arc, sr[i][t >> 1], accr[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < FULL; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ib[((s * FULL + j) * 4 + g) * 64 + lane] = acc[j][g];
+#pragma unroll
+      for (int i = 0; i < REM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pb[((i * 4 + s) * 4 + g) * 64 + lane] = accr[i][g];
+      __builtin_amdgcn_s_waitcnt(0x0070);  // the next tile has landed (vmcnt(0)), the partial tiles are written (lgkmcnt(0))
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    // ---------------- storing waves: first K half, the previous tile's results
+    static_assert(KQ <= (KH + 1) / 2 + 1, "K-split slots");
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    double4_t pacc[FULL];
+#pragma unroll
+    for (int j = 0; j < FULL; ++j) pacc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    int64_t pm0 = ntiles * 16;  // the slack rows
+    const int colr = 16 * (4 * FULL) + lr;  // first K-split panel's column of this lane
+    int it = 0;
+    auto ksplit = [&](const double* pprev, int i) {  // wave s adds result register s (rows lk + 4 s) of the four K-split partial tiles
+      double v = pprev[((i * 4 + 0) * 4 + s) * 64 + lane];
+      v += pprev[((i * 4 + 1) * 4 + s) * 64 + lane];
+      v += pprev[((i * 4 + 2) * 4 + s) * 64 + lane];
+      v += pprev[((i * 4 + 3) * 4 + s) * 64 + lane];
+      return v;
+    };
+    for (int64_t tile = first; tile < last; ++tile, ++it) {
+      const double* vb = vt + (it & 1) * TILE;
+      const double* iprev = img + ((it + 1) & 1) * IMG + s * FULL * 256 + lane;
+      const double* pprev = part + ((it + 1) & 1) * PART;
+      double* cprev = C + pm0 * ldc;
+      double fr[PF];
+#pragma unroll
+      for (int p = 0; p < PF; ++p) fr[p] = vb[64 * (p < KH ? p : KH - 1) + lane];
+      double* prow[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) prow[g] = cprev + (lk + 4 * g) * ldc + 16 * s + lr;
+      double other = iprev[0];  // the (s, 1) wave's partial of result 0: read one k-step before it is needed
+      __builtin_amdgcn_sched_barrier(0);
+      double4_t acc[FULL];
+#pragma unroll
+      for (int j = 0; j < FULL; ++j) acc[j] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < KH; ++t) {
+        const double a = fr[t % PF];
+        if (t + PF < KH) fr[t % PF] = vb[64 * (t + PF) + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < FULL; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sf[j][t], acc[j], 0, 0, 0);
+        // ---- riders: the previous tile's results, one store instruction per k-step
+        if (t >= 2 && t < 2 + 4 * FULL) {
+          const int r = t - 2, j = r >> 2, g = r & 3;
+          const double v = pacc[j][g] + other;
+          if (r + 1 < 4 * FULL) other = iprev[(r + 1) * 64];
+          if (!(ABL & 2)) __builtin_nontemporal_store(v, prow[g] + 64 * j);
+        }
+        if (t >= 2 + 4 * FULL && t < 2 + 4 * FULL + REM) {
+          const int i = t - 2 - 4 * FULL;
+          const double v = ksplit(pprev, i);
+          if (!(ABL & 2) && colr + 16 * i < ncols) __builtin_nontemporal_store(v, cprev + (lk + 4 * s) * ldc + colr + 16 * i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < FULL; ++j) pacc[j] = acc[j];
+      pm0 = tile * 16;
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: the stores stay in flight
+      __builtin_amdgcn_s_barrier();
+    }
+    // the last tile's results
+    {
+      const double* iprev = img + ((it + 1) & 1) * IMG + s * FULL * 256 + lane;
+      const double* pprev = part + ((it + 1) & 1) * PART;
+      double* cprev = C + pm0 * ldc;
+#pragma unroll
+      for (int j = 0; j < FULL; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          __builtin_nontemporal_store(pacc[j][g] + iprev[(j * 4 + g) * 64], cprev + (lk + 4 * g) * ldc + 16 * (s + 4 * j) + lr);
+#pragma unroll
+      for (int i = 0; i < REM; ++i) {
+        const double v = ksplit(pprev, i);
+        if (colr + 16 * i < ncols) __builtin_nontemporal_store(v, cprev + (lk + 4 * s) * ldc + colr + 16 * i);
+      }
+    }
+  }
+#ifdef LZ_KBENCH
+  if ((threadIdx.x == 0 || threadIdx.x == 256) && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    const uint64_t c = clock64() - kb_c0, t = wall_clock64() - kb_t0;
+    printf("k_gemm_tn_sreg ABL=%d block %d wave %d: %llu shader cycles in %llu ticks of 10 ns: %.0f MHz, %d tiles, %.0f cycles per tile\n", ABL,
+           (int)blockIdx.x, w, (unsigned long long)c, (unsigned long long)t, t ? 100.0 * (double)c / (double)t : 0.0, (int)(last - first),
+           (double)c / (double)(last - first));
+  }
+#endif
+}
+
 static void launch_gemm_tn(const double* A, int64_t lda, int64_t mdim, int64_t kcount, int64_t kchunk, int nz, const double* B,
                            int64_t ldb, int ncols, double* C, int64_t ldc, int64_t zstride, hipStream_t s) {
   const int CT = (ncols + 15) / 16;
@@ -378,11 +590,30 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
                       int64_t ldy, hipStream_t s, int variant) {
   const int CT = (n + 15) / 16;
   const int64_t ntiles = (rows + 31) / 32;
-  if (variant == 0 || variant == 1 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) {  // default; also > 256 columns or too few tiles to loop over
+  // 0 (auto): the S-stationary kernel where it applies (193 <= n <= 200, enough row tiles for a persistent grid), else the
+  // one-workgroup-per-128-rows kernel; 1 forces the latter; 2..5 are the A/B arms
+  const bool sreg_ok = n > 192 && n <= 200 && (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 && npad >= 208 &&
+                       ntiles >= 2 * kNumCU * (kTPB / 64);
+  if (variant == 0 && sreg_ok) variant = 5;
+  if (variant == 0 || variant == 1 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) {  // also > 256 columns or too few tiles to loop over
     launch_gemm_tn(V, ldv, rows, n, n, 1, Spad, npad, n, Y, ldy, 0, s);
     return;
   }
 #ifdef LZ_KBENCH
+  if (variant >= 20 && variant < 84 && CT == 13 && n == 200) {  // timing-only arms of the S-stationary kernel
+    constexpr size_t lds50 = (size_t)(2 * 64 * 50 + 2 * 3 * 4 * 256 + 2 * 4 * 256) * sizeof(double);
+    auto go = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds50);
+      hipLaunchKernelGGL(kern, dim3(kNumCU), dim3(512), lds50, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy);
+    };
+    switch (variant - 20) {
+      case 1: go(k_gemm_tn_sreg<13, 50, 1>); break;
+      case 2: go(k_gemm_tn_sreg<13, 50, 2>); break;
+      case 3: go(k_gemm_tn_sreg<13, 50, 3>); break;
+      default: go(k_gemm_tn_sreg<13, 50, 0>); break;
+    }
+    return;
+  }
   if (variant >= 10 && CT == 13) {  // timing-only ablation arms at n = 200
     const size_t ldsk = (size_t)2 * 16 * npad * sizeof(double);
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(kNumCU), dim3(512), ldsk, s, V, ldv, rows, n, Spad, npad, n, Y, ldy); };
@@ -398,6 +629,18 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
     return;
   }
 #endif
+  if (variant == 5 && sreg_ok) {
+    // S-stationary kernel: S in registers (25 k-steps x 3 panels per wave: 50 k-steps cover n <= 200), V tiles through
+    // LDS (reads whole 16-row tiles: ldv covers the padded rows)
+    static bool attr_done = false;  // more than 64 KiB of dynamic LDS: allowed once per kernel
+    constexpr size_t lds50 = (size_t)(2 * 64 * 50 + 2 * 3 * 4 * 256 + 2 * 4 * 256) * sizeof(double);
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_sreg<13, 50>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds50);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((k_gemm_tn_sreg<13, 50>), dim3(kNumCU), dim3(512), lds50, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy);
+    return;
+  }
   if (variant == 4) {  // one wave per SIMD with a 32-row tile, S through LDS: every staged fragment feeds two MFMAs
     const size_t lds = (size_t)2 * 16 * npad * sizeof(double);
 #define LZ_TNL2(nt)                                                                                                           \

@@ -1,5 +1,6 @@
 // Column-blocked two-phase SpMV for CSR matrices WITHOUT column locality (random graphs: BASELINE config C3).
-// Opt-in (lz_set_tuning(h, 14, 2)); y is bit-identical to SciPy's csr_matvec (tests/test_gpu_kernels.py).
+// Selected by lz_set_csr for such matrices (lz_api.hip; lz_set_tuning(h, 14, 1) switches it off, 2 forces it); y is
+// bit-identical to SciPy's csr_matvec (tests/test_gpu_kernels.py).
 //
 // Why.  r = A v with random columns is a gather of nnz 8-byte values out of a vector that fits no cache (C3: 8e7 gathers
 // into 80 MB).  Such gathers run at ~50-65e9/s on MI355X whether v sits in HBM or in the Infinity Cache and ~96e9/s out of
@@ -9,15 +10,18 @@
 //
 // How.  Two kernels, each of which gathers out of LDS only:
 //   phase 1, one workgroup per COLUMN block cb (W consecutive entries of v staged into LDS with coalesced loads):
-//            streams its matrix entries - stored column-block-major: values `pvals`, 16-bit local columns `pcol` and the
-//            destination `tdst` of every product - and SCATTERS the products  T2[tdst[t]] = pvals[t] * v[cb*W + pcol[t]].
+//            streams its matrix entries - stored column-block-major: values `pvals`, 16-bit local columns `pcol` and one
+//            destination `gdst` per group of 8 entries - and SCATTERS the products
+//            T2[gdst[t / 8] + t % 8] = pvals[t] * v[cb*W + pcol[t]].
 //            T2 is ordered (row block, column block, -): the products of one tile (row block x column block) are
 //            contiguous, every tile is padded to a multiple of 8 products and starts on a 64-byte boundary, and the pad
 //            slots are real (zero-valued) entries of the stream - so every store covers whole 64-byte sectors, and a
 //            store is fire-and-forget: nothing in this phase waits for a scattered access.
-//   phase 2, one workgroup per ROW block rb: its products are ONE contiguous segment of T2 - a plain coalesced stream into
-//            LDS, together with the 16-bit map `perm` (CSR position -> slot in the segment) - then every row adds its
-//            products out of LDS in CSR order.  Same multiplications, same additions in the same order as SciPy.
+//   phase 2, one persistent workgroup per CU walking the ROW blocks: the products of a row block are ONE contiguous
+//            segment of T2 - a plain coalesced stream into LDS, together with the 16-bit map `perm` (CSR position -> slot in
+//            the segment) - then every row adds its products out of LDS in CSR order.  The loads of the NEXT row block are
+//            issued into registers before the sums of the current one, so the CU (whose LDS holds one segment only) always
+//            has a stream in flight.  Same multiplications, same additions in the same order as SciPy.
 // (The first version of this file kept the products column-block-major and let phase 2 fetch 512 short runs per row block:
 // two dependent scattered round trips per workgroup, 0.99 ms - slower than the gather it replaced.  Measurements:
 // profiles/r02/ablate_pb_rows_and_ritz.json)
@@ -34,8 +38,13 @@
 namespace lz {
 
 constexpr int kPbThreads = 1024;
-constexpr int kPbPad = 8;          // products per 64-byte sector: tiles are padded to a multiple of it
-constexpr int kPbMaxRows = 8192;   // rows per row block
+#ifndef LZ_PB_PAD
+#define LZ_PB_PAD 8
+#endif
+constexpr int kPbPad = LZ_PB_PAD;  // tiles are padded to a multiple of it: 8 products = one 64-byte sector
+constexpr int kPbPadLog = kPbPad == 8 ? 3 : kPbPad == 4 ? 2 : 1;
+static_assert(kPbPad == (1 << kPbPadLog) && kPbPad >= 2, "tile padding: 2, 4 or 8 products");
+constexpr int kPbMaxRows = 2048;   // rows per row block: two per thread of phase 2, whose bounds travel with the prefetch
 constexpr int kPbMaxW = 19968;     // doubles of v per column block: 156 KiB of LDS in phase 1
 constexpr int kPbLdsMax = 158 * 1024;
 
@@ -50,10 +59,12 @@ struct PbDev {
   int32_t* cbptr = nullptr;    // nCB + 1: range of each column block in the padded stream
   uint16_t* perm = nullptr;    // nnz: CSR position -> slot within its row block's segment
   uint16_t* pcol = nullptr;    // np (stream order): column - cb * W
-  uint32_t* tdst = nullptr;    // np: slot in T2
+  uint32_t* gdst = nullptr;    // np / 8: slot in T2 of every group of 8 stream entries
   double* pvals = nullptr;     // np
   double* T2 = nullptr;        // np products
-  size_t lds2 = 0;             // dynamic LDS of phase 2: the longest segment + cap perm entries
+  int segmax = 0;              // longest padded segment (products)
+  int ncu = 256;               // compute units of the device: phase 2's persistent grid
+  size_t lds2 = 0;             // dynamic LDS of phase 2: the longest segment + an aligned window of cap perm entries
 };
 
 namespace {
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ ro
                                                   const int32_t* __restrict__ cbptr, const int32_t* __restrict__ len,
                                                   const int32_t* __restrict__ toff, const int2* __restrict__ rbseg,
                                                   uint16_t* __restrict__ perm, uint16_t* __restrict__ pcol,
-                                                  uint32_t* __restrict__ tdst, double* __restrict__ pvals) {
+                                                  uint32_t* __restrict__ gdst, double* __restrict__ pvals) {
   extern __shared__ int sm[];
   int* cursor = sm;          // nCB
   int* ls = sm + nCB;        // nCB + 1: first slot of every tile inside the segment
@@ -126,24 +137,24 @@ __global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ ro
     const int64_t t = (int64_t)cbptr[cb] + toff[(int64_t)rb * nCB + cb] + p;
     pvals[t] = vals[k];
     pcol[t] = (uint16_t)(col - cb * W);
-    tdst[t] = segbase + (uint32_t)(ls[cb] + p);
     perm[k] = (uint16_t)(ls[cb] + p);
   }
-  for (int c = threadIdx.x; c < nCB; c += blockDim.x) {  // pad slots: zero-valued entries, so that whole sectors are written
+  for (int c = threadIdx.x; c < nCB; c += blockDim.x) {
     const int n = len[(int64_t)rb * nCB + c];
-    const int64_t t0 = (int64_t)cbptr[c] + toff[(int64_t)rb * nCB + c];
-    for (int p = n; p < pad8(n); ++p) {
+    const int64_t t0 = (int64_t)cbptr[c] + toff[(int64_t)rb * nCB + c];  // a multiple of 8: every tile is padded
+    for (int p = n; p < pad8(n); ++p) {  // pad slots: zero-valued entries, so that whole sectors are written
       pvals[t0 + p] = 0.0;
       pcol[t0 + p] = 0;
-      tdst[t0 + p] = segbase + (uint32_t)(ls[c] + p);
     }
+    for (int g = 0; g < pad8(n) / kPbPad; ++g) gdst[(t0 >> kPbPadLog) + g] = segbase + (uint32_t)(ls[c] + kPbPad * g);
   }
 }
 
-// ---- phase 1: T2[tdst] = pvals * v[columns], column block in LDS
+// ---- phase 1: T2[gdst[t / 8] + t % 8] = pvals[t] * v[columns], column block in LDS.  A lane takes PAIRS of entries (one
+// 16-byte value load, one 4-byte column load, a 16-byte product store); four lanes share a group's destination.
 template <int U>
 __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __restrict__ cbptr, const double* __restrict__ pvals,
-                                                           const uint16_t* __restrict__ pcol, const uint32_t* __restrict__ tdst,
+                                                           const uint16_t* __restrict__ pcol, const uint32_t* __restrict__ gdst,
                                                            const double* __restrict__ x, int64_t ncols, int W,
                                                            double* __restrict__ T2) {
   extern __shared__ double xs[];
@@ -159,86 +170,165 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
     if ((wn & 1) && threadIdx.x == 0) xs[wn - 1] = x[c0 + wn - 1];
   }
   __syncthreads();
-  const int64_t t0 = cbptr[cb], t1 = cbptr[cb + 1];
-  for (int64_t tb = t0 + threadIdx.x; tb < t1; tb += (int64_t)U * kPbThreads) {
-    double a[U];
-    uint16_t c[U];
-    uint32_t d[U];
+  const int64_t p0 = (int64_t)cbptr[cb] >> 1, p1 = (int64_t)cbptr[cb + 1] >> 1;  // stream positions are multiples of 8
+  const double2* pv2 = reinterpret_cast<const double2*>(pvals);
+  const uint32_t* pc2 = reinterpret_cast<const uint32_t*>(pcol);
+  for (int64_t pb = p0 + threadIdx.x; pb < p1; pb += (int64_t)U * kPbThreads) {
+    double2 a[U];
+    uint32_t c[U], d[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t t = tb + (int64_t)u * kPbThreads;
-      const bool ok = t < t1;
-      a[u] = ok ? __builtin_nontemporal_load(pvals + t) : 0.0;
-      c[u] = ok ? __builtin_nontemporal_load(pcol + t) : (uint16_t)0;
-      d[u] = ok ? __builtin_nontemporal_load(tdst + t) : 0u;
+      const int64_t p = pb + (int64_t)u * kPbThreads;
+      const bool ok = p < p1;
+      a[u] = ok ? ld_stream<1>(pv2 + p) : make_double2(0.0, 0.0);
+      c[u] = ok ? __builtin_nontemporal_load(pc2 + p) : 0u;
+      d[u] = ok ? __builtin_nontemporal_load(gdst + (p >> (kPbPadLog - 1))) : 0u;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t t = tb + (int64_t)u * kPbThreads;
-      if (t < t1) __builtin_nontemporal_store(a[u] * xs[c[u]], T2 + d[u]);  // streamed once, read back by phase 2 from HBM
+      const int64_t p = pb + (int64_t)u * kPbThreads;
+      // streamed once, read back by phase 2 from HBM: non-temporal
+      if (p < p1)
+        st_stream<1>(reinterpret_cast<double2*>(T2 + d[u] + (((uint32_t)p & (uint32_t)(kPbPad / 2 - 1)) << 1)),
+                     make_double2(a[u].x * xs[c[u] & 0xffffu], a[u].y * xs[c[u] >> 16]));
     }
   }
 }
 
-// ---- phase 2: one contiguous segment of products + its perm entries -> LDS, row sums in CSR order, alpha partial
+// ---- phase 2: one contiguous segment of products + its perm entries -> LDS, row sums in CSR order, alpha partial.
+// Persistent: block b takes the row blocks b, b + gridDim.x, ...; a tile travels HBM -> registers -> LDS and the
+// registers of the next tile are in flight while the current one is summed.
+constexpr int kPbNQ = 10;  // double2 per thread: 20480 products >= the longest segment the LDS can hold
+constexpr int kPbNP = 2;   // uint4 (8 perm entries) per thread: 16384 >= cap + 16
+constexpr int kPbNR = kPbMaxRows / kPbThreads;  // rows per thread: their bounds are prefetched with the tile
+
+typedef unsigned int u4v_t __attribute__((ext_vector_type(4)));
+
+struct PbTile {
+  double2 q[kPbNQ];
+  u4v_t pm[kPbNP];
+  int ka[kPbNR], kb[kPbNR];
+  double xo[kPbNR];
+};
+
+template <int ABL>
+__device__ __forceinline__ void pb_tile_load(PbTile& t, int4 hd, int2 sg, const int32_t* __restrict__ rowptr,
+                                             const uint16_t* __restrict__ perm, const double* __restrict__ T2,
+                                             const double* __restrict__ xown) {
+  const double2* src = reinterpret_cast<const double2*>(T2 + sg.x);  // 64-byte aligned, a multiple of 8 products long
+  const int n2 = sg.y >> 1;
+#pragma unroll
+  for (int i = 0; i < kPbNQ; ++i) {
+    const int p = threadIdx.x + i * kPbThreads;
+    if (!(ABL & 1) && p < n2) t.q[i] = ld_stream<1>(src + p);
+  }
+  const int kbase = hd.z & ~7;  // aligned window of perm: 16-byte loads
+  const int n8 = (hd.z + hd.w - kbase + 7) >> 3;
+  const u4v_t* pm8 = reinterpret_cast<const u4v_t*>(perm + kbase);
+#pragma unroll
+  for (int i = 0; i < kPbNP; ++i) {
+    const int p = threadIdx.x + i * kPbThreads;
+    if (!(ABL & 2) && p < n8) t.pm[i] = __builtin_nontemporal_load(pm8 + p);
+  }
+#pragma unroll
+  for (int i = 0; i < kPbNR; ++i) {
+    const int row = hd.x + threadIdx.x + i * kPbThreads;
+    t.ka[i] = t.kb[i] = 0;
+    t.xo[i] = 0.0;
+    if (row < hd.x + hd.y) {
+      t.ka[i] = rowptr[row];  // raw: nothing here may wait for a load (the consumer subtracts the window base)
+      t.kb[i] = rowptr[row + 1];
+      t.xo[i] = xown[row];
+    }
+  }
+}
+
 template <int ABL>  // kernel-bench build: 1 no product loads, 2 no perm loads, 4 no LDS gathers
 __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__ rbhead, const int2* __restrict__ rbseg,
                                                        const int32_t* __restrict__ rowptr, const uint16_t* __restrict__ perm,
-                                                       const double* __restrict__ T2, int segcap, const double* __restrict__ xown,
-                                                       double* __restrict__ y, double* __restrict__ part) {
-  extern __shared__ double seg[];  // segcap products, then the perm entries of the row block
+                                                       const double* __restrict__ T2, int segcap, int nRB,
+                                                       const double* __restrict__ xown, double* __restrict__ y,
+                                                       double* __restrict__ part) {
+  extern __shared__ double seg[];  // segcap products, then the aligned window of the row block's perm entries
   __shared__ double red[kPbThreads / 64];
   uint16_t* perm_s = reinterpret_cast<uint16_t*>(seg + segcap);
-  const int rb = blockIdx.x;
-  const int4 hd = rbhead[rb];
-  const int2 sg = rbseg[rb];
-  const int r0 = hd.x, r1 = hd.x + hd.y, k0 = hd.z, cnt = hd.w;
-  // everything this workgroup reads is known now: ONE round trip
-  const double2* src = reinterpret_cast<const double2*>(T2 + sg.x);  // 64-byte aligned, a multiple of 8 products long
-  double2* dst = reinterpret_cast<double2*>(seg);
-  const int n2 = sg.y >> 1;
-  if (!(ABL & 1))
-    for (int i = threadIdx.x; i < n2; i += kPbThreads) dst[i] = ld_stream<1>(src + i);
-  if (!(ABL & 2))
-    for (int i = threadIdx.x; i < cnt; i += kPbThreads) perm_s[i] = __builtin_nontemporal_load(perm + k0 + i);
-  const int row = r0 + threadIdx.x;
-  int ka = 0, kb = 0;
-  double xo = 0.0;
-  if (row < r1) {
-    ka = rowptr[row] - k0;
-    kb = rowptr[row + 1] - k0;
-    xo = xown[row];
-  }
-  __syncthreads();
-  double d = 0.0;
-  for (int rw = row; rw < r1; rw += kPbThreads) {  // one row per thread, except in row blocks of many short rows
-    if (rw != row) {
-      ka = rowptr[rw] - k0;
-      kb = rowptr[rw + 1] - k0;
-      xo = xown[rw];
-    }
-    double sum = 0.0;
-    int k = ka;
-    for (; k + 4 <= kb; k += 4) {  // four LDS gathers in flight; the adds stay in CSR order, one rounding each
-      const double p0 = (ABL & 4) ? 1.0 : seg[perm_s[k]], p1 = (ABL & 4) ? 1.0 : seg[perm_s[k + 1]], p2 = (ABL & 4) ? 1.0 : seg[perm_s[k + 2]],
-                   p3 = (ABL & 4) ? 1.0 : seg[perm_s[k + 3]];
-      sum += p0;
-      sum += p1;
-      sum += p2;
-      sum += p3;
-    }
-    for (; k < kb; ++k) sum += (ABL & 4) ? 1.0 : seg[perm_s[k]];
-    y[rw] = sum;
-    d += xo * sum;
-  }
-  d = wave_sum(d);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
+  int rb = blockIdx.x;  // the grid is never larger than nRB
+  int4 hd = rbhead[rb];
+  int2 sg = rbseg[rb];
+  PbTile t;
+  pb_tile_load<ABL>(t, hd, sg, rowptr, perm, T2, xown);
+  for (;;) {
+    // registers -> LDS.  The explicit vmcnt(0) tells the compiler's wait-count pass, on every path, that nothing is
+    // outstanding from here on - otherwise the predicated loads below make it wait in the middle of the next prefetch.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    {
+      double2* dst = reinterpret_cast<double2*>(seg);
+      const int n2 = sg.y >> 1;
 #pragma unroll
-    for (int i = 0; i < kPbThreads / 64; ++i) t += red[i];
-    part[rb] = t;
+      for (int i = 0; i < kPbNQ; ++i) {
+        const int p = threadIdx.x + i * kPbThreads;
+        if (!(ABL & 1) && p < n2) dst[p] = t.q[i];
+      }
+      const int n8 = (hd.z + hd.w - (hd.z & ~7) + 7) >> 3;
+      u4v_t* pd = reinterpret_cast<u4v_t*>(perm_s);
+#pragma unroll
+      for (int i = 0; i < kPbNP; ++i) {
+        const int p = threadIdx.x + i * kPbThreads;
+        if (!(ABL & 2) && p < n8) pd[p] = t.pm[i];
+      }
+    }
+    int ka[kPbNR], kb[kPbNR];
+    double xo[kPbNR];
+#pragma unroll
+    for (int i = 0; i < kPbNR; ++i) {
+      ka[i] = t.ka[i];
+      kb[i] = t.kb[i];
+      xo[i] = t.xo[i];
+      // keep the compiler from folding "- kbase" into the prefetch (it would wait for the loads right where they are issued)
+      asm volatile("" : "+v"(ka[i]), "+v"(kb[i]));
+    }
+    const int r0 = hd.x, r1 = hd.x + hd.y, kbase = hd.z & ~7;
+    const int cur = rb;
+    __syncthreads();
+    // the next row block's stream goes out before this one is summed
+    rb += gridDim.x;
+    const bool more = rb < nRB;  // uniform over the block
+    if (more) {
+      hd = rbhead[rb];
+      sg = rbseg[rb];
+      pb_tile_load<ABL>(t, hd, sg, rowptr, perm, T2, xown);
+    }
+    double d = 0.0;
+#pragma unroll
+    for (int i = 0; i < kPbNR; ++i) {  // no global load in here: the prefetch above stays in flight until the next trip
+      const int rw = r0 + threadIdx.x + i * kPbThreads;
+      if (rw < r1) {
+        const int a = ka[i] - kbase, b = kb[i] - kbase;
+        double sum = 0.0;
+        int k = a;
+        for (; k + 4 <= b; k += 4) {  // four LDS gathers in flight; the adds stay in CSR order, one rounding each
+          const double p0 = (ABL & 4) ? 1.0 : seg[perm_s[k]], p1 = (ABL & 4) ? 1.0 : seg[perm_s[k + 1]], p2 = (ABL & 4) ? 1.0 : seg[perm_s[k + 2]],
+                       p3 = (ABL & 4) ? 1.0 : seg[perm_s[k + 3]];
+          sum += p0;
+          sum += p1;
+          sum += p2;
+          sum += p3;
+        }
+        for (; k < b; ++k) sum += (ABL & 4) ? 1.0 : seg[perm_s[k]];
+        y[rw] = sum;
+        d += xo[i] * sum;
+      }
+    }
+    d = wave_sum(d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();  // every thread is done with this segment (and red is complete)
+    if (threadIdx.x == 0) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < kPbThreads / 64; ++i) s += red[i];
+      part[cur] = s;
+    }
+    if (!more) break;
   }
 }
 
@@ -260,7 +350,7 @@ void pb_free(PbDev*& pb) {
   hipFree(pb->cbptr);
   hipFree(pb->perm);
   hipFree(pb->pcol);
-  hipFree(pb->tdst);
+  hipFree(pb->gdst);
   hipFree(pb->pvals);
   hipFree(pb->T2);
   delete pb;
@@ -277,8 +367,9 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   if (W < 256) W = 256;
   if (W > kPbMaxW) W = kPbMaxW;
   const int nCB = (int)((A.ncols + W - 1) / W);
-  // Products per row block: phase 2 keeps the padded segment (<= cap + 7 nCB products) and cap perm entries in LDS.
-  const int cap_max = (int)((kPbLdsMax - (int64_t)(kPbPad - 1) * nCB * 8) / 10);
+  // Products per row block: phase 2 keeps the padded segment (<= cap + 7 nCB products) and an aligned window of
+  // cap + 16 perm entries in LDS.
+  const int cap_max = std::min((int)((kPbLdsMax - 32 - (int64_t)(kPbPad - 1) * nCB * 8) / 10), kPbNP * 8 * kPbThreads - 16);
   int cap = cap_knob > 0 ? cap_knob : cap_max;  // as large as fits: longer tiles, less padding (measured best)
   if (cap > cap_max) cap = cap_max;
   if (cap < 256 || A.max_row_nnz > cap) return hipSuccess;
@@ -299,6 +390,11 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   pb->cap = cap;
   pb->nnz = A.nnz;
   hipError_t e = hipSuccess;
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      pb->ncu = cus;
+  }
   auto chk = [&](hipError_t x) {
     if (e == hipSuccess && x != hipSuccess) e = x;
   };
@@ -307,7 +403,7 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   chk(pb_alloc(pb->rbhead, (size_t)nRB));
   chk(pb_alloc(pb->rbseg, (size_t)nRB));
   chk(pb_alloc(pb->cbptr, (size_t)nCB + 1));
-  chk(pb_alloc(pb->perm, (size_t)A.nnz));
+  chk(pb_alloc(pb->perm, (size_t)A.nnz + 16));  // phase 2 reads whole aligned 16-byte groups
   chk(pb_alloc(len, (size_t)nRB * nCB));
   chk(pb_alloc(toff, (size_t)nRB * nCB));
   chk(pb_alloc(tot, (size_t)nCB));
@@ -346,14 +442,14 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   }
   pb->np = np;
   chk(pb_alloc(pb->pcol, (size_t)np));
-  chk(pb_alloc(pb->tdst, (size_t)np));
+  chk(pb_alloc(pb->gdst, (size_t)np / kPbPad));
   chk(pb_alloc(pb->pvals, (size_t)np));
   chk(pb_alloc(pb->T2, (size_t)np));
   if (e == hipSuccess) chk(hipMemcpyAsync(pb->cbptr, cbp.data(), cbp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
   if (e == hipSuccess) chk(hipMemcpyAsync(pb->rbseg, seg.data(), seg.size() * sizeof(int2), hipMemcpyHostToDevice, s));
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_pb_place, dim3(nRB), dim3(256), (size_t)(2 * nCB + 1) * sizeof(int), s, A.rowptr, A.colidx, A.vals, pb->rbptr, (int)W,
-                       nCB, pb->cbptr, len, toff, pb->rbseg, pb->perm, pb->pcol, pb->tdst, pb->pvals);
+                       nCB, pb->cbptr, len, toff, pb->rbseg, pb->perm, pb->pcol, pb->gdst, pb->pvals);
     chk(hipGetLastError());
     chk(hipStreamSynchronize(s));
   }
@@ -361,12 +457,14 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   hipFree(toff);
   hipFree(tot);
   hipFree(segtot);
-  pb->lds2 = (size_t)segmax * sizeof(double) + (size_t)cap * sizeof(uint16_t);
+  pb->segmax = segmax;
+  pb->lds2 = (size_t)segmax * sizeof(double) + (size_t)(cap + 16) * sizeof(uint16_t);
+  if (e == hipSuccess && segmax > kPbNQ * 2 * kPbThreads) e = hipErrorInvalidValue;  // cannot happen: the LDS bound is tighter
   // both phases may need more than the default 64 KiB of dynamic LDS: allowed once per kernel, here, so that the
   // launches themselves have no failure mode
   if (e == hipSuccess && pb->lds2 > 160 * 1024) e = hipErrorInvalidValue;
   if (e == hipSuccess && W * sizeof(double) > 65536)
-    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_products<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W * sizeof(double))));
+    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_products<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W * sizeof(double))));
   if (e == hipSuccess && pb->lds2 > 65536)
     chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pb->lds2));
 #ifdef LZ_KBENCH
@@ -390,12 +488,12 @@ int pb_num_partials(const PbDev* pb) { return pb->nRB; }
 // Returns the number of partials.
 int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s) {
   const size_t lds1 = (size_t)pb->W * sizeof(double);
-  const int segcap = (int)((pb->lds2 - (size_t)pb->cap * sizeof(uint16_t)) / sizeof(double));
-  hipLaunchKernelGGL(k_pb_products<8>, dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, pb->tdst, x, A.ncols, pb->W,
+  hipLaunchKernelGGL(k_pb_products<4>, dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, pb->gdst, x, A.ncols, pb->W,
                      pb->T2);
+  const int grid = std::min(pb->nRB, pb->ncu);  // one segment fills a CU's LDS: one persistent workgroup per CU
 #define LZ_PB_ROWS(abl)                                                                                                            \
-  hipLaunchKernelGGL(k_pb_rows<abl>, dim3(pb->nRB), dim3(kPbThreads), pb->lds2, s, pb->rbhead, pb->rbseg, A.rowptr, pb->perm, pb->T2, segcap, \
-                     x_own, y, part)
+  hipLaunchKernelGGL(k_pb_rows<abl>, dim3(grid), dim3(kPbThreads), pb->lds2, s, pb->rbhead, pb->rbseg, A.rowptr, pb->perm, pb->T2, pb->segmax, \
+                     pb->nRB, x_own, y, part)
 #ifdef LZ_KBENCH  // timing-only ablation arms (wrong results): 1 no product loads, 2 no perm loads, 7 neither and no LDS gathers
   if (A.ablation == 1) {
     LZ_PB_ROWS(1);

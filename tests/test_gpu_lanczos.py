@@ -407,12 +407,12 @@ def test_ablation_knobs_are_rejected_by_the_product_library(hip):
     h.close()
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4])
-@pytest.mark.parametrize("dims,n", [((300, 250), 50), ((331, 211), 37), ((512, 256), 200)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("dims,n", [((300, 250), 50), ((331, 211), 37), ((512, 256), 200), ((331, 211), 197), ((331, 211), 193)])
 def test_ritz_backtransform_kernels(hip, variant, dims, n):
-    """Y = V S (Lanczos.py:153-156) by the three FP64-MFMA kernels - 0: one workgroup per 128 rows, one wave per SIMD with a
-    32-row x n tile (default); 2: the same tile walked by persistent waves; 3: persistent, two waves per SIMD with 16-row
-    tiles, S staged through LDS; 4: persistent, one wave per SIMD with a 32-row tile, S through LDS - against NumPy on the fetched basis, ragged row and column counts included."""
+    """Y = V S (Lanczos.py:153-156) by the FP64-MFMA kernels - 0: automatic choice (5 where it applies, else 1); 1: one workgroup per 128 rows, one wave per SIMD with a
+    32-row x n tile; 2: the same tile walked by persistent waves; 3: persistent, two waves per SIMD with 16-row
+    tiles, S staged through LDS; 4: persistent, one wave per SIMD with a 32-row tile, S through LDS; 5: S held in registers, 16-row tiles of V through LDS (n in 193..200) - against NumPy on the fetched basis, ragged row and column counts included."""
     A = synthetic.laplacian_2d_5pt(*dims)
     M = A.shape[0]
     v0 = synthetic.reference_start_vector(M)

@@ -14,13 +14,11 @@ _capi.LIB_PATH = os.path.join(os.path.dirname(_capi.LIB_PATH), "liblanczos_kbenc
 out = {}
 only = sys.argv[1] if len(sys.argv) > 1 else "all"
 
-if only != "ritz":
-  pass
 # --- k_pb_rows arms on the C3 matrix: knob 3 = ablation (1 no product loads, 2 no perm loads, 4 no LDS gathers)
-A = synthetic.random_graph_laplacian(10_000_000 if only != "ritz" else 1000, 35_000_000 if only != "ritz" else 3000, seed=1234)
+A = synthetic.random_graph_laplacian(10_000_000 if only not in ("ritz", "sreg") else 1000, 35_000_000 if only not in ("ritz", "sreg") else 3000, seed=1234)
 M = A.shape[0]
 x = np.random.default_rng(0).standard_normal(M)
-for arm in ((0, 1, 2, 7) if only != "ritz" else ()):
+for arm in ((0, 1, 2, 7) if only not in ("ritz", "sreg") else ()):
     h = _capi.Handle(0)
     h.set_options(_capi.FLAG_PROFILE)
     h.set_tuning(3, arm)
@@ -50,7 +48,7 @@ h.set_options(_capi.FLAG_PROFILE | _capi.FLAG_FUSED_NORM | _capi.FLAG_REORTH_PAR
 h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
 a, b = h.run(200, v0)
 S = np.linalg.eigh(np.diag(a) + np.diag(b, 1) + np.diag(b, -1))[1]
-for arm in (0, 2, 3, 4, 0, 4):
+for arm in ((0, 5, 20, 21, 22, 23, 5) if only == "sreg" else (0, 2, 3, 4, 5, 0, 5)):
     h.set_tuning(9, arm)
     h.ritz_vectors(S, fetch=False)
     h.timings()
