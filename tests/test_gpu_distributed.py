@@ -37,6 +37,8 @@ WORKER = textwrap.dedent('''
              # LZ_FLAG_ONE_REDUCE: one all-reduce (+ one halo exchange / all-gather) per iteration instead of two
              ("lap2d_onereduce", lambda lo, hi: synthetic.laplacian_2d_5pt(96, 80, rows=(lo, hi)), 96 * 80, "halo", 40),
              ("graph_onereduce", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 30),
+             # the column-blocked two-phase SpMV (what config C3 runs) on every rank's row block against the all-gathered vector
+             ("graph_twophase", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 30),
              # M = 1000 is not a multiple of world * 32: the last rank's all-gather chunk has a tail no kernel writes; the
              # fresh basis allocation is NaN-poisoned first (tuning knob 13), so the run only survives if the library
              # clears what the dense GEMV reads against zero-padded columns (0 * NaN = NaN)
@@ -49,7 +51,9 @@ WORKER = textwrap.dedent('''
         lo, hi = b[boot.rank], b[boot.rank + 1]
         opts = 64 if name.endswith("_partial") else 0  # LZ_FLAG_REORTH_PARTIAL: every rank must take the same sweep decisions
         s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode, fused_norm=(name != "lap3d"), options=opts,
-                                           one_reduce=name.endswith("_onereduce"))
+                                           one_reduce=name.endswith("_onereduce"), tuning={14: 2} if name == "graph_twophase" else None)
+        if name == "graph_twophase":
+            assert s.h.spmv_plan() == "two-phase"
         if name == "dense_poison":
             s.h.set_tuning(13, 1)
         a, bta = s.execute_Lanczos(n)
@@ -106,6 +110,8 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
         assert per_rank["dense"]["mode"] == "allgather" and per_rank["dense_poison"]["mode"] == "allgather"
         assert per_rank["c4_slab_k200"]["mode"] == "halo" and per_rank["c5_k500"]["mode"] == "halo"
         assert per_rank["c4_slab_k200"]["device_built_equal"] is True
+        # same matrix, same partition: the two-phase SpMV adds every row's products in CSR order too
+        assert per_rank["graph_twophase"]["da"] == per_rank["graph"]["da"] and per_rank["graph_twophase"]["db"] == per_rank["graph"]["db"]
         assert per_rank["c4_slab_k200"]["prefix"] >= 100 and per_rank["c5_k500"]["prefix"] >= 300, per_rank
         for name, r in per_rank.items():
             if name.endswith("_partial"):
