@@ -218,7 +218,9 @@ int lz_get_ritz_vectors(lz_handle h, double* Y_out);
  * device-resident Y of the last lz_ritz_vectors call (summed over ranks). */
 int lz_ritz_gram(lz_handle h, double* gram_out);
 /* y_i = A * Y[:, i] residual check used by print_good_eigs (Lanczos.py:166-185):
- * out[i] = (A y_i . y_i)^2 / (||A y_i||^2), for all n columns. */
+ * out[i] = (A y_i . y_i)^2 / (||A y_i||^2), for all n columns.  One rank: one fused kernel over the CSR matrix.
+ * Row-block partition (world > 1): collective; every Ritz vector is exchanged and multiplied like a Lanczos vector
+ * (CSR or dense), the 2 n sums travel in one all-reduce, every rank receives the same n values. */
 int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */

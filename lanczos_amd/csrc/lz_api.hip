@@ -1883,10 +1883,39 @@ int lz_ritz_gram(lz_handle h, double* gram_out) {
 int lz_ritz_quality(lz_handle h, double* out) {
   if (!h || !out) return LZ_ERR_ARG;
   if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: call lz_ritz_vectors first");
-  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: CSR matrices only");
-  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: single-rank only (needs ghost rows of Y)");
+  if (h->kind != 1 && !(h->world > 1 || h->tune[6])) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: CSR matrices only");
   LZ_HIP(h, hipSetDevice(h->dev));
   const int n = h->y_n;
+  if (h->world > 1 || h->tune[6]) {
+    // Row-block partition: z = A y_i needs the neighbours' entries of y_i, so every Ritz vector takes the path a Lanczos
+    // vector takes - copied into basis row 0 (saved and restored), exchanged (halo or all-gather), multiplied by the
+    // SpMV kernel, whose epilogue already delivers y_i . z; ||z||^2 from the three-term kernel with zero coefficients.
+    // One all-reduce of the 2 n sums at the end.
+    if (!h->d_V || h->n < 1 || h->y_rows != h->rows) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: the basis of the run is gone");
+    if ((size_t)2 * n > (size_t)2 * qtw_ldp(h->n + 2) + 8) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: coefficient buffer too small");
+    double* v0 = h->d_V;
+    LZ_HIP(h, hipMemcpyAsync(h->d_r2, v0, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    LZ_HIP(h, hipMemsetAsync(h->d_nrm2, 0, 2 * sizeof(double), h->stream));
+    h->halo_inflight_j = -1;
+    int rc = LZ_OK;
+    for (int i = 0; i < n && rc == LZ_OK; ++i) {
+      launch_extract_column(h->d_Y, n, i, h->rows, h->rows_pad, v0, h->stream);
+      rc = step_spmv(h, 0, h->d_c + i, false);
+      if (rc != LZ_OK) break;
+      const int np = launch_three_term(h->d_r, v0, nullptr, h->d_nrm2, h->d_nrm2, h->rows_pad, h->d_part, h->stream);
+      launch_final_sum(h->d_part, np, h->d_c + n + i, h->stream);
+      rc = check_launch(h, "ritz_quality(row-block)");
+    }
+    hipError_t e = hipMemcpyAsync(v0, h->d_r2, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream);  // basis row 0 back
+    if (rc == LZ_OK) rc = comm_allreduce(h, h->d_c, 2 * n);
+    std::vector<double> sums(2 * (size_t)n);
+    if (rc == LZ_OK && e == hipSuccess) e = hipMemcpyAsync(sums.data(), h->d_c, sums.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (rc != LZ_OK) return rc;
+    if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
+    for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];
+    return LZ_OK;
+  }
   const size_t nblk = (size_t)((h->rows + 2047) / 2048);
   double* part = nullptr;
   LZ_TRY(dev_alloc(h, part, (nblk + 1) * 2 * n));

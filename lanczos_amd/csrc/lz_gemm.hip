@@ -742,4 +742,13 @@ int launch_ritz_quality(const CsrDev& A, const double* Y, int64_t ldy, int n, do
   return grid;
 }
 
+__global__ __launch_bounds__(kTPB) void k_extract_column(const double* __restrict__ Y, int64_t ldy, int col, int64_t rows, int64_t rows_pad,
+                                                        double* __restrict__ x) {
+  const int64_t r = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  if (r < rows_pad) x[r] = r < rows ? Y[r * ldy + col] : 0.0;
+}
+void launch_extract_column(const double* Y, int64_t ldy, int col, int64_t rows, int64_t rows_pad, double* x, hipStream_t s) {
+  hipLaunchKernelGGL(k_extract_column, dim3((unsigned)((rows_pad + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, Y, ldy, col, rows, rows_pad, x);
+}
+
 }  // namespace lz

@@ -132,6 +132,8 @@ int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part,
 void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s);
 // per-block [s1 (n), s2 (n)] partials of the Ritz-vector quality sums; returns the number of blocks
 int launch_ritz_quality(const CsrDev& A, const double* Y, int64_t ldy, int n, double* part, hipStream_t s);
+// x[r] = Y[r * ldy + col] for r < rows, 0 for rows <= r < rows_pad
+void launch_extract_column(const double* Y, int64_t ldy, int col, int64_t rows, int64_t rows_pad, double* x, hipStream_t s);
 
 // ---- small-problem engine (lz_small.hip): the whole run as one cooperative kernel
 struct SmallArgs {

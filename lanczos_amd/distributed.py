@@ -478,5 +478,10 @@ class DistributedLanczos:
         self.H_eigvecs_local = self.h.ritz_vectors(S, fetch=fetch)
         return self.H_eigvals
 
+    def ritz_quality(self):
+        """print_good_eigs' figure of merit (A y_i . y_i)^2 / ||A y_i||^2 for every Ritz vector of the last get_H_eigs
+        (Lanczos.py:166-185), on the partitioned matrix: collective, every rank gets the same n values."""
+        return self.h.ritz_quality()
+
     def timings(self):
         return self.h.timings()
