@@ -430,12 +430,35 @@ def main():
         overlap_arm = {"iterations_per_s": round(2 * k / to, 1), "ms_per_solve": round(1e3 * to / 2, 3),
                        "max_abs_coeff_diff_vs_default": float(max(np.abs(a_o - alpha_main).max(), np.abs(b_o - beta_main).max()))}
         solver.h.set_options(solver.options)
+    # (3) N > 1: LZ_FLAG_ONE_REDUCE - alpha, ||r||^2 and the coefficients in ONE all-reduce per iteration (2 collectives per
+    # step instead of 3; pass 1 dots the basis against two columns).  Opt-in until measured on a multi-GPU node - this arm
+    # is that measurement.
+    one_reduce_arm = None
+    if world > 1 and not args.no_overlap_arm and not args.one_reduce:
+        arm_state["arm"] = "one_reduce"
+        solver.h.set_options(solver.options | _capi.FLAG_ONE_REDUCE)
+        solver.execute_Lanczos(k, v0_normalized_local=v0)
+        solver.timings()
+        boot.barrier()
+        solver.h.synchronize()
+        t1r = time.perf_counter()
+        for _ in range(2):
+            a_1, b_1 = solver.execute_Lanczos(k, v0_normalized_local=v0)
+        solver.h.synchronize()
+        boot.barrier()
+        t1r = max(boot.allgather_obj(time.perf_counter() - t1r))
+        tm1 = solver.timings()
+        one_reduce_arm = {"iterations_per_s": round(2 * k / t1r, 1), "ms_per_solve": round(1e3 * t1r / 2, 3),
+                          "comm_calls_per_iteration": round(tm1["comm"]["launches"] / 2.0 / k, 2),
+                          "max_abs_coeff_diff_vs_default": float(max(np.abs(a_1 - alpha_main).max(), np.abs(b_1 - beta_main).max()))}
+        solver.h.set_options(solver.options)
     watchdog.cancel()
     arm_state["arm"] = "none"
 
     if rank == 0:
         line["partial_reorth"] = partial
         line["halo_overlap_arm"] = overlap_arm
+        line["one_reduce_arm"] = one_reduce_arm
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(kind, dims, k)
