@@ -108,7 +108,7 @@ int lz_set_options(lz_handle h, int flags);
  * 8/4/1 positions per lane), 9: Ritz back-transform kernel (0 auto: S-stationary for 193 <= n <= 200, else one workgroup per
  * 128 rows; 1 the latter always; 2..5 A/B arms), 11: two-sided links (2 = single launch), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
  * fresh basis allocation before the required parts are cleared (test knob), 14: irregular SpMV plan (0 auto: the column-blocked
- * two-phase kernels for matrices without column locality, 1 never, 2 always), 10: its products per row block, 15: small problems (0 fused-launch path, 1 plain six-launch path, 2 one-kernel engine, 3 engine on a plain grid)); they take effect
+ * two-phase kernels for matrices without column locality, 1 never, 2 always), 10: its products per row block, 15: loop structure (0 auto: fused-launch path for small problems, three-term recurrence folded into pass 1 up to 4e6 rows per rank; 1 plain six-launch loop; 2 one-kernel engine, 3 engine on a plain grid)); they take effect
  * at the next lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order.  The
  * timing-only ablation arms (knob 1 values >= 20, knob 3) exist only in the kernel-bench build (make KBENCH=1,
  * liblanczos_kbench.so, tools/kbench.py); this library returns LZ_ERR_ARG for them. */
@@ -228,7 +228,9 @@ int lz_last_sweeps(lz_handle h, int* sweeps);
 /* How the last lz_run was executed.  0: six launches per step.  2: the fused-launch path of small problems (a vector of at
  * most eight pass-1 slices, one rank, fused-norm mode): the second-stage reductions and the three-term recurrence ride
  * in the prologue of their consumer kernels - three launches per step, bit-identical results; lz_set_tuning(h, 15, 1)
- * switches it off.  1: the opt-in one-kernel engine (lz_small.hip, lz_set_tuning(h, 15, 2): rows <= 1280; correct and
+ * switches it off.  3: the default loop of problems up to 4e6 rows per rank in fused-norm mode with the full sweep: the three-term
+ * recurrence rides in the prologue of the next step's pass 1 (five launches per step, bit-identical; knob 15 = 1 switches it
+ * off; not with LZ_FLAG_OVERLAP_HALO).  1: the opt-in one-kernel engine (lz_small.hip, lz_set_tuning(h, 15, 2): rows <= 1280; correct and
  * bit-identical, but on MI355X no faster than the launches it replaces - DESIGN.md section 4). */
 int lz_last_engine(lz_handle h, int* engine);
 

@@ -653,6 +653,52 @@ int run_loop_fused_small(lz_handle h, int n) {
   return LZ_OK;
 }
 
+// The default loop of problems that are neither small nor huge (any number of ranks, fused-norm mode, full
+// re-orthogonalisation, at most kThreeTermFusedMaxRows rows per rank - measured: C2 (10^6 rows) +3.6 %, 6 400 .. 350 000 rows
+// +4 .. 11 %, the headline's 10^7 rows +0.4 %: there the separate three-term kernel streams at a higher rate than the
+// prologue does, and the six-launch loop stays):
+// the three-term recurrence r = (A v_j - alpha_j v_j) - beta_{j-1} v_{j-1} rides in the prologue of the NEXT step's pass 1
+// (k_qtw_mfma4<4>, alpha read back from its slot after the all-reduce) instead of being a pass of its own - five launches
+// per step, one read-modify-write of r less, bit-identical coefficients and basis (tests/test_gpu_small.py).
+// lz_set_tuning(h, 15, 1) selects the six-launch loop.
+constexpr int64_t kThreeTermFusedMaxRows = 4'000'000;
+int run_loop_three_term_fused(lz_handle h, int n) {
+  const double M = (double)h->rows;
+  LZ_TRY(step_spmv(h, 0));  // warm-up: y = A v0, alpha_0 (Lanczos.py:108-109)
+  for (int j = 0; j < n; ++j) {
+    const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+    h->prof_iter = (j % pstride) == pstride / 2;
+    const int bidx = (j + n - 2) % (n - 1);
+    QtwFuse fz;
+    fz.apart = nullptr;
+    fz.np = 0;
+    fz.jprev = j > 0 ? j - 1 : 0;     // j == 0: the warm-up's r = A v0 - alpha0 v0 (Lanczos.py:110)
+    fz.jprev2 = j >= 2 ? j - 2 : -1;  // the reference's V[-1] term at its step 0 is the zero row
+    fz.beta_prev = h->d_beta + (j >= 2 ? j - 2 : 0);
+    fz.alpha_out = h->d_alpha + fz.jprev;
+    fz.r_out = h->d_r2;
+    h->qplan.variant = 0;
+    {
+      Scope sc(h, LZ_K_QTW, 8.0 * j * M + 40.0 * M, 2.0 * (j + 1) * M + 4.0 * M);
+      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_r, nullptr, nullptr, h->qplan, h->d_part, 4, h->stream, &fz));
+      LZ_TRY(check_launch(h, "qtw(three-term in the prologue)"));
+    }
+    {
+      Scope sc(h, LZ_K_FINAL, 0, 0);
+      launch_final_rows(h->d_part, j + 1, h->qplan.P, h->d_c, h->stream, h->qplan.family == 2);
+      LZ_TRY(check_launch(h, "final_rows"));
+    }
+    LZ_TRY(comm_allreduce(h, h->d_c, j + 1));
+    {
+      Scope sc(h, LZ_K_UPDATE, 8.0 * j * M + 16.0 * M, 2.0 * (j + 1) * M);
+      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_c, h->d_r2, h->d_beta + bidx, 0, h->stream, 0, -1, 1);
+      LZ_TRY(check_launch(h, "update"));
+    }
+    LZ_TRY(step_spmv(h, j));
+  }
+  return LZ_OK;
+}
+
 int require_basis(lz_handle h, int j) {
   if (!h->d_V) return fail(h, LZ_ERR_STATE, "no basis allocated (call lz_run or lz_basis_alloc first)");
   if (j < 0 || j >= h->n) return fail(h, LZ_ERR_ARG, "basis row index out of range");
@@ -1467,6 +1513,15 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   if (fsmall) {
     LZ_TRY(run_loop_fused_small(h, n));
     h->last_engine = 2;
+    small = true;  // (skips the six-launch loop below)
+  }
+  // everything else in fused-norm mode with the full sweep: the loop with the three-term recurrence folded into pass 1
+  const bool f3 = !small && !one_reduce && h->tune[15] == 0 && (h->flags & LZ_FLAG_FUSED_NORM) &&
+                  !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU | LZ_FLAG_OVERLAP_HALO)) && h->qplan.family == 2 &&
+                  h->tune[1] == 0 && h->tune[8] == 0 && h->rows_pad <= kThreeTermFusedMaxRows;
+  if (f3) {
+    LZ_TRY(run_loop_three_term_fused(h, n));
+    h->last_engine = 3;
     small = true;  // (skips the six-launch loop below)
   }
   if (one_reduce) LZ_TRY(run_loop_onereduce(h, n));

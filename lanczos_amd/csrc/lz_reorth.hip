@@ -342,9 +342,16 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
     for (int q = 0; q < 3; ++q) self3[q] = wave_sum(self3[q]);
   } else if constexpr (SCALE == 4) {
     // fused small-problem mode: finish the previous step here (see QtwFuse), then stage and dot r like SCALE == 2
+    // np > 0 (small problems): alpha is added up here from the SpMV's block partials; np == 0 (any size): alpha has been
+    // reduced (and all-reduced) already and is read back from its slot
     __shared__ double sm16[16];
-    const double al = final_sum_emulated(fz.apart, fz.np, sm16);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fz.alpha_out[0] = al;
+    double al;
+    if (fz.np > 0) {
+      al = final_sum_emulated(fz.apart, fz.np, sm16);
+      if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fz.alpha_out[0] = al;
+    } else {
+      al = fz.alpha_out[0];
+    }
     const double be = fz.jprev2 >= 0 ? fz.beta_prev[0] : 0.0;
     const double2* y2 = reinterpret_cast<const double2*>(r + base);
     double2* ro2 = reinterpret_cast<double2*>(fz.r_out + base);

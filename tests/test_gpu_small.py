@@ -86,6 +86,29 @@ def test_fused_launch_path_is_bit_identical_and_faster(hip, name):
     print(f"\n[fused-launch] {name}: six launches {1e3 * t1:.3f} ms, three launches {1e3 * t0:.3f} ms, x{t1 / t0:.2f}")
 
 
+def _mid_cases():
+    return {
+        "lap2d_80x80_n30": (synthetic.laplacian_2d_5pt(80, 80).to_scipy(), 30),                      # 6400 rows: 13 pass-1 slices
+        "lap3d_24x20x18_n40": (synthetic.laplacian_3d_7pt(24, 20, 18).to_scipy(), 40),
+        "graph_M50000_n25": (synthetic.random_graph_laplacian(50000, 175000, seed=11).to_scipy(), 25),
+        "lap2d_700x500_n24": (synthetic.laplacian_2d_5pt(700, 500).to_scipy(), 24),                   # 350 000 rows
+        "dense_M4500_n12": (synthetic.dense_symmetric(4500, seed=6), 12),
+    }
+
+
+@pytest.mark.parametrize("name", list(_mid_cases()))
+def test_three_term_fused_loop_is_bit_identical(hip, name):
+    """Default loop of everything that is not small: the three-term recurrence rides in the prologue of the next step's
+    pass 1 (five launches per step) - against the plain six-launch loop: same bits."""
+    H, n = _mid_cases()[name]
+    a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True, knob=1)
+    a0, b0, V0, e0, t0 = _run(hip, H, n, engine_off=False, knob=0)
+    assert e1 == "kernels" and e0 == "three-term-fused"
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1), (np.abs(a0 - a1).max(), np.abs(b0 - b1).max())
+    assert np.array_equal(V0, V1), np.abs(V0 - V1).max()
+    print(f"\n[three-term-fused] {name}: six launches {1e3 * t1:.3f} ms, five launches {1e3 * t0:.3f} ms, x{t1 / t0:.2f}")
+
+
 def test_device_scope_arm_is_bit_identical_too(hip):
     """tuning knob 15 = 3: the same kernel on a plain grid with device-scope coherence (what it costs when the blocks do
     NOT share an XCD) - an A/B arm, same bits."""
@@ -111,7 +134,7 @@ def test_engine_is_not_used_where_it_does_not_apply(hip):
     assert _run(hip, Hs, 10, engine_off=False, flags=0)[3] == "kernels"  # not fused-norm mode
     assert _run(hip, Hs, 10, engine_off=True)[3] == "kernels"  # knob 15 = 1: the plain path
     assert _run(hip, Hs, 10, engine_off=False, knob=0)[3] == "fused"  # the default for small problems
-    assert _run(hip, synthetic.laplacian_2d_5pt(80, 80).to_scipy(), 10, engine_off=False, knob=0)[3] == "kernels"  # 6400 rows: 13 slices
+    assert _run(hip, synthetic.laplacian_2d_5pt(80, 80).to_scipy(), 10, engine_off=False, knob=0)[3] == "three-term-fused"  # 6400 rows: 13 slices
     assert _run(hip, Hs, 10, engine_off=False, flags=hip.FLAG_FUSED_NORM | hip.FLAG_REORTH_PARTIAL)[3] == "kernels"
     assert _run(hip, Hs, 10, engine_off=False)[3] == "small"
 
