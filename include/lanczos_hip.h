@@ -106,7 +106,7 @@ int lz_set_options(lz_handle h, int flags);
  * entries per block, 5: fixed-K rows per block, 6: issue the collectives even when world == 1, 7: profile only every
  * value-th iteration of lz_run, 8: update-kernel variant (1 cached loads, 2 one position per lane, 3/4/5 slice owner with
  * 8/4/1 positions per lane), 9: Ritz back-transform kernel (0 auto: S-stationary for 193 <= n <= 200, else one workgroup per
- * 128 rows; 1 the latter always; 2..5 A/B arms), 11: two-sided links (2 = single launch), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
+ * 128 rows; 1 the latter always; 2..5 A/B arms), 11: two-sided Gram-Schmidt links (0/1: streaming kernel + fold kernel per link; A/B arms: 2 single launch with a last-block fold, 3 fold deferred into the next link's prologue), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
  * fresh basis allocation before the required parts are cleared (test knob), 14: irregular SpMV plan (0 auto: the column-blocked
  * two-phase kernels for matrices without column locality, 1 never, 2 always), 10: its products per row block, 15: loop structure (0 auto: fused-launch path for small problems, three-term recurrence folded into pass 1 up to 4e6 rows per rank; 1 plain six-launch loop; 2 one-kernel engine, 3 engine on a plain grid)); they take effect
  * at the next lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order.  The

@@ -1658,7 +1658,8 @@ double* bi_row(lz_handle h, int which, int j) { return bi_base(h, which) + (int6
 // d_bi[7] doubles as the ticket counter of the single-launch A/B arm (tune[11] == 2: the last block folds the partials
 // behind a __threadfence()).  Measured (tools/two_sided_probe.py, profiles/r01/ab_two_sided_links.json): the agent-scope
 // release has to write back the L2 lines the kernel just dirtied, which costs far more than the launch it saves - 157
-// vs 41 ms at M = 2.6e5, 250 vs 98 ms at M = 1e6, 178 vs 75 ms at M = 1e7, a tie at M = 9e4.  Default: two launches.
+// vs 41 ms at M = 2.6e5, 250 vs 98 ms at M = 1e6, 178 vs 75 ms at M = 1e7, a tie at M = 9e4.  Default: two launches.  (A third arm, the fold deferred into the
+// consumer's prologue, tune[11] == 3, is no faster either: see bi_reorth.)
 unsigned* bi_ticket(lz_handle h) { return h->tune[11] == 2 ? reinterpret_cast<unsigned*>(h->d_bi + 7) : nullptr; }
 
 int bi_alloc(lz_handle h, int n, int zero_rows) {
@@ -1674,7 +1675,7 @@ int bi_alloc(lz_handle h, int n, int zero_rows) {
     LZ_TRY(dev_alloc(h, h->d_bi, 8));
     h->bi_n = n;
   }
-  LZ_TRY(ensure_part(h, (size_t)bi_partials_needed()));
+  LZ_TRY(ensure_part(h, (size_t)2 * bi_partials_needed()));  // two partial buffers: a link whose fold is deferred leaves its partials for its consumer
   const size_t zr = (size_t)std::min(zero_rows, n) * (size_t)h->ldv * sizeof(double);
   for (int w = 1; w < 4; ++w) LZ_HIP(h, hipMemsetAsync(bi_base(h, w), 0, zr, h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_s, 0, (size_t)h->ldv * sizeof(double), h->stream));
@@ -1694,32 +1695,43 @@ int bi_reorth(lz_handle h, int jj, bool from_rs) {
   double *q = bi_row(h, 0, jj), *p = bi_row(h, 1, jj), *qb = bi_row(h, 2, jj), *pb = bi_row(h, 3, jj);
   const double M = (double)h->rows;
   Scope sc(h, LZ_K_QTW, (2.0 * jj * 64.0 + 5.0 * 32.0) * M, (2.0 * jj * 12.0) * M);
+  // A/B arm (tune[11] == 3): a link's four sums are not folded by a launch of their own - the link leaves its block
+  // partials in one of two buffers and the NEXT link (which applies the axpy they decide) folds them in its prologue, in
+  // k_bi_final's order: one launch per link instead of two, same bits.  Measured (tests/test_gpu_two_sided.py, device
+  // time): 0.81-0.92x - a dependent launch costs ~4 us here and the emulated fold (16 shuffle trees per block) as much,
+  // so the separate fold kernel stays the default.
+  const bool defer = h->tune[11] == 3 && !tk;
+  double* pbuf[2] = {h->d_part, h->d_part + bi_partials_needed()};
+  int cur = 0;  // buffer the next link writes its partials to
+  const double* pend = nullptr;  // where the previous link's deferred partials are
+  auto link = [&](int first, int pnd, int dots, double* x, double* y, const double* xs, const double* ys, const double* ff, const double* ap,
+                  const double* bp, const double* a, const double* b, int epi) {
+    launch_bi(first, pnd, dots, x, y, xs, ys, ff, ap, bp, S, a, b, len, pbuf[cur], epi, S, f, nullptr, nullptr, tk, h->stream, pnd ? pend : nullptr,
+              defer);
+    pend = (defer && dots == 0) ? pbuf[cur] : nullptr;
+    cur ^= 1;
+  };
   // project q on the orthonormalised p's and p on the orthonormalised q's, one vector at a time (:409-416)
   for (int i = 0; i < jj; ++i) {
     const double *a = bi_row(h, 3, i), *b = bi_row(h, 2, i);
     if (i == 0)
-      launch_bi(from_rs ? 1 : 0, 0, 0, q, p, h->d_r, h->d_s, f, nullptr, nullptr, nullptr, a, b, len, h->d_part, 0, S, f, nullptr, nullptr,
-                tk, h->stream);
+      link(from_rs ? 1 : 0, 0, 0, q, p, h->d_r, h->d_s, f, nullptr, nullptr, a, b, 0);
     else
-      launch_bi(0, 1, 0, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, i - 1), bi_row(h, 2, i - 1), S, a, b, len, h->d_part, 0, S, f,
-                nullptr, nullptr, tk, h->stream);
+      link(0, 1, 0, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, i - 1), bi_row(h, 2, i - 1), a, b, 0);
   }
   // last axpy + q.p  ->  f = {sqrt|q.p|, sqrt|q.p|, sign(q.p)}; rescale so that q.p = +-1 (:418-420) + the two norms
-  launch_bi(0, 1, 1, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, jj - 1), bi_row(h, 2, jj - 1), S, nullptr, nullptr, len, h->d_part, 1, S,
-            f, nullptr, nullptr, tk, h->stream);
-  launch_bi(1, 0, 2, q, p, q, p, f, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S, f, nullptr, nullptr, tk, h->stream);
+  link(0, 1, 1, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, jj - 1), bi_row(h, 2, jj - 1), nullptr, nullptr, 1);
+  link(1, 0, 2, q, p, q, p, f, nullptr, nullptr, nullptr, nullptr, 2);
   // q_basis[jj] = q / |q|, p_basis[jj] = p / |p| (:423-424), made orthogonal to the earlier basis vectors (:427-434)
   for (int i = 0; i < jj; ++i) {
     const double *a = bi_row(h, 2, i), *b = bi_row(h, 3, i);
     if (i == 0)
-      launch_bi(1, 0, 0, qb, pb, q, p, f, nullptr, nullptr, nullptr, a, b, len, h->d_part, 0, S, f, nullptr, nullptr, tk, h->stream);
+      link(1, 0, 0, qb, pb, q, p, f, nullptr, nullptr, a, b, 0);
     else
-      launch_bi(0, 1, 0, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, i - 1), bi_row(h, 3, i - 1), S, a, b, len, h->d_part, 0, S, f,
-                nullptr, nullptr, tk, h->stream);
+      link(0, 1, 0, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, i - 1), bi_row(h, 3, i - 1), a, b, 0);
   }
-  launch_bi(0, 1, 2, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, jj - 1), bi_row(h, 3, jj - 1), S, nullptr, nullptr, len, h->d_part, 2, S,
-            f, nullptr, nullptr, tk, h->stream);
-  launch_bi(1, 0, 3, qb, pb, qb, pb, f, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S, f, nullptr, nullptr, tk, h->stream);  // :437-438
+  link(0, 1, 2, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, jj - 1), bi_row(h, 3, jj - 1), nullptr, nullptr, 2);
+  link(1, 0, 3, qb, pb, qb, pb, f, nullptr, nullptr, nullptr, nullptr, 2);  // :437-438
   return check_launch(h, "bireorthogonalize");
 }
 

@@ -114,12 +114,13 @@ void launch_gather(const double* x, const int32_t* idx, int64_t n, double* buf, 
 // 1 -> x.y (epi 1: fo = {sqrt|.|, sqrt|.|, sign}); 2 -> [x.x, y.y] (epi 2: fo = {sqrt, sqrt, 1}); 3 -> none.
 void launch_bi(int first, int pend, int dots, double* x, double* y, const double* xs, const double* ys, const double* f,
                const double* ap, const double* bp, const double* Sp, const double* a, const double* b, int64_t len, double* part,
-               int epi, double* S, double* fo, double* o0, double* o1, unsigned* ticket, hipStream_t s);
+               int epi, double* S, double* fo, double* o0, double* o1, unsigned* ticket, hipStream_t s, const double* pend_part = nullptr,
+               bool defer_fold = false);
 // r -= c0 u, s -= c1 v (sub); dots 0: o0 = (da.r + db.s)/2; 1: o0 = sqrt|r.s|, o1 = r.s/o0, fo = {o0, o1, 1}; 2: o0 = da.r
 void launch_bi_two_term(int sub, int dots, double* r, double* sv, const double* u, const double* v, const double* c0, const double* c1,
                         const double* da, const double* db, int64_t len, double* part, double* fo, double* o0, double* o1,
                         unsigned* ticket, hipStream_t s);  // ticket != nullptr: the last block folds the partials (one launch)
-int bi_partials_needed();
+int bi_partials_needed();  // per partial buffer; the handle keeps two (deferred folds ping-pong between them)
 
 // Y(rows x n, row-major, ldy) = sum_k V[k][m] * S[k][i]   (FP64 MFMA)
 // variant 0/1: one workgroup per 128 rows, one wave per SIMD owning 32 rows x all columns (default: the fastest of the

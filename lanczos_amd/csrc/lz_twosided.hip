@@ -81,11 +81,37 @@ __device__ __forceinline__ void bi_last_block_final(unsigned* ticket, const doub
   }
 }
 
+// The fold of k_bi_final<0> (1024 threads: one partial per thread, wave shuffle tree, 16 wave sums added in order) for the
+// four sums of a link, evaluated by every 256-thread block of the CONSUMER kernel: each wave plays four of the sixteen.
+// Same additions in the same order, so a link whose fold rides here produces the same bits as with the separate kernel.
+__device__ __forceinline__ void bi_fold4_emulated(const double* __restrict__ pp, int NBp, double (&tot)[4]) {
+  __shared__ double sm16[4][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    for (int vw = w; vw < 16; vw += kTPB / 64) {
+      double acc = 0.0;
+      for (int i = vw * 64 + lane; i < NBp; i += 1024) acc += pp[(int64_t)k * NBp + i];
+      acc = wave_sum(acc);
+      if (lane == 0) sm16[k][vw] = acc;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm16[k][q];
+    tot[k] = t;
+  }
+}
+
+// pp != nullptr (PEND links of the default path): the previous link's per-block partials (NBp blocks x 4 sums) - the
+// fold that k_bi_final<0> would do in a launch of its own is done here, by every block (see bi_fold4_emulated).
 template <int FIRST, int PEND, int DOTS>
 __global__ __launch_bounds__(kTPB) void k_bi(double* x, double* y, const double* xs, const double* ys, const double* f,
                                             const double* ap, const double* bp, const double* Sp, const double* a,
                                             const double* b, int64_t n2, int NB, double* __restrict__ part, unsigned* ticket,
-                                            double* S, double* fo) {
+                                            double* S, double* fo, const double* __restrict__ pp, int NBp) {
   __shared__ double sm[kTPB / 64];
   double fx = 1.0, fy = 1.0, sg = 1.0, cx = 0.0, cy = 0.0;
   if (FIRST) {
@@ -94,8 +120,15 @@ __global__ __launch_bounds__(kTPB) void k_bi(double* x, double* y, const double*
     sg = f[2];
   }
   if (PEND) {
-    cx = Sp[0] / Sp[1];
-    cy = Sp[2] / Sp[3];
+    if (pp) {
+      double tot[4];
+      bi_fold4_emulated(pp, NBp, tot);
+      cx = tot[0] / tot[1];
+      cy = tot[2] / tot[3];
+    } else {
+      cx = Sp[0] / Sp[1];
+      cy = Sp[2] / Sp[3];
+    }
   }
   double2* x2 = reinterpret_cast<double2*>(x);
   double2* y2 = reinterpret_cast<double2*>(y);
@@ -245,13 +278,18 @@ static int bi_grid(int64_t n2) {
 
 int bi_partials_needed() { return 4 * kBiMaxBlocks; }
 
+// pend_part: where the PREVIOUS link left its block partials when its fold was deferred (else nullptr: Sp holds the sums);
+// defer_fold: this link's own fold is left to its consumer (dots == 0 only; the partials stay in `part`).
 void launch_bi(int first, int pend, int dots, double* x, double* y, const double* xs, const double* ys, const double* f,
                const double* ap, const double* bp, const double* Sp, const double* a, const double* b, int64_t len, double* part,
-               int epi, double* S, double* fo, double* o0, double* o1, unsigned* ticket, hipStream_t s) {
+               int epi, double* S, double* fo, double* o0, double* o1, unsigned* ticket, hipStream_t s, const double* pend_part,
+               bool defer_fold) {
   const int64_t n2 = len >> 1;
   const int NB = bi_grid(n2);
   const dim3 g(NB), t(kTPB);
-#define LZ_BI(F, P, D) hipLaunchKernelGGL((k_bi<F, P, D>), g, t, 0, s, x, y, xs, ys, f, ap, bp, Sp, a, b, n2, NB, part, ticket, S, fo)
+  const double* pp = pend ? pend_part : nullptr;
+  const int NBp = NB;  // every link of a chain runs over the same length
+#define LZ_BI(F, P, D) hipLaunchKernelGGL((k_bi<F, P, D>), g, t, 0, s, x, y, xs, ys, f, ap, bp, Sp, a, b, n2, NB, part, ticket, S, fo, pp, NBp)
   const int key = first * 100 + pend * 10 + dots;
   switch (key) {
     case 100: LZ_BI(1, 0, 0); break;  // first link of a Gram-Schmidt chain, pair formed from a scaled source
@@ -265,7 +303,7 @@ void launch_bi(int first, int pend, int dots, double* x, double* y, const double
     default: break;
   }
 #undef LZ_BI
-  if (dots == 3 || ticket) return;
+  if (dots == 3 || ticket || (defer_fold && dots == 0)) return;
   const int K = dots == 0 ? 4 : (dots == 1 ? 1 : 2);
   const dim3 g1(1), t1(kBiFinalThreads);
   switch (epi) {

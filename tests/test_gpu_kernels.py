@@ -72,11 +72,12 @@ def _two_phase_matrices():
     vals.data = rng.standard_normal(big.nnz)  # non-integer values: products and partial sums really round
     too_long = scipy.sparse.random(40000, 40000, density=0.0002, random_state=rng, format="lil")
     too_long[7, :] = 1.0  # 40000 entries > the largest LDS tile: the layout does not apply, CSR-stream runs instead
-    return {"graph_60000": big, "graph_60000_real": vals.tocsr(), "row_too_long": too_long.tocsr()}
+    short = synthetic.random_graph_laplacian(50000, 40000, seed=3).to_scipy()  # 2.6 entries per row: row blocks end at their 2048-row limit, not at the LDS tile
+    return {"graph_60000": big, "graph_60000_real": vals.tocsr(), "row_too_long": too_long.tocsr(), "short_rows_50000": short}
 
 
 @pytest.mark.parametrize("name", ["graph_5000", "ragged_3000", "longrow_9000", "empty_rows", "lap2d_37x29", "lap2d_400x300",
-                                  "graph_60000", "graph_60000_real", "row_too_long"])
+                                  "graph_60000", "graph_60000_real", "row_too_long", "short_rows_50000"])
 def test_spmv_two_phase_bit_exact(hip, name):
     """The column-blocked two-phase SpMV (lz_spmv_pb.hip; auto-selected for matrices without column locality, forced here
     with tuning knob 14 = 2): products staged through a column-block-major buffer, every row summed out of LDS in CSR
