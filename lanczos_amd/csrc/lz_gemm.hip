@@ -408,6 +408,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sreg(const double* __restrict__
   constexpr int PF = 4;  // fragments are read from LDS PF k-steps ahead of their MFMAs (explicit ring, fully unrolled loops)
   if (h == 1) {
     // ---------------- loader waves: second K half, the K-split panels, the LDS-DMA
+    __builtin_amdgcn_s_setprio(3);  // the longer of a SIMD's two waves (87.5 of 162.5 MFMAs plus the LDS-DMA): its MFMAs go first
     const int q0 = KS * s / 4, q1 = KS * (s + 1) / 4;
     double sr[REM > 0 ? REM : 1][KQ];
 #pragma unroll
