@@ -108,7 +108,7 @@ int lz_set_options(lz_handle h, int flags);
  * 8/4/1 positions per lane), 9: Ritz back-transform kernel (0 auto: S-stationary for 193 <= n <= 200, else one workgroup per
  * 128 rows; 1 the latter always; 2..5 A/B arms), 11: two-sided Gram-Schmidt links (0/1: streaming kernel + fold kernel per link; A/B arms: 2 single launch with a last-block fold, 3 fold deferred into the next link's prologue), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
  * fresh basis allocation before the required parts are cleared (test knob), 14: irregular SpMV plan (0 auto: the column-blocked
- * two-phase kernels for matrices without column locality, 1 never, 2 always), 10: its products per row block, 15: loop structure (0 auto: fused-launch path for small problems, three-term recurrence folded into pass 1 up to 4e6 rows per rank; 1 plain six-launch loop; 2 one-kernel engine, 3 engine on a plain grid)); they take effect
+ * two-phase kernels for matrices without column locality, 1 never, 2 always), 10: its products per row block, 15: loop structure (0 auto: fused-launch path for small problems, three-term recurrence folded into pass 1 up to 4e6 rows per rank; 1 plain six-launch loop; A/B arms: 2 one-kernel engine, 3 engine on a plain grid, 5 one launch per step)); they take effect
  * at the next lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order.  The
  * timing-only ablation arms (knob 1 values >= 20, knob 3) exist only in the kernel-bench build (make KBENCH=1,
  * liblanczos_kbench.so, tools/kbench.py); this library returns LZ_ERR_ARG for them. */
@@ -225,7 +225,9 @@ int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
 int lz_last_sweeps(lz_handle h, int* sweeps);
-/* How the last lz_run was executed.  0: six launches per step.  2: the fused-launch path of small problems (a vector of at
+/* How the last lz_run was executed.  0: six launches per step.  4: the opt-in per-step kernels (lz_set_tuning(h, 15, 5); rows <= 1280
+ * padded, n <= 64, one rank, fused-norm mode, short CSR rows or dense): ONE launch per step, every block redoes the vector work of
+ * the step and multiplies its share of the rows - bit-identical, but slower than the three launches it replaces.  2: the fused-launch path of small problems (a vector of at
  * most eight pass-1 slices, one rank, fused-norm mode): the second-stage reductions and the three-term recurrence ride
  * in the prologue of their consumer kernels - three launches per step, bit-identical results; lz_set_tuning(h, 15, 1)
  * switches it off.  3: the default loop of problems up to 4e6 rows per rank in fused-norm mode with the full sweep: the three-term

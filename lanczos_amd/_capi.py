@@ -468,11 +468,11 @@ class Handle:
     def last_engine(self):
         """"kernels": six launches per step; "fused": the three-launch path of small problems (second-stage reductions
         and the three-term recurrence folded into their consumer kernels); "three-term-fused": five launches per step (the
-        three-term recurrence folded into pass 1; the default between the small problems and 4e6 rows per rank); "small": the opt-in
-        one-kernel engine."""
+        three-term recurrence folded into pass 1; the default between the small problems and 4e6 rows per rank); "step": the
+        opt-in one-launch-per-step kernels (every block redoes the vector work); "small": the opt-in one-kernel engine."""
         k = C.c_int()
         self.check(self.lib.lz_last_engine(self._h, C.byref(k)))
-        return ("kernels", "small", "fused", "three-term-fused")[k.value]
+        return ("kernels", "small", "fused", "three-term-fused", "step")[k.value]
 
     def timings(self):
         t = LzTimings()

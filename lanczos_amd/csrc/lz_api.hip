@@ -653,6 +653,8 @@ int run_loop_fused_small(lz_handle h, int n) {
   return LZ_OK;
 }
 
+constexpr int kSmallStepMaxN = 64;  // per-step kernels: every block redoes both passes over all n rows
+
 // The default loop of problems that are neither small nor huge (any number of ranks, fused-norm mode, full
 // re-orthogonalisation, at most kThreeTermFusedMaxRows rows per rank - measured: C2 (10^6 rows) +3.6 %, 6 400 .. 350 000 rows
 // +4 .. 11 %, the headline's 10^7 rows +0.4 %: there the separate three-term kernel streams at a higher rate than the
@@ -1449,7 +1451,13 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   // Opt-in (tune[15] == 2, or 3 for the plain-grid arm): measured on MI355X it is NOT faster than the six launches per
   // step it replaces (0.86-1.14x, profiles/r02/small_engine.json) - a device-coherent round trip costs ~2 us here, about
   // what a kernel boundary costs, and a step needs a dozen of them.  Kept as a tested experiment, off by default.
-  bool small = h->tune[15] >= 2 && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
+  // tune[15] == 5 and n <= 64: the same conditions select the PER-STEP kernels (k_small_step: one launch per step, every
+  // block redoes the vector work, no grid barrier).  Bit-identical too, and measured SLOWER than the three-launch path
+  // (C1 0.43 vs 0.37 ms, 1Dbox 1.26 vs 0.94 ms, a 32 x 32 Laplacian 1.12 vs 0.56 ms: the phases of a step are latency
+  // chains - rows written by the previous launch come from HBM or another XCD's L2 - and one block walks them all
+  // back to back instead of three grids each doing one): opt-in A/B arm.
+  const bool want_steps = h->tune[15] == 5 && n <= kSmallStepMaxN;
+  bool small = (h->tune[15] == 2 || h->tune[15] == 3 || want_steps) && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
                !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_SPMV_SCALAR | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->qplan.family == 2 &&
                h->qplan.L == 512 && h->rows_pad <= kSmallMaxPadRows && h->tune[1] == 0 && h->tune[8] == 0 && n <= 4096;
   SmallArgs sa;
@@ -1488,6 +1496,22 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     sa.beta = h->d_beta;
     sa.bar = reinterpret_cast<unsigned*>(h->d_nrm2);  // 16 bytes, zeroed by basis_alloc
     sa.xcc = reinterpret_cast<unsigned*>(h->d_part + 3400);
+    if (want_steps) {
+      // one launch per step: first SpMV, steps j = -1 .. n-2, the last alpha
+      const int nb = h->kind == 2 ? (int)std::min<int64_t>(256, (h->rows + 3) / 4) : (int)std::max<int64_t>(1, (h->rows + kTPB - 1) / kTPB);
+      const double Mr = (double)h->rows;
+      LZ_HIP(h, launch_small_step(sa, 0, -1, nb, h->stream));
+      for (int j = -1; j <= n - 2; ++j) {
+        const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+        h->prof_iter = ((j + 1) % pstride) == pstride / 2;
+        Scope sc(h, LZ_K_UPDATE, spmv_bytes(h) + 16.0 * (j + 2) * Mr + 40.0 * Mr, spmv_flops(h) + 4.0 * (j + 2) * Mr);
+        LZ_HIP(h, launch_small_step(sa, 1, j, nb, h->stream));
+      }
+      h->prof_iter = true;
+      LZ_HIP(h, launch_small_step(sa, 2, n - 1, 1, h->stream));
+      LZ_TRY(check_launch(h, "small_step"));
+      h->last_engine = 4;
+    } else {
     h->acc.launches[LZ_K_FINAL] += 1;
     // tune[15] == 2: the participating blocks share one XCD (every eighth block of the grid); 3: plain grid over all XCDs
     LZ_HIP(h, launch_small_run(sa, small_grid(sa.rows_pad), h->tune[15] == 2, h->stream));
@@ -1504,10 +1528,13 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
       LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
       LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
     }
+    h->last_engine = small ? 1 : 0;
+    }
+  } else {
+    h->last_engine = 0;
   }
-  h->last_engine = small ? 1 : 0;
   // fused-launch path for small problems (tune[15] == 1 switches it off): see run_loop_fused_small
-  const bool fsmall = !small && h->tune[15] == 0 && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
+  const bool fsmall = !small && (h->tune[15] == 0 || h->tune[15] == 5) && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
                       !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->qplan.family == 2 && h->qplan.G <= 8 &&
                       h->tune[1] == 0 && h->tune[8] == 0 && n <= 4096 && h->part_cap >= fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G;
   if (fsmall) {
@@ -1516,7 +1543,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     small = true;  // (skips the six-launch loop below)
   }
   // everything else in fused-norm mode with the full sweep: the loop with the three-term recurrence folded into pass 1
-  const bool f3 = !small && !one_reduce && h->tune[15] == 0 && (h->flags & LZ_FLAG_FUSED_NORM) &&
+  const bool f3 = !small && !one_reduce && (h->tune[15] == 0 || h->tune[15] == 5) && (h->flags & LZ_FLAG_FUSED_NORM) &&
                   !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU | LZ_FLAG_OVERLAP_HALO)) && h->qplan.family == 2 &&
                   h->tune[1] == 0 && h->tune[8] == 0 && h->rows_pad <= kThreeTermFusedMaxRows;
   if (f3) {

@@ -163,5 +163,6 @@ struct SmallArgs {
 constexpr int kSmallMaxPadRows = 1280;
 int small_grid(int rows_pad);
 hipError_t launch_small_run(const SmallArgs& a, int nb, bool local, hipStream_t s);
+hipError_t launch_small_step(const SmallArgs& a, int mode, int j, int nb, hipStream_t s);
 
 }  // namespace lz

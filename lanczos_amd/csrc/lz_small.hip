@@ -43,13 +43,19 @@ namespace {
 // hang), sc0 buffer loads likewise, L2 atomics used as loads (fetch_add 0) are coherent but serialise (tens of thousands
 // per step), release/acquire fences cost ~8 us per barrier.  Device-scope loads and write-through stores are the
 // cheapest correct protocol - ~2 us per dependent round trip, wherever the blocks sit.
-template <bool LOCAL>
+// COH 0 / 1: the one-kernel engine (plain grid / one XCD), device-scope accesses as described above.  COH 2: the per-step
+// kernels (k_small_step): writer and reader are separated by a kernel boundary, plain loads and stores.
+template <int COH>
 __device__ __forceinline__ double ld_sh(const double* base, int idx) {
+  if (COH == 2) return base[idx];
   return __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <bool LOCAL>
+template <int COH>
 __device__ __forceinline__ void st_sh(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (COH == 2)
+    *p = v;
+  else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Monotonic-counter grid barrier over the nb participating blocks.  Every participant calls it the same number of times
@@ -86,7 +92,7 @@ __device__ __forceinline__ bool grid_sync(unsigned* bar, unsigned nb, unsigned* 
 //   dense : k_gemv_dense   - blocks of 4 rows, part = (((0 + d0) + d1) + d2) + d3
 //   CSR   : k_spmv_stream / k_spmv_fixed - thread t of a row block adds its rows r0 + t + 256 q, block_sum over 4 waves
 //   then k_final_sum over the partials (1024 threads = 16 waves, one partial per thread, shuffle tree, 16 sequential adds).
-template <bool LOCAL>
+template <int LOCAL>
 __device__ double small_alpha(const SmallArgs& a, double* parts, double* sm16) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (a.kind == 2) {
@@ -125,7 +131,7 @@ __device__ double small_alpha(const SmallArgs& a, double* parts, double* sm16) {
 }
 
 // r = A V[j] on the rows dealt to this block, per-row products for alpha
-template <bool LOCAL>
+template <int LOCAL>
 __device__ void small_spmv(const SmallArgs& a, const double* __restrict__ x, int bid, int nb) {
   const int lane = threadIdx.x & 63;
   if (a.kind == 2) {
@@ -331,6 +337,164 @@ __global__ __launch_bounds__(kTPB) void k_small_run(SmallArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-step kernel: ONE launch per Lanczos step, no grid barrier.  The default for the smallest problems (rows_pad <= 1280,
+// n <= 64: BASELINE config C1, 1Dbox.py) - the three-launch path spends 5.2 us per dependent kernel there
+// (profiles/r02/launch_bound_probe.txt).  The only data a step needs from OTHER blocks is the SpMV result, so every block
+// redoes the vector work of the step for itself - alpha, the three-term recurrence, both re-orthogonalisation passes over
+// ALL positions, from its own LDS - then multiplies its share of the rows by the new vector and leaves y and the per-row
+// products for the next launch.  Block 0 publishes alpha, beta and the new basis row.  Same arithmetic contract as the
+// engine above (same trees, same MFMA sequence, same expressions): bit-identical to the multi-kernel paths.
+// MODE 0: r = A x0 only (first launch); 1: a whole step; 2: the last alpha only.
+template <int MODE>
+__global__ __launch_bounds__(kTPB) void k_small_step(SmallArgs a, int j) {
+  __shared__ double2 sw[kSmallMaxPad / 2 + 64];
+  __shared__ double vnew[kSmallMaxPad];
+  __shared__ double parts[kSmallMaxParts];
+  __shared__ double sm16[16];
+  __shared__ double selfw[kTPB / 64];
+  __shared__ double pcs[kSmallMaxPad];
+  const int bid = blockIdx.x, nb = gridDim.x;
+  if (MODE == 0) {
+    small_spmv<2>(a, a.x0, bid, nb);
+    return;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = a.n, cnt2 = a.rows_pad >> 1;
+  const int64_t ld2 = a.ldv >> 1;
+  double2* V2 = reinterpret_cast<double2*>(a.V);
+  const int vj = j < 0 ? 0 : j;
+  const double al = small_alpha<2>(a, parts, sm16);
+  if (bid == 0 && threadIdx.x == 0) a.alpha[vj] = al;
+  if (MODE == 2) return;
+  // beta of the previous step (the norm that formed V[j]): block 0 of the previous launch stored it
+  const double beta_prev = j > 0 ? a.beta[(j + n - 2) % (n - 1)] : 0.0;
+  {
+    const double2* v2 = j < 0 ? reinterpret_cast<const double2*>(a.x0) : V2 + (int64_t)vj * ld2;
+    const double2* m2 = j > 0 ? V2 + (int64_t)(j - 1) * ld2 : nullptr;  // j == 0: the reference's V[-1] is the zero row
+    const double2* y2 = reinterpret_cast<const double2*>(a.y);
+    for (int p = threadIdx.x; p < cnt2; p += kTPB) {
+      double2 x = y2[p];
+      const double2 v = v2[p];
+      x.x = x.x - v.x * al;
+      x.y = x.y - v.y * al;
+      if (m2) {
+        const double2 m = m2[p];
+        x.x = x.x - m.x * beta_prev;
+        x.y = x.y - m.y * beta_prev;
+      }
+      sw[p] = x;
+    }
+  }
+  __syncthreads();
+  // pass 1 for row jn: the grouping of the multi-kernel path (see k_small_run); every block does every tile
+  const int jn = j + 1, nrows = jn + 1;
+  const int nslices = (a.rows_pad + 511) >> 9;
+  double rr = 0.0;
+  for (int b = 0; b < nslices; ++b) {
+    const int c2 = ((a.rows_pad - 512 * b < 512 ? a.rows_pad - 512 * b : 512)) >> 1;
+    double self = 0.0;
+    if ((int)threadIdx.x < c2) {
+      const double2 v = sw[256 * b + threadIdx.x];
+      self = fma(v.x, v.x, self);
+      self = fma(v.y, v.y, self);
+    }
+    self = wave_sum(self);
+    __syncthreads();
+    if (lane == 0) selfw[w] = self;
+    __syncthreads();
+    rr = rr + (((selfw[0] + selfw[1]) + selfw[2]) + selfw[3]);
+  }
+  {
+    const int li = lane & 3, blk = (lane >> 2) & 3, lk = lane >> 4;
+    const int eoff = 8 * blk + 2 * lk;
+    const int ntiles = jn > 0 ? (nrows + 7) >> 3 : 0;
+    for (int k = w; k < ntiles; k += kTPB / 64) {
+      const int i0 = 8 * k;
+      const double* rowp[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        int i = i0 + 4 * t + li;
+        if (i >= nrows) i = nrows - 1;
+        if (i == jn) i = jn > 0 ? jn - 1 : (nrows > 1 ? 1 : 0);  // row jn is r itself (not formed yet): its sum is r . r
+        rowp[t] = a.V + (int64_t)i * a.ldv;
+      }
+      double c[2] = {0.0, 0.0};
+      for (int b = 0; b < nslices; ++b) {
+        double sb[2] = {0.0, 0.0};
+        for (int q = 0; q < 4; ++q) {
+          const int m_lo = 512 * b + 128 * q;
+          int m_hi = m_lo + 128;
+          if (m_hi > a.rows_pad) m_hi = a.rows_pad;
+          const int nsteps = m_hi > m_lo ? (m_hi - m_lo) >> 5 : 0;
+          const double2* swl = sw + ((m_lo + eoff) >> 1);
+          double acc[2] = {0.0, 0.0};
+          double2 av[2][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              av[t][u] = u < nsteps ? reinterpret_cast<const double2*>(rowp[t] + m_lo + eoff)[16 * u] : make_double2(0.0, 0.0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double2 bv = u < nsteps ? swl[16 * u] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].x, bv.x, acc[t], 0, 0, 0);
+              acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].y, bv.y, acc[t], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            double v = acc[t];
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            sb[t] = q == 0 ? v : sb[t] + v;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) c[t] = c[t] + sb[t];
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = i0 + 4 * t + lk;
+        if ((lane & 15) == 0 && row < nrows && row != jn) pcs[row] = c[t];
+      }
+    }
+  }
+  __syncthreads();
+  // pass 2: beta, V[jn] = 2 r/beta - sum_{i <= jn} c_i V[i] for ALL positions, into LDS (block 0 also publishes the row)
+  const double bnorm = sqrt(rr);
+  if (bid == 0 && threadIdx.x == 0) a.beta[(jn + n - 2) % (n - 1)] = bnorm;
+  {
+    const double* sr = reinterpret_cast<const double*>(sw);
+    for (int e = threadIdx.x; e < a.rows_pad; e += kTPB) {
+      const double wv = sr[e] / bnorm;
+      double tx = 0.0;
+      constexpr int RU = 64;
+      for (int k = 0; k < nrows; k += RU) {
+        double q[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+          if (k + u < nrows) q[u] = (k + u == jn) ? wv : a.V[(int64_t)(k + u) * a.ldv + e];
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+          if (k + u < nrows) {
+            double ck = (k + u == jn) ? rr : pcs[k + u];
+            ck = (k + u == jn) ? ck / (bnorm * bnorm) : ck / bnorm;
+            tx = tx + ck * q[u];
+          }
+      }
+      const double vn = 2.0 * wv - tx;
+      vnew[e] = vn;
+      if (bid == 0) a.V[(int64_t)jn * a.ldv + e] = vn;
+    }
+  }
+  __syncthreads();
+  // r = A V[jn] on this block's rows, per-row products for the next launch's alpha
+  small_spmv<2>(a, vnew, bid, nb);
+}
+
 // participating blocks: one per CU of the one XCD they share (32 CUs; the cooperative grid of 8 x 32 blocks is the most
 // this kernel's registers allow) - every phase is a latency chain per wave (a dense row, an 8-row tile, an element's walk
 // over the basis), so what counts is the number of waves
@@ -345,6 +509,17 @@ hipError_t launch_small_run(const SmallArgs& a, int nb, bool local, hipStream_t 
   void* args[] = {&copy};
   if (local) return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_small_run<true>), dim3(8 * nb), dim3(kTPB), args, 0, s);
   return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_small_run<false>), dim3(nb), dim3(kTPB), args, 0, s);
+}
+
+// the per-step kernels: mode 0 (first SpMV), 1 (step j), 2 (last alpha)
+hipError_t launch_small_step(const SmallArgs& a, int mode, int j, int nb, hipStream_t s) {
+  if (mode == 0)
+    hipLaunchKernelGGL(k_small_step<0>, dim3(nb), dim3(kTPB), 0, s, a, j);
+  else if (mode == 1)
+    hipLaunchKernelGGL(k_small_step<1>, dim3(nb), dim3(kTPB), 0, s, a, j);
+  else
+    hipLaunchKernelGGL(k_small_step<2>, dim3(1), dim3(kTPB), 0, s, a, j);
+  return hipGetLastError();
 }
 
 }  // namespace lz

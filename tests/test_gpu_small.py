@@ -86,6 +86,25 @@ def test_fused_launch_path_is_bit_identical_and_faster(hip, name):
     print(f"\n[fused-launch] {name}: six launches {1e3 * t1:.3f} ms, three launches {1e3 * t0:.3f} ms, x{t1 / t0:.2f}")
 
 
+@pytest.mark.parametrize("name", list(_fused_cases()))
+def test_step_kernels_are_bit_identical(hip, name):
+    """A/B arm (tuning knob 15 = 5; padded rows <= 1280, n <= 64, short CSR rows or dense): ONE launch per step - every block
+    redoes the vector work of the step and multiplies its share of the rows - against the plain six-launch path: same bits
+    (and slower than the default three-launch path: the printed timings are the record).  Where the conditions do not hold
+    the knob falls back to the fused-launch path."""
+    H, n = _fused_cases()[name]
+    a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True, knob=1)
+    a0, b0, V0, e0, t0 = _run(hip, H, n, engine_off=False, knob=5)
+    M = H.shape[0]
+    import scipy.sparse
+    long_rows = scipy.sparse.issparse(H) and np.diff(H.tocsr().indptr).max() > 32
+    applies = M <= 1280 and n <= 64 and not long_rows
+    assert e1 == "kernels" and e0 == ("step" if applies else "fused"), (e0, applies)
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1), (np.abs(a0 - a1).max(), np.abs(b0 - b1).max())
+    assert np.array_equal(V0, V1), np.abs(V0 - V1).max()
+    print(f"\n[step-kernels] {name} ({e0}): six launches {1e3 * t1:.3f} ms, knob 15 = 5 {1e3 * t0:.3f} ms, x{t1 / t0:.2f}")
+
+
 def _mid_cases():
     return {
         "lap2d_80x80_n30": (synthetic.laplacian_2d_5pt(80, 80).to_scipy(), 30),                      # 6400 rows: 13 pass-1 slices
@@ -134,6 +153,7 @@ def test_engine_is_not_used_where_it_does_not_apply(hip):
     assert _run(hip, Hs, 10, engine_off=False, flags=0)[3] == "kernels"  # not fused-norm mode
     assert _run(hip, Hs, 10, engine_off=True)[3] == "kernels"  # knob 15 = 1: the plain path
     assert _run(hip, Hs, 10, engine_off=False, knob=0)[3] == "fused"  # the default for small problems
+    assert _run(hip, Hs, 10, engine_off=False, knob=5)[3] == "step"  # the one-launch-per-step arm
     assert _run(hip, synthetic.laplacian_2d_5pt(80, 80).to_scipy(), 10, engine_off=False, knob=0)[3] == "three-term-fused"  # 6400 rows: 13 slices
     assert _run(hip, Hs, 10, engine_off=False, flags=hip.FLAG_FUSED_NORM | hip.FLAG_REORTH_PARTIAL)[3] == "kernels"
     assert _run(hip, Hs, 10, engine_off=False)[3] == "small"
