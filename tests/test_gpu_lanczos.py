@@ -5,6 +5,8 @@ Tolerance (BASELINE.json north_star): Ritz values within 1e-10 relative - taken
 relative to the spectral scale max|theta| because the test Laplacians are
 singular (lambda_min = 0).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -245,7 +247,8 @@ def test_get_H_eigs_asserts_fire_on_device_gram():
 
 def test_headline_full_size_properties():
     """BASELINE headline size (2-D 5-pt, M = 1e7, k = 200): the first 12 recurrence coefficients against the CPU
-    oracle (a k = 12 oracle run produces the same leading coefficients), and size-independent properties evaluated
+    oracle (a k = 12 oracle run produces the same leading coefficients), all 200 against a full-size run of the reference
+    itself (golden fixture), and size-independent properties evaluated
     on the device: Ritz vectors orthonormal (Gram), every Ritz value within its residual bound of an analytic
     eigenvalue 4 - 2cos(2 pi p/Nx) - 2cos(2 pi q/Ny) of the periodic Laplacian, spectrum inside the Gershgorin
     interval, bit-reproducible reruns."""
@@ -258,6 +261,15 @@ def test_headline_full_size_properties():
     a, b, _ = oracle.execute_lanczos(H, 12, economy=True)
     assert np.abs(np.diag(H_eff)[:12] - a).max() <= 1e-12 * 8
     assert np.abs(np.diag(H_eff, 1)[:11] - b).max() <= 1e-12 * 8
+    # ALL 200 coefficients against the reference itself, run at this size on the CPU (oracle/gen_golden_headline.py, 85 min
+    # per run; the fixture holds alpha / beta and how far a second run with another BLAS thread count moved each of them):
+    # north-star bar 1e-10 of the spectral scale wherever the reference's own arithmetic determines the coefficient to 1e-12
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "headline_lap2d_4000x2500_n200.npz"), allow_pickle=False)
+    assert int(gold["M"]) == nx * ny and int(gold["n"]) == n
+    st_a, st_b = gold["alpha_moved"] <= 1e-12 * 8, gold["beta_moved"] <= 1e-12 * 8
+    assert st_a.sum() >= 150 and st_b.sum() >= 150, (int(st_a.sum()), int(st_b.sum()))
+    assert np.abs(np.diag(H_eff) - gold["alpha"])[st_a].max() <= 1e-10 * 8
+    assert np.abs(np.diag(H_eff, 1) - gold["beta"])[st_b].max() <= 1e-10 * 8
     s.get_H_eigs()  # device back-transform + the reference's two asserts on the device Gram matrix
     G = s._handle.ritz_gram()
     assert np.abs(G - np.eye(n)).max() < 1e-12
