@@ -13,6 +13,8 @@ The CPU oracle cannot run 200-500 full-size iterations in test time, so each con
   (5) Ritz values inside the Gershgorin interval; for the periodic Laplacians each within its residual bound of an
       analytic eigenvalue.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -84,6 +86,26 @@ def test_c3_random_graph_full_size():
     s2 = Lanczos(H)
     s2.execute_Lanczos(n)
     assert np.array_equal(H_eff, s2.H_eff)
+    del s2
+    # Against a FULL-SIZE run of the reference itself on the CPU (oracle/gen_golden_c3.py, ~90 min; fixture: alpha, beta).
+    # The top of this spectrum converges within 200 steps, so late coefficients are rounding noise in the reference too: the
+    # stable prefix is where a run from a start vector with every entry perturbed in its last bit still agrees to 1e-12 of the scale.
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "c3_graph_M1e7_n200.npz"), allow_pickle=False)
+    assert int(gold["M"]) == M and int(gold["n"]) == n
+    np.random.seed(99)  # the reference's default start vector (Lanczos.py:93-97)
+    v0 = np.random.uniform(-1, 1, size=M)
+    v0 = np.nextafter(v0, np.where(np.arange(M) % 2 == 0, 2.0, -2.0))  # EVERY entry moved by one ulp (a 1e-16 relative change of the
+    # vector: the size of one step's rounding differences between two implementations - one entry alone would be 1e-20)
+    s3 = Lanczos(H)
+    s3.execute_Lanczos(n, v0=v0)
+    moved = np.maximum(np.abs(np.diag(s3.H_eff) - np.diag(H_eff)), np.append(np.abs(np.diag(s3.H_eff, 1) - np.diag(H_eff, 1)), 0.0))
+    unstable = np.nonzero(moved > 1e-12 * scale)[0]
+    prefix = int(unstable[0]) if len(unstable) else n
+    assert prefix >= 30, prefix
+    assert np.abs(np.diag(H_eff) - gold["alpha"])[:prefix].max() <= 1e-10 * scale
+    assert np.abs(np.diag(H_eff, 1) - gold["beta"])[: prefix - 1].max() <= 1e-10 * scale
+    print(f"\n[c3 vs reference] stable prefix {prefix} of {n}: max |dalpha| {np.abs(np.diag(H_eff) - gold['alpha'])[:prefix].max():.2e}, "
+          f"max |dbeta| {np.abs(np.diag(H_eff, 1) - gold['beta'])[:prefix - 1].max():.2e} (scale {scale:.0f})")
 
 
 def test_c4_lap3d_7pt_full_size():
