@@ -140,11 +140,27 @@ def cpu_baseline(kind, dims, k, budget_s=40.0):
     return out
 
 
+def ritz_clock(info):
+    """The S-stationary kernel's own clock record (lz_ritz_info): what clock the part held under FP64 MFMA + HBM traffic and
+    how close the kernel runs to the MFMA issue floor IN CYCLES - the wall-time fraction is the product of the two."""
+    if not info:
+        return {}
+    out = {"chunked_rows": info["chunk_rows"]}
+    if info["tiles"] > 0:
+        out.update({"shader_clock_mhz": round(info["clock_mhz"], 1), "cycles_per_16row_tile": round(info["cycles_per_tile"], 1),
+                    "mfma_issue_floor_cycles_per_tile": round(info["mfma_floor_cycles_per_tile"], 1),
+                    "mfma_issue_utilisation_in_cycles": round(info["mfma_floor_cycles_per_tile"] / info["cycles_per_tile"], 4),
+                    "peak_tflops_at_held_clock": round(FP64_MFMA_PEAK_TFLOPS * info["clock_mhz"] / 2400.0, 2)})
+    return out
+
+
 def spawn_ranks(n):
     """Launcher for `python bench.py --gpus N` without torch.distributed.run: N child processes (RANK / LOCAL_RANK /
-    WORLD_SIZE / LZ_RDZV_KEY exported), rank 0's stdout (the JSON line) relayed, exit status = the worst child's.
-    The parent never touches the GPU, and nothing that has is ever re-exec'ed."""
+    WORLD_SIZE / LZ_RDZV_KEY exported), rank 0's stdout (the JSON line) relayed, exit status = the first failing child's.
+    The parent never touches the GPU, and nothing that has is ever re-exec'ed.  All children are polled: when one exits
+    non-zero the others (which would sit in accept() or in a collective) are terminated - exactly the processes started here."""
     import subprocess
+    import threading
     import uuid
 
     key = uuid.uuid4().hex[:16]
@@ -154,14 +170,35 @@ def spawn_ranks(n):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    out0 = []
+    drain = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)  # rank 0 must never block on a full pipe
+    drain.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+                break
+        time.sleep(0.2)
+    if failed is None:
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+        failed = bad[0] if bad else None
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    drain.join(timeout=30)
+    sys.stdout.write(b"".join(x for x in out0 if x).decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit status): {bad}", file=sys.stderr)
-        return max(abs(c) for _, c in bad) or 1
+    if failed is not None:
+        print(f"bench.py: rank {failed[0]} exited with status {failed[1]}; the other ranks were terminated", file=sys.stderr)
+        return abs(failed[1]) or 1
     return 0
 
 
@@ -284,11 +321,13 @@ def main():
         theta = solver.get_H_eigs(fetch=False)
         tr = solver.timings()["ritz"]
         tr["ms_first_call"] = tr_first["ms"]
+        tr["info"] = solver.h.ritz_info()  # chunked? + the S-stationary kernel's own clock record of THIS call
     except _capi.LanczosHipError as e:  # e.g. no room for a second M x k array next to the basis
         print(f"[rank {rank}] Ritz back-transform skipped: {e}", file=sys.stderr)
         theta = np.linalg.eigvalsh(solver.H_eff)
         tr = {"ms": 0.0, "flops": 0.0, "ms_first_call": 0.0}
     assert np.isfinite(theta).all()
+    assert not getattr(solver, "breakdown", False), "Lanczos breakdown in the timed runs: the coefficients are rounding noise"
 
     if rank == 0:
         iters = args.steps * k
@@ -313,6 +352,9 @@ def main():
                 for name, v in measured.items():
                     if name in per_class:
                         per_class[name]["traffic"] = v
+                        # NOT a counter of this run: HBM bytes per launch from separate `rocprofv3 --pmc` passes of the same
+                        # command (FETCH_SIZE / WRITE_SIZE, corrected as the guide prescribes), kept in profiles/
+                        per_class[name]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this workload; static copy)"
             except Exception:
                 pass
         line = {
@@ -351,7 +393,8 @@ def main():
             "ritz_backtransform": {"ms": round(tr["ms"], 3), "ms_first_call": round(tr.get("ms_first_call", 0.0), 3), "tflops": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9, 2),
                                    "bound": "mfma", "peak_tflops": FP64_MFMA_PEAK_TFLOPS,
                                    "frac": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 4),
-                                   "note": "Y = V^T-layout x S (M x k x k) FP64 MFMA GEMM, outside the timed steps; second call of the process (ms_first_call: the first)"},
+                                   "note": "Y = V^T-layout x S (M x k x k) FP64 MFMA GEMM, outside the timed steps; second call of the process (ms_first_call: the first)",
+                                   **ritz_clock(tr.get("info"))},
         }
     else:
         line = None

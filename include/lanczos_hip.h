@@ -208,11 +208,27 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
 /* Krylov basis, row-major (n, rows_local): basis vector j is row j
  * (replaces cp.asnumpy(V.T), Lanczos.py:136; the mirror exposes the transposed view). */
 int lz_get_basis(lz_handle h, double* V_out, int64_t ld);
+/* the entries [row0, row0 + nrows) of every basis vector: (n, nrows) row-major with leading dimension ld >= nrows (a window
+ * of V when the whole (n, rows_local) array is too large to move: BASELINE config C4, 160 GB) */
+int lz_get_basis_block(lz_handle h, int64_t row0, int64_t nrows, double* V_out, int64_t ld);
 /* Ritz back-transform Y = V_cols * S  (Lanczos.py:153-156: n GEMVs np.dot(V, S[:, i])):
- * S is (n, n) row-major (columns = eigenvectors of H_eff), Y_out is (rows_local, n) row-major. */
+ * S is (n, n) row-major (columns = eigenvectors of H_eff), Y_out is (rows_local, n) row-major or NULL (Y stays on the
+ * device for the checks and is fetched later, whole or by rows).  Never fails for lack of room for Y: see lz_ritz_info. */
 int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out);
-/* copy the device-resident Y of the last lz_ritz_vectors call to the host: (rows_local, n) row-major */
+/* copy the Y of the last lz_ritz_vectors call to the host: (rows_local, n) row-major */
 int lz_get_ritz_vectors(lz_handle h, double* Y_out);
+/* rows [row0, row0 + nrows) of that Y: (nrows, n) row-major.  This is how H_eigvecs (Lanczos.py:60-66) is served when the
+ * whole (M, n) array fits neither beside the basis on the device nor on the host. */
+int lz_get_ritz_rows(lz_handle h, int64_t row0, int64_t nrows, double* Y_out);
+/* How the last lz_ritz_vectors call is held.  *chunk_rows = 0: Y is resident on the device; > 0: CHUNKED mode - a second
+ * rows_local x n array does not fit beside the basis (BASELINE config C4 on one GPU: 160 GB + 160 GB), so the device keeps
+ * S and a buffer of that many rows, and lz_get_ritz_rows / lz_get_ritz_vectors / lz_ritz_gram / lz_ritz_quality re-form the
+ * rows (or column batches) they need from the basis: a 16-row tile of Y depends only on the same 16 columns of V.
+ * lz_set_tuning(h, 16, rows) forces the chunked mode (tests).
+ * clock4 (may be NULL; zeros unless the S-stationary kernel ran): {shader clock in MHz while the kernel ran (s_memtime
+ * cycles / s_memrealtime ticks of the constant 100 MHz counter, one workgroup's whole trip), shader cycles per 16-row
+ * tile, the MFMA issue floor in cycles per tile (MFMAs per tile and SIMD x 64), tiles walked by that workgroup}. */
+int lz_ritz_info(lz_handle h, int64_t* chunk_rows, double* clock4);
 /* Device-side versions of the two checks get_H_eigs runs on Y (Lanczos.py:157-158,
  * 288-323): column norms (n) and the (n, n) Gram matrix Y^T Y, computed on the
  * device-resident Y of the last lz_ritz_vectors call (summed over ranks). */

@@ -12,7 +12,8 @@ from ._capi import (FLAG_FUSED_NORM, FLAG_REORTH_PARTIAL, FLAG_PROFILE, FLAG_QTW
 from .hamiltonian import Hamiltonian
 from .irregular import IrrLanczos
 from .regular import Lanczos
+from ._pool import StencilOperator
 
-__all__ = ["Lanczos", "IrrLanczos", "Hamiltonian", "LanczosHipError", "load_library", "FLAG_PROFILE", "FLAG_QTW_MFMA", "FLAG_QTW_VALU",
+__all__ = ["Lanczos", "IrrLanczos", "Hamiltonian", "StencilOperator", "LanczosHipError", "load_library", "FLAG_PROFILE", "FLAG_QTW_MFMA", "FLAG_QTW_VALU",
            "FLAG_SPMV_SCALAR", "FLAG_FUSED_NORM", "FLAG_REORTH_PARTIAL"]
 __version__ = "0.1.0"

@@ -86,8 +86,11 @@ SIGNATURES = {
     "lz_set_allgather": (C.c_int, [_P, C.c_int64]),
     "lz_run": (C.c_int, [_P, C.c_int, _D, _D, _D]),
     "lz_get_basis": (C.c_int, [_P, _D, C.c_int64]),
+    "lz_get_basis_block": (C.c_int, [_P, C.c_int64, C.c_int64, _D, C.c_int64]),
     "lz_ritz_vectors": (C.c_int, [_P, _D, _D]),
     "lz_get_ritz_vectors": (C.c_int, [_P, _D]),
+    "lz_get_ritz_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _D]),
+    "lz_ritz_info": (C.c_int, [_P, _I64, _D]),
     "lz_ritz_gram": (C.c_int, [_P, _D]),
     "lz_ritz_quality": (C.c_int, [_P, _D]),
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
@@ -116,6 +119,8 @@ class LanczosHipError(RuntimeError):
         super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
         self.status = status
 
+
+KBENCH_LIB_PATH = os.path.join(_HERE, "liblanczos_kbench.so")  # kernel-bench build: retired A/B arms + timing-only ablations (tools/, tests of those arms)
 
 _lib = None
 _live_handles = None  # weakref.WeakSet of open Handle objects, closed by an atexit hook (see Handle)
@@ -222,8 +227,10 @@ def f64(a):
 class Handle:
     """Thin RAII wrapper over ``lz_handle``: raises on every non-zero status."""
 
-    def __init__(self, device_id=0):
-        self.lib = load_library()
+    def __init__(self, device_id=0, lib=None):
+        """``lib``: another build of the library (``load_library(KBENCH_LIB_PATH)``: the kernel-bench build); default the product."""
+        self.lib = lib if lib is not None else load_library()
+        self.matrix_uploads = 0  # lz_set_csr / lz_set_dense / stencil assemblies issued through this handle
         self._h = _P()
         st = self.lib.lz_create(C.byref(self._h), int(device_id))
         if st != LZ_OK:
@@ -347,6 +354,7 @@ class Handle:
             ncols_ext = M_global
         self.check(self.lib.lz_set_csr(self._h, int(M_global), int(row0), rows, int(ncols_ext), nnz, i32ptr(rowptr), i32ptr(colidx), dptr(vals)))
         self.rows = rows
+        self.matrix_uploads += 1
 
     def set_dense(self, A):
         A = f64(A)
@@ -354,6 +362,7 @@ class Handle:
             raise ValueError("dense H must be square")
         self.check(self.lib.lz_set_dense(self._h, A.shape[0], dptr(A)))
         self.rows = A.shape[0]
+        self.matrix_uploads += 1
 
     def set_dense_block(self, M_global, row0, A_block):
         """Row block of a dense matrix split over ranks; columns already in the all-gather layout (see the header)."""
@@ -361,6 +370,7 @@ class Handle:
         rows, ncols_ext = A_block.shape
         self.check(self.lib.lz_set_dense_block(self._h, int(M_global), int(row0), rows, ncols_ext, dptr(A_block)))
         self.rows = rows
+        self.matrix_uploads += 1
 
     def build_stencil3d(self, N, points, T_factor, weights4, potential=None, negate_T=False):
         w = f64(weights4)
@@ -393,6 +403,7 @@ class Handle:
                                                      None if pot is None else dptr(pot), int(bool(negate_T)), int(row0), int(rows_local),
                                                      len(gs), i64ptr(gs) if len(gs) else None, i64ptr(gl) if len(gl) else None))
         self.rows = int(rows_local)
+        self.matrix_uploads += 1
 
     SPMV_PLANS = ("scalar", "csr-stream", "fixed-k", "two-phase", "dense")
 
@@ -439,6 +450,13 @@ class Handle:
         self.check(self.lib.lz_get_basis(self._h, dptr(V), self.rows))
         return V
 
+    def get_basis_block(self, r0, r1):
+        """(n, r1 - r0): the entries [r0, r1) of every basis vector"""
+        r0, r1 = int(r0), int(r1)
+        V = np.empty((self.n, r1 - r0))
+        self.check(self.lib.lz_get_basis_block(self._h, r0, r1 - r0, dptr(V), r1 - r0))
+        return V
+
     def ritz_vectors(self, S, fetch=True):
         S = f64(S)
         Y = np.empty((self.rows, self.n)) if fetch else None
@@ -449,6 +467,22 @@ class Handle:
         Y = np.empty((self.rows, self.n))
         self.check(self.lib.lz_get_ritz_vectors(self._h, dptr(Y)))
         return Y
+
+    def ritz_fetch_rows(self, r0, r1):
+        """rows [r0, r1) of the Ritz vectors, (r1 - r0, n): served from the resident Y or re-formed from the basis (chunked mode)"""
+        r0, r1 = int(r0), int(r1)
+        Y = np.empty((r1 - r0, self.n))
+        self.check(self.lib.lz_get_ritz_rows(self._h, r0, r1 - r0, dptr(Y)))
+        return Y
+
+    def ritz_info(self):
+        """{"chunk_rows": 0 (Y resident) or the rows per chunk of the chunked mode, "clock_mhz", "cycles_per_tile",
+        "mfma_floor_cycles_per_tile", "tiles"}: the last four from the S-stationary kernel's own clock record (0 if another kernel ran)"""
+        ch = C.c_int64()
+        clk = np.zeros(4)
+        self.check(self.lib.lz_ritz_info(self._h, C.byref(ch), dptr(clk)))
+        return {"chunk_rows": int(ch.value), "clock_mhz": float(clk[0]), "cycles_per_tile": float(clk[1]), "mfma_floor_cycles_per_tile": float(clk[2]),
+                "tiles": int(clk[3])}
 
     def ritz_gram(self):
         G = np.empty((self.n, self.n))
@@ -468,11 +502,12 @@ class Handle:
     def last_engine(self):
         """"kernels": six launches per step; "fused": the three-launch path of small problems (second-stage reductions
         and the three-term recurrence folded into their consumer kernels); "three-term-fused": five launches per step (the
-        three-term recurrence folded into pass 1; the default between the small problems and 4e6 rows per rank); "step": the
-        opt-in one-launch-per-step kernels (every block redoes the vector work); "small": the opt-in one-kernel engine."""
+        three-term recurrence folded into pass 1; the default between the small problems and 4e6 rows per rank);
+        "one-reduce": LZ_FLAG_ONE_REDUCE; "one-reduce-repeated": such a run whose cancellation guard fired and that was
+        repeated on the default loop; "step" / "small": the retired one-launch-per-step / one-kernel engines (kernel-bench build)."""
         k = C.c_int()
         self.check(self.lib.lz_last_engine(self._h, C.byref(k)))
-        return ("kernels", "small", "fused", "three-term-fused", "step")[k.value]
+        return ("kernels", "small", "fused", "three-term-fused", "step", "one-reduce-repeated", "one-reduce")[k.value]
 
     def timings(self):
         t = LzTimings()

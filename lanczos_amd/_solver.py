@@ -9,9 +9,18 @@ legacy RNG exactly like the reference's CPU branch, CSR packing), assembles the
 small tridiagonal ``H_eff``, calls ``numpy.linalg.eigh`` on it (as the reference
 does, also in its GPU mode, Lanczos.py:151) and formats the diagnostics.
 
-There is deliberately NO CPU implementation of the recurrence here:
-``use_cuda=False`` raises ``NotImplementedError`` (that path is the reference's
-own NumPy code), and a missing HIP extension or GPU raises ``LanczosHipError``.
+There is deliberately NO CPU implementation of the recurrence here: the only
+compute path is the HIP library, and a missing extension or GPU raises
+``LanczosHipError``.  ``use_cuda=False`` (the reference's NumPy branch, which its
+``3Ddeuteron.py:95`` asks for) is accepted and ALSO runs the HIP path, with a
+one-line notice - the two branches of the reference agree to rounding and this
+build is held to its NumPy branch anyway; ``strict_use_cuda = True`` restores the
+``NotImplementedError``.
+
+Multi-GPU: ``Lanczos.devices = [0, 1, ..., 7]`` (class or instance attribute;
+default ``None`` = one GPU, in this process) keeps the same calls and partitions
+H and the Krylov basis row-block-wise over one worker process per GPU (see
+``_pool.py``).
 """
 from __future__ import annotations
 
@@ -24,8 +33,36 @@ from . import _capi
 _NOT_EXECUTED = "Lanczos Algorithm has not been called."
 _CPU_MSG = (
     "lanczos_amd implements the device path only (use_cuda=True runs on the MI355X through liblanczos_hip.so); "
-    "use_cuda=False is the reference's own NumPy path and is not re-implemented here"
+    "use_cuda=False is the reference's own NumPy path and is not re-implemented here (strict_use_cuda is set)"
 )
+_CPU_NOTICE = "+++ use_cuda=False: lanczos_amd has no NumPy path; running the HIP path on the MI355X (same results to rounding)."
+
+
+def _use_cuda_or_notice(obj, use_cuda):
+    """``use_cuda=False`` handling shared by every entry point that takes the flag (Lanczos.py:75,89-91,233)."""
+    if use_cuda:
+        return
+    if getattr(obj, "strict_use_cuda", LanczosBase.strict_use_cuda):
+        raise NotImplementedError(_CPU_MSG)
+    print(_CPU_NOTICE)
+
+
+def _fingerprint(*arrays):
+    """Cheap content hash of the matrix arrays (a few GB/s): decides whether the device copy of H is still current."""
+    try:
+        import xxhash
+
+        h = xxhash.xxh3_64()
+        for a in arrays:
+            h.update(memoryview(np.ascontiguousarray(a)).cast("B"))
+        return h.hexdigest()
+    except ImportError:  # pragma: no cover - xxhash is optional
+        import zlib
+
+        c = 0
+        for a in arrays:
+            c = zlib.crc32(memoryview(np.ascontiguousarray(a)).cast("B"), c)
+        return c
 
 
 def _pack_matrix(H):
@@ -59,18 +96,38 @@ class LanczosBase:
                        # then dot, exactly in the reference's order (the coefficients differ by one rounding of a division)
     reorth = "full"  # "full" = the reference's sweep at every step; "partial" = opt-in Simon partial
                      # re-orthogonalisation (same sweep kernels, run only when semi-orthogonality is about to be lost)
+    devices = None   # None / one entry: this process drives that GPU.  Several entries, e.g. list(range(8)): H and the Krylov
+                     # basis are row-block partitioned over one FRESH worker process per listed GPU (RCCL all-reduces of
+                     # alpha / ||r||^2 / Q^T w, halo or all-gather exchange of the SpMV input); same calls, same results
+    comm_backend = "rccl"  # "host": collectives staged through host memory (several workers on ONE GPU: tests)
+    strict_use_cuda = False  # True: use_cuda=False raises NotImplementedError instead of running the HIP path with a notice
+    cache_matrix = True  # keep H on the device across execute_Lanczos calls while its content hash is unchanged
     _check_eigs = ("normalized", "orthogonal")  # which asserts get_H_eigs runs (Lanczos.py:157-158)
 
     def __init__(self, H):
         self.H = H
-        self.M = np.shape(H)[0]
+        self.M = H.shape[0] if hasattr(H, "shape") else np.shape(H)[0]
         self.Lanczos_has_been_executed = False
         self.H_eigs_have_been_found = False
         self.H_exact_eigs_have_been_found = False
         self._handle = None
+        self._matrix_key = self._matrix_key_alt = None
         self._V = None
         self._H_eigvecs_host = None
         self._timings = None
+
+    def close(self):
+        """Release the device memory (and, with ``devices``, end the worker processes) now rather than at exit."""
+        if self._handle is not None:
+            self._handle.close()
+            self._handle = None
+            self._matrix_key = self._matrix_key_alt = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _say(self, msg):
         if self.verbose:
@@ -130,13 +187,56 @@ class LanczosBase:
         self._say("+++ Finished calculating exact eigs.")
 
     # ------------------------------------------------------------------ the hot path
+    def _multi(self):
+        return self.devices is not None and len(self.devices) > 1
+
+    def _get_handle(self):
+        """The object that owns the device state: a ``_capi.Handle`` (this process, one GPU) or a ``_pool.PoolHandle``
+        (one worker process per entry of ``devices``).  Re-created when ``devices`` changes."""
+        want = tuple(int(d) for d in self.devices) if self.devices is not None else (int(self.device_id),)
+        if self._handle is not None and getattr(self, "_handle_devices", None) != (want, self.comm_backend):
+            self.close()
+        if self._handle is None:
+            if len(want) > 1:
+                from . import _pool
+
+                self._handle = _pool.PoolHandle(want, self.comm_backend)
+            else:
+                self._handle = _capi.Handle(want[0])
+            self._handle_devices = (want, self.comm_backend)
+            self._matrix_key = self._matrix_key_alt = None
+        return self._handle
+
+    def _upload_matrix(self, h):
+        """H -> device(s), skipped when the device copy is still current (same format, shape and content hash): a second
+        ``execute_Lanczos`` on one object then costs no repack, no H2D and no SpMV-plan rebuild (C3: ~1 GB + 2.6 GB of layout)."""
+        H = self.H
+        if hasattr(H, "dims") and hasattr(H, "points"):  # _pool.StencilOperator: assembled on the device(s), never on the host
+            key = H.key()
+            if not (self.cache_matrix and key == self._matrix_key):
+                if self._multi():
+                    h.set_stencil(H)
+                else:
+                    h.build_stencil3d_block(H.dims, H.points, H.T_factor, H.weights4, 0, H.shape[0], (), potential=H.potential,
+                                            potential_params=H.potential_params, negate_T=H.negate_T)
+                self._matrix_key, self._matrix_key_alt = key, None
+            return
+        packed = _pack_matrix(H)
+        key = (packed[0], tuple(np.shape(H)), _fingerprint(*packed[1:])) if self.cache_matrix else None
+        if key is not None and key in (self._matrix_key, self._matrix_key_alt):
+            return
+        if packed[0] == "csr":
+            h.set_csr(self.M, 0, packed[1], packed[2], packed[3])
+        else:
+            h.set_dense(packed[1])
+        self._matrix_key, self._matrix_key_alt = key, None
+
     def _execute(self, n, seed, use_cuda, v0):
         if n > self.M:
             raise ValueError("n cannot be larger than M!")
         self._say("+++ Executing Lanczos algorithm")
         self.n = n
-        if not use_cuda:
-            raise NotImplementedError(_CPU_MSG)
+        _use_cuda_or_notice(self, use_cuda)
         M = self.M
 
         # start vector: the reference's CPU-branch stream (global legacy RNG), Lanczos.py:93-100
@@ -150,18 +250,12 @@ class LanczosBase:
             # the reference allocates beta = zeros(n-1) and writes beta[-1] at j = 0 (Lanczos.py:107,112)
             raise IndexError("index -1 is out of bounds for axis 0 with size 0")
 
-        packed = _pack_matrix(self.H)
-        if self._handle is None:
-            self._handle = _capi.Handle(self.device_id)
-        h = self._handle
         if self.reorth not in ("full", "partial"):
             raise ValueError("reorth must be 'full' or 'partial'")
+        h = self._get_handle()
         h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0)
                       | (_capi.FLAG_FUSED_NORM if self.fused_norm else 0))
-        if packed[0] == "csr":
-            h.set_csr(M, 0, packed[1], packed[2], packed[3])
-        else:
-            h.set_dense(packed[1])
+        self._upload_matrix(h)
         alpha, beta = h.run(n, v0)
         if h.breakdown:  # lz_run returned LZ_WARN_BREAKDOWN
             # The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov space gives inf/NaN there too.
@@ -181,8 +275,15 @@ class LanczosBase:
         self._alpha, self._beta = alpha, beta
         self._H_eff = H_eff
         self._V = None
-        # the reference's GPU branch leaves a SciPy CSR in self.H (Lanczos.py:137)
-        self.H = scipy.sparse.csr_matrix(self.H, dtype=np.float64)
+        self._H_eigvecs_host = None
+        # the reference's GPU branch leaves a SciPy CSR in self.H (Lanczos.py:137); a stencil descriptor stays what it is
+        # (materialising it is exactly what it exists to avoid)
+        if not (hasattr(self.H, "dims") and hasattr(self.H, "points")):
+            was_dense = not (scipy.sparse.issparse(self.H) or hasattr(self.H, "rowptr"))
+            self.H = scipy.sparse.csr_matrix(self.H.to_scipy() if hasattr(self.H, "to_scipy") else self.H, dtype=np.float64)
+            if was_dense and self.cache_matrix and self._matrix_key is not None and self._matrix_key_alt is None:
+                # the dense matrix stays resident (dense GEMV); the CSR copy now in self.H is the same operator
+                self._matrix_key_alt = ("csr", tuple(self.H.shape), _fingerprint(*_pack_matrix(self.H)[1:]))
         self.H_eigs_have_been_found = False
         self._say("+++ Lanczos executed successfully.")
         self.Lanczos_has_been_executed = True
@@ -193,8 +294,11 @@ class LanczosBase:
         self._say("+++ Converting eigenvectors from H_eff to H basis.")
         H_eff_eigvals, H_eff_eigvecs = np.linalg.eigh(self.H_eff)
         # Y = V S on the device (FP64 MFMA GEMM), Lanczos.py:153-156.  Y stays on the device; the two checks of
-        # Lanczos.py:157-158 only need its n x n Gram matrix, which the device forms too.
+        # Lanczos.py:157-158 only need its n x n Gram matrix, which the device forms too.  When a second M x n array does
+        # not fit beside the basis (BASELINE C4 on one GPU) the library keeps S and re-forms Y in row chunks for the Gram
+        # matrix and for every later fetch (lz_ritz_info): nothing here depends on free device memory.
         self._handle.ritz_vectors(H_eff_eigvecs, fetch=False)
+        self._H_eff_eigvecs = H_eff_eigvecs
         self._H_eigvecs_host = None
         if checks:
             G = self._handle.ritz_gram()
@@ -218,6 +322,19 @@ class LanczosBase:
             self._H_eigvecs_host = self._handle.ritz_fetch()
         return self._H_eigvecs_host
 
+    def V_rows(self, lo, hi):
+        """Rows ``[lo, hi)`` of ``V`` (an (hi - lo, n) block) without moving the whole basis off the device (extension)."""
+        if not self.Lanczos_has_been_executed:
+            raise ValueError(_NOT_EXECUTED)
+        return self._handle.get_basis_block(lo, hi).T
+
+    def H_eigvecs_rows(self, lo, hi):
+        """Rows ``[lo, hi)`` of ``H_eigvecs`` without materialising the whole (M, n) array on the host (extension: at
+        BASELINE C4 size ``H_eigvecs`` alone is 160 GB)."""
+        if not self.H_eigs_have_been_found:
+            self.get_H_eigs()
+        return self._handle.ritz_fetch_rows(lo, hi)
+
     def get_H_eigs(self):
         self._ritz(self._check_eigs)
 
@@ -229,8 +346,9 @@ class LanczosBase:
             self.get_H_eigs()
         try:
             return self._handle.ritz_quality()
-        except _capi.LanczosHipError:
-            pass
+        except _capi.LanczosHipError as e:
+            if e.status != -4:  # LZ_ERR_STATE: no device kernel for this matrix kind (dense, one rank) -> NumPy on the host copy
+                raise
         H, X = self.H, self.H_eigvecs
         HX = H @ X if scipy.sparse.issparse(H) else np.asarray(H) @ X
         HX = HX / np.linalg.norm(HX, axis=0)
@@ -277,8 +395,7 @@ class LanczosBase:
         """In-place single-pass Gram-Schmidt of row ``j`` of the (n, M) array ``V`` against
         all rows, with the reference's arithmetic ``V[j] = 2 V[j] - (V V[j])^T V``
         (Lanczos.py:247-249), executed by the HIP kernels."""
-        if not use_cuda:
-            raise NotImplementedError(_CPU_MSG)
+        _use_cuda_or_notice(LanczosBase, use_cuda)
         V = np.asarray(V)
         n, M = V.shape
         h = _capi.Handle(LanczosBase.device_id)

@@ -98,7 +98,7 @@ struct lz_context {
   std::string err;
   std::string name;
   int flags = 0;
-  int tune[16] = {0};  // A/B knobs, see lz_set_tuning
+  int tune[24] = {0};  // A/B knobs, see lz_set_tuning
 
   // partition
   int64_t Mg = 0, row0 = 0, rows = 0, ncols_ext = 0;
@@ -135,10 +135,18 @@ struct lz_context {
   double* d_gamma = nullptr;  // n + 1
   double* d_bi = nullptr;     // [0..3] raw sums S, [4..6] factors f
 
-  // Ritz vectors
+  // Ritz vectors: Y = V^T-layout x S.  Resident (d_Y holds all y_rows rows) when it fits beside the basis; otherwise
+  // CHUNKED: d_Y is a y_chunk-row buffer, the padded S stays on the device (d_S) and every consumer (Gram matrix, row
+  // fetch, quality sums) re-forms the rows it needs - a 16-row tile of Y depends only on the same 16 columns of V.
   double* d_Y = nullptr;
   int64_t y_rows = 0;
   int y_n = 0;
+  double* d_S = nullptr;
+  int s_npad = 0;
+  uint64_t* d_rclk = nullptr;  // in-kernel clock record of the last S-stationary back-transform (lz_ritz_info)
+  bool y_chunked = false;
+  int64_t y_chunk = 0;     // rows per chunk (multiple of 16)
+  int64_t y_cap = 0;       // doubles allocated behind d_Y
 
   // communication
   int world = 1, rank = 0;
@@ -578,7 +586,7 @@ int run_loop_onereduce(lz_handle h, int n) {
     LZ_TRY(comm_allreduce(h, h->d_c, onered_slot(m) + 1));  // THE collective of this iteration
     {
       Scope sc(h, LZ_K_FINAL, 0, 0);
-      launch_onereduce_prepare(h->d_c, m, ldp, h->d_alpha + urow, h->stream);  // j = 0: alpha[0] of the warm-up, rewritten below
+      launch_onereduce_prepare(h->d_c, m, ldp, h->d_alpha + urow, h->d_nrm2 + 1, h->stream);  // j = 0: alpha[0] of the warm-up, rewritten below
       LZ_TRY(check_launch(h, "onereduce_prepare"));
     }
     {
@@ -653,7 +661,6 @@ int run_loop_fused_small(lz_handle h, int n) {
   return LZ_OK;
 }
 
-constexpr int kSmallStepMaxN = 64;  // per-step kernels: every block redoes both passes over all n rows
 
 // The default loop of problems that are neither small nor huge (any number of ranks, fused-norm mode, full
 // re-orthogonalisation, at most kThreeTermFusedMaxRows rows per rank - measured: C2 (10^6 rows) +3.6 %, 6 400 .. 350 000 rows
@@ -698,6 +705,215 @@ int run_loop_three_term_fused(lz_handle h, int n) {
     }
     LZ_TRY(step_spmv(h, j));
   }
+  return LZ_OK;
+}
+
+}  // namespace
+extern "C" {
+static int basis_alloc(lz_handle h, int n, int zero_rows);
+}
+
+namespace {
+
+#ifdef LZ_KBENCH
+constexpr int kSmallStepMaxN = 64;  // per-step kernels: every block redoes both passes over all n rows
+// ---- kernel-bench build only: the retired small-problem engines (lz_small.hip) ------------------------------------------
+// The whole run as ONE cooperative kernel (tune[15] == 2; 3 = on a plain grid), or one launch per step (tune[15] == 5,
+// n <= 64).  Both are bit-identical to the multi-kernel path and both measured no faster than the three launches per step
+// that are the default for small problems (a device-coherent round trip costs ~2 us on MI355X, about
+// what a kernel boundary costs), so they left the product library in round 3; tests/test_gpu_small.py keeps their
+// bit-identity checks against liblanczos_kbench.so.
+bool small_args(lz_handle h, int n, SmallArgs& sa) {
+  memset(&sa, 0, sizeof sa);
+  sa.kind = h->kind;
+  if (h->kind == 2) {
+    sa.dense = h->d_dense;
+    sa.lda = h->dense_lda;
+    sa.nparts = (int)((h->rows + 3) / 4);
+  } else {
+    const CsrDev& A = h->csr;
+    const bool fixed = !(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7);
+    // (one lane walks one row in the engine: rows of more than 32 entries would turn into a chain of dependent loads)
+    if (A.pb || A.max_row_nnz > 32 || (fixed && A.fixed_rb != 512)) return false;
+    sa.rowptr = A.rowptr;
+    sa.colidx = A.colidx;
+    sa.vals = A.vals;
+    sa.rowblk = fixed ? nullptr : A.rowblk;
+    sa.nparts = fixed ? (int)((h->rows + 511) / 512) : A.n_rowblk;
+  }
+  if (sa.nparts > 1024 || h->part_cap < (size_t)(2048 + h->rows_pad)) return false;
+  sa.rows = (int)h->rows;
+  sa.rows_pad = (int)h->rows_pad;
+  sa.n = n;
+  sa.ldv = h->ldv;
+  sa.V = h->d_V;
+  sa.y = h->d_r;
+  sa.drow = h->d_part;
+  sa.x0 = h->d_part + 2048;  // d_part holds >= 4096 doubles; rows_pad <= 1280
+  sa.pc = h->d_c;
+  sa.alpha = h->d_alpha;
+  sa.beta = h->d_beta;
+  sa.bar = reinterpret_cast<unsigned*>(h->d_nrm2);  // 16 bytes, zeroed by basis_alloc
+  sa.xcc = reinterpret_cast<unsigned*>(h->d_part + 3400);
+  return true;
+}
+bool small_engine_applies(lz_handle h) {
+  SmallArgs sa;
+  return small_args(h, 2, sa);
+}
+
+int run_small_engine(lz_handle h, int n, const double* v0_local, bool steps, bool* ran) {
+  SmallArgs sa;
+  *ran = small_args(h, n, sa);
+  if (!*ran) return LZ_OK;
+  LZ_HIP(h, hipMemcpyAsync(h->d_part + 2048, h->d_V, (size_t)h->rows_pad * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (steps) {
+    // one launch per step: first SpMV, steps j = -1 .. n-2, the last alpha
+    const int nb = h->kind == 2 ? (int)std::min<int64_t>(256, (h->rows + 3) / 4) : (int)std::max<int64_t>(1, (h->rows + kTPB - 1) / kTPB);
+    const double Mr = (double)h->rows;
+    LZ_HIP(h, launch_small_step(sa, 0, -1, nb, h->stream));
+    for (int j = -1; j <= n - 2; ++j) {
+      const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+      h->prof_iter = ((j + 1) % pstride) == pstride / 2;
+      Scope sc(h, LZ_K_UPDATE, spmv_bytes(h) + 16.0 * (j + 2) * Mr + 40.0 * Mr, spmv_flops(h) + 4.0 * (j + 2) * Mr);
+      LZ_HIP(h, launch_small_step(sa, 1, j, nb, h->stream));
+    }
+    h->prof_iter = true;
+    LZ_HIP(h, launch_small_step(sa, 2, n - 1, 1, h->stream));
+    return check_launch(h, "small_step");
+  }
+  h->acc.launches[LZ_K_FINAL] += 1;
+  // tune[15] == 2: the participating blocks share one XCD (every eighth block of the grid); 3: plain grid over all XCDs
+  LZ_HIP(h, launch_small_run(sa, small_grid(sa.rows_pad), h->tune[15] == 2, h->stream));
+  LZ_TRY(check_launch(h, "small_run"));
+  unsigned status = 0;
+  LZ_HIP(h, hipMemcpyAsync(&status, sa.bar + 2, sizeof status, hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  if (status != 0) {
+    // the engine refused (its blocks were not dealt to one XCD) or a barrier timed out: the caller repeats the run
+    if (getenv("LZ_DEBUG_TIMING")) fprintf(stderr, "[lz_run] small-problem engine gave up (status %u): multi-kernel path\n", status);
+    *ran = false;
+    LZ_TRY(basis_alloc(h, n, 1));
+    LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+  }
+  return LZ_OK;
+}
+#endif  // LZ_KBENCH
+
+// ---- which loop structure runs the Krylov iteration --------------------------------------------------------------------
+// (the values are what lz_last_engine reports)
+enum Loop {
+  LOOP_SIX = 0,               // six launches per step; also the partial re-orthogonalisation mode and every A/B arm of a kernel
+  LOOP_SMALL_ENGINE = 1,      // kernel-bench build only: the whole run as one cooperative kernel (lz_small.hip)
+  LOOP_FUSED_SMALL = 2,       // <= 8 pass-1 slices, one rank: three launches per step (run_loop_fused_small)
+  LOOP_THREE_TERM_FUSED = 3,  // up to 4e6 rows per rank: five launches per step (run_loop_three_term_fused)
+  LOOP_SMALL_STEP = 4,        // kernel-bench build only: one launch per step
+  LOOP_ONE_REDUCE_REPEATED = 5,  // a one-reduce run whose cancellation guard fired: repeated on the default loop
+  LOOP_ONE_REDUCE = 6         // LZ_FLAG_ONE_REDUCE: one all-reduce per iteration
+};
+
+Loop choose_loop(lz_handle h, int n) {
+  const int f = h->flags;
+  const bool default_kernels = h->qplan.family == 2 && !(f & (LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->tune[1] == 0 && h->tune[8] == 0;
+  const bool full_fused = (f & LZ_FLAG_FUSED_NORM) && !(f & LZ_FLAG_REORTH_PARTIAL);
+  if ((f & LZ_FLAG_ONE_REDUCE) && !(f & LZ_FLAG_REORTH_PARTIAL) && h->qplan.family == 2) return LOOP_ONE_REDUCE;
+  const bool one_rank = h->world == 1 && h->comm_kind == 0;
+#ifdef LZ_KBENCH
+  const bool want_steps = h->tune[15] == 5 && n <= kSmallStepMaxN;
+  if ((h->tune[15] == 2 || h->tune[15] == 3 || want_steps) && one_rank && full_fused && default_kernels && !(f & LZ_FLAG_SPMV_SCALAR) &&
+      h->qplan.L == 512 && h->rows_pad <= kSmallMaxPadRows && n <= kSmallMaxPadRows && small_engine_applies(h))
+    return want_steps ? LOOP_SMALL_STEP : LOOP_SMALL_ENGINE;
+  const bool knob_auto = h->tune[15] == 0 || h->tune[15] == 5;
+#else
+  const bool knob_auto = h->tune[15] == 0;
+#endif
+  if (!knob_auto || !full_fused || !default_kernels) return LOOP_SIX;
+  if (one_rank && h->qplan.G <= 8 && n <= 4096 && h->part_cap >= fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G) return LOOP_FUSED_SMALL;
+  if (!(f & LZ_FLAG_OVERLAP_HALO) && h->rows_pad <= kThreeTermFusedMaxRows) return LOOP_THREE_TERM_FUSED;
+  return LOOP_SIX;
+}
+
+// ---- the plain loop: six launches per step (pass 1, second-stage sums, pass 2, SpMV, alpha sum, three-term), with the
+// opt-in partial re-orthogonalisation (Simon's omega-recurrence on the host) --------------------------------------------
+int run_loop_six(lz_handle h, int n, int* sweeps_out) {
+  // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
+  LZ_TRY(step_spmv(h, 0));
+  const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL);
+  LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
+  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+  const bool partial = (h->flags & LZ_FLAG_REORTH_PARTIAL) != 0;
+  // Partial re-orthogonalisation (opt-in): Simon's omega-recurrence on the host, fed with alpha_j and beta_{j+1}
+  // (two doubles copied back per step).  omega_{j,k} estimates v_j . v_k; a sweep is due when it exceeds sqrt(eps).
+  const double eps = 2.220446049250313e-16, thresh = 1.4901161193847656e-08;
+  std::vector<double> w_prev, w_cur, w_new, ha, hb;  // omega_{j-2,:}, omega_{j-1,:}, omega_{j,:}; alpha_k; beta_k (norm forming V[k])
+  if (partial) {
+    if (!h->h_pinned) LZ_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), 8 * sizeof(double), hipHostMallocDefault));
+    w_prev.assign((size_t)n + 1, 0.0);
+    w_cur.assign((size_t)n + 1, 0.0);
+    w_new.assign((size_t)n + 1, 0.0);
+    ha.assign((size_t)n + 1, 0.0);
+    hb.assign((size_t)n + 1, 0.0);
+    double nrm2 = 0.0;
+    LZ_HIP(h, hipMemcpyAsync(&nrm2, h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    hb[0] = std::sqrt(nrm2);
+  }
+  bool force_next = false;
+  double normA = 0.0;
+  int sweeps = 0;
+  for (int j = 0; j < n; ++j) {
+    h->prof_iter = (j % pstride) == pstride / 2;  // centred sample: same mean j as the full run
+    const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
+    bool sweep = true;
+    if (partial) {
+      bool due = false;
+      if (j >= 1) {
+        // beta_j omega_{j,k} = beta_{k+1} omega_{j-1,k+1} + (alpha_k - alpha_{j-1}) omega_{j-1,k} + beta_k omega_{j-1,k-1}
+        //                      - beta_{j-1} omega_{j-2,k}  (+ rounding of size eps ||A||),   k <= j-2
+        std::fill(w_new.begin(), w_new.end(), 0.0);
+        w_new[(size_t)j] = 1.0;
+        w_new[(size_t)j - 1] = eps;
+        double worst = 0.0;
+        for (int k = 0; k + 2 <= j; ++k) {
+          double t = hb[(size_t)k + 1] * w_cur[(size_t)k + 1] + (ha[(size_t)k] - ha[(size_t)j - 1]) * w_cur[(size_t)k] -
+                     hb[(size_t)j - 1] * w_prev[(size_t)k];
+          if (k > 0) t += hb[(size_t)k] * w_cur[(size_t)k - 1];
+          t += (t < 0 ? -1.0 : 1.0) * 2.0 * eps * normA;
+          w_new[(size_t)k] = t / hb[(size_t)j];
+          worst = std::max(worst, std::fabs(w_new[(size_t)k]));
+        }
+        due = worst > thresh;
+        std::swap(w_prev, w_cur);
+        std::swap(w_cur, w_new);
+      }
+      sweep = (j == 0) || due || force_next;  // a due sweep also covers the next vector (both feed the recurrence)
+      force_next = due;
+      if (sweep)
+        for (int k = 0; k < j; ++k) w_cur[(size_t)k] = eps;
+    }
+    if (sweep) {
+      ++sweeps;
+      LZ_TRY(step_reorth(h, j, j + 1, true, bidx, true));
+    } else {
+      Scope sc(h, LZ_K_QTW, 16.0 * (double)h->rows, (double)h->rows);
+      launch_scale_store(h->d_V + (int64_t)j * h->ldv, h->d_r, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream);
+      LZ_TRY(check_launch(h, "scale_store"));
+    }
+    LZ_TRY(step_spmv(h, j));
+    // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
+    LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, !fused || partial));
+    if (partial) {
+      double* two = h->h_pinned;
+      LZ_HIP(h, hipMemcpyAsync(&two[0], h->d_alpha + j, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      LZ_HIP(h, hipMemcpyAsync(&two[1], h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      LZ_HIP(h, hipStreamSynchronize(h->stream));
+      ha[(size_t)j] = two[0];
+      hb[(size_t)j + 1] = std::sqrt(two[1]);
+      normA = std::max(normA, std::fabs(two[0]) + hb[(size_t)j] + hb[(size_t)j + 1]);
+    }
+  }
+  *sweeps_out = sweeps;
   return LZ_OK;
 }
 
@@ -890,6 +1106,8 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_bi);
   hipFree(h->d_xtmp);
   hipFree(h->d_Y);
+  hipFree(h->d_S);
+  hipFree(h->d_rclk);
   hipFree(h->d_send_idx);
   hipFree(h->d_sendbuf);
   hipFree(h->d_xfull);
@@ -919,18 +1137,27 @@ const char* lz_last_error(lz_handle h) { return h ? h->err.c_str() : g_create_er
 
 int lz_set_options(lz_handle h, int flags) {
   if (!h) return LZ_ERR_ARG;
+#ifndef LZ_KBENCH
+  if (flags & LZ_FLAG_QTW_MFMA)
+    return fail(h, LZ_ERR_ARG, "lz_set_options: LZ_FLAG_QTW_MFMA (the 16x16x4 Q^T w arm, 20 % slower) was retired from the product library (build with KBENCH=1)");
+#endif
   h->flags = flags;
   return LZ_OK;
 }
 
 int lz_set_tuning(lz_handle h, int index, int value) {
   if (!h) return LZ_ERR_ARG;
-  if (index < 0 || index >= 16) return fail(h, LZ_ERR_ARG, "lz_set_tuning: knob index out of range");
+  if (index < 0 || index >= 24) return fail(h, LZ_ERR_ARG, "lz_set_tuning: knob index out of range");
 #ifndef LZ_KBENCH
   // Timing-only ablation arms (they compute wrong results on purpose) exist only in the kernel-bench build
   // (`make KBENCH=1` -> liblanczos_kbench.so, loaded by tools/kbench.py); the product library refuses them.
   if ((index == 1 && value >= 20) || (index == 3 && value != 0))
     return fail(h, LZ_ERR_ARG, "lz_set_tuning: ablation arms are not part of the product library (build with KBENCH=1)");
+  // Retired A/B arms (built, measured slower, kept bit-identity-tested in the kernel-bench build): the one-kernel /
+  // one-launch-per-step engines (15 = 2, 3, 5), the persistent and LDS-staged Ritz GEMMs (9 >= 2), the ticket / deferred-fold
+  // two-sided links (11 >= 2)
+  if ((index == 15 && value >= 2) || (index == 9 && value >= 2) || (index == 11 && value >= 2))
+    return fail(h, LZ_ERR_ARG, "lz_set_tuning: this A/B arm was retired from the product library (build with KBENCH=1)");
 #endif
   if (value < 0) return fail(h, LZ_ERR_ARG, "lz_set_tuning: negative value");
   h->tune[index] = value;
@@ -1446,196 +1673,50 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const double t2 = now();
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
-  const bool one_reduce = (h->flags & LZ_FLAG_ONE_REDUCE) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL) && h->qplan.family == 2;
-  // Small-problem engine (lz_small.hip): the whole run as one cooperative kernel, bit-identical to the multi-kernel path.
-  // Opt-in (tune[15] == 2, or 3 for the plain-grid arm): measured on MI355X it is NOT faster than the six launches per
-  // step it replaces (0.86-1.14x, profiles/r02/small_engine.json) - a device-coherent round trip costs ~2 us here, about
-  // what a kernel boundary costs, and a step needs a dozen of them.  Kept as a tested experiment, off by default.
-  // tune[15] == 5 and n <= 64: the same conditions select the PER-STEP kernels (k_small_step: one launch per step, every
-  // block redoes the vector work, no grid barrier).  Bit-identical too, and measured SLOWER than the three-launch path
-  // (C1 0.43 vs 0.37 ms, 1Dbox 1.26 vs 0.94 ms, a 32 x 32 Laplacian 1.12 vs 0.56 ms: the phases of a step are latency
-  // chains - rows written by the previous launch come from HBM or another XCD's L2 - and one block walks them all
-  // back to back instead of three grids each doing one): opt-in A/B arm.
-  const bool want_steps = h->tune[15] == 5 && n <= kSmallStepMaxN;
-  bool small = (h->tune[15] == 2 || h->tune[15] == 3 || want_steps) && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
-               !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_SPMV_SCALAR | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->qplan.family == 2 &&
-               h->qplan.L == 512 && h->rows_pad <= kSmallMaxPadRows && h->tune[1] == 0 && h->tune[8] == 0 && n <= 4096;
-  SmallArgs sa;
-  memset(&sa, 0, sizeof sa);
-  if (small) {
-    sa.kind = h->kind;
-    if (h->kind == 2) {
-      sa.dense = h->d_dense;
-      sa.lda = h->dense_lda;
-      sa.nparts = (int)((h->rows + 3) / 4);
-    } else {
-      const CsrDev& A = h->csr;
-      const bool fixed = !(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7);
-      // (one lane walks one row in the engine: rows of more than 32 entries would turn into a chain of dependent loads)
-      small = !A.pb && A.max_row_nnz <= 32 && (!fixed || A.fixed_rb == 512);
-      sa.rowptr = A.rowptr;
-      sa.colidx = A.colidx;
-      sa.vals = A.vals;
-      sa.rowblk = fixed ? nullptr : A.rowblk;
-      sa.nparts = fixed ? (int)((h->rows + 511) / 512) : A.n_rowblk;
-    }
-    small = small && sa.nparts <= 1024 && h->part_cap >= (size_t)(2048 + h->rows_pad) && n <= kSmallMaxPadRows;
-  }
-  if (small) {
-    sa.rows = (int)h->rows;
-    sa.rows_pad = (int)h->rows_pad;
-    sa.n = n;
-    sa.ldv = h->ldv;
-    sa.V = h->d_V;
-    sa.y = h->d_r;
-    sa.drow = h->d_part;
-    sa.x0 = h->d_part + 2048;  // d_part holds >= 4096 doubles; rows_pad <= 1280
-    LZ_HIP(h, hipMemcpyAsync(h->d_part + 2048, h->d_V, (size_t)h->rows_pad * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    sa.pc = h->d_c;
-    sa.alpha = h->d_alpha;
-    sa.beta = h->d_beta;
-    sa.bar = reinterpret_cast<unsigned*>(h->d_nrm2);  // 16 bytes, zeroed by basis_alloc
-    sa.xcc = reinterpret_cast<unsigned*>(h->d_part + 3400);
-    if (want_steps) {
-      // one launch per step: first SpMV, steps j = -1 .. n-2, the last alpha
-      const int nb = h->kind == 2 ? (int)std::min<int64_t>(256, (h->rows + 3) / 4) : (int)std::max<int64_t>(1, (h->rows + kTPB - 1) / kTPB);
-      const double Mr = (double)h->rows;
-      LZ_HIP(h, launch_small_step(sa, 0, -1, nb, h->stream));
-      for (int j = -1; j <= n - 2; ++j) {
-        const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-        h->prof_iter = ((j + 1) % pstride) == pstride / 2;
-        Scope sc(h, LZ_K_UPDATE, spmv_bytes(h) + 16.0 * (j + 2) * Mr + 40.0 * Mr, spmv_flops(h) + 4.0 * (j + 2) * Mr);
-        LZ_HIP(h, launch_small_step(sa, 1, j, nb, h->stream));
+  const Loop loop = choose_loop(h, n);
+  const bool one_reduce = loop == LOOP_ONE_REDUCE;
+  int sweeps = n;
+  h->last_engine = (int)loop;
+  switch (loop) {
+#ifdef LZ_KBENCH
+    case LOOP_SMALL_ENGINE:
+    case LOOP_SMALL_STEP: {
+      bool ran = false;
+      LZ_TRY(run_small_engine(h, n, v0_local, loop == LOOP_SMALL_STEP, &ran));
+      if (!ran) {  // the engine refused (placement / barrier timeout): nothing is lost, the plain loop repeats the run
+        h->last_engine = LOOP_SIX;
+        LZ_TRY(run_loop_six(h, n, &sweeps));
       }
-      h->prof_iter = true;
-      LZ_HIP(h, launch_small_step(sa, 2, n - 1, 1, h->stream));
-      LZ_TRY(check_launch(h, "small_step"));
-      h->last_engine = 4;
-    } else {
-    h->acc.launches[LZ_K_FINAL] += 1;
-    // tune[15] == 2: the participating blocks share one XCD (every eighth block of the grid); 3: plain grid over all XCDs
-    LZ_HIP(h, launch_small_run(sa, small_grid(sa.rows_pad), h->tune[15] == 2, h->stream));
-    LZ_TRY(check_launch(h, "small_run"));
-    unsigned status = 0;
-    LZ_HIP(h, hipMemcpyAsync(&status, sa.bar + 2, sizeof status, hipMemcpyDeviceToHost, h->stream));
-    LZ_HIP(h, hipStreamSynchronize(h->stream));
-    if (status != 0) {
-      // the engine refused (its blocks were not dealt to one XCD) or a barrier timed out: nothing is lost, the run is
-      // repeated on the multi-kernel path
-      if (getenv("LZ_DEBUG_TIMING")) fprintf(stderr, "[lz_run] small-problem engine gave up (status %u): multi-kernel path\n", status);
-      small = false;
-      LZ_TRY(basis_alloc(h, n, 1));
-      LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
-      LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+      break;
     }
-    h->last_engine = small ? 1 : 0;
-    }
-  } else {
-    h->last_engine = 0;
+#endif
+    case LOOP_FUSED_SMALL: LZ_TRY(run_loop_fused_small(h, n)); break;
+    case LOOP_THREE_TERM_FUSED: LZ_TRY(run_loop_three_term_fused(h, n)); break;
+    case LOOP_ONE_REDUCE: LZ_TRY(run_loop_onereduce(h, n)); break;
+    default: LZ_TRY(run_loop_six(h, n, &sweeps)); break;
   }
-  // fused-launch path for small problems (tune[15] == 1 switches it off): see run_loop_fused_small
-  const bool fsmall = !small && (h->tune[15] == 0 || h->tune[15] == 5) && h->world == 1 && h->comm_kind == 0 && (h->flags & LZ_FLAG_FUSED_NORM) && !one_reduce &&
-                      !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->qplan.family == 2 && h->qplan.G <= 8 &&
-                      h->tune[1] == 0 && h->tune[8] == 0 && n <= 4096 && h->part_cap >= fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G;
-  if (fsmall) {
-    LZ_TRY(run_loop_fused_small(h, n));
-    h->last_engine = 2;
-    small = true;  // (skips the six-launch loop below)
-  }
-  // everything else in fused-norm mode with the full sweep: the loop with the three-term recurrence folded into pass 1
-  const bool f3 = !small && !one_reduce && (h->tune[15] == 0 || h->tune[15] == 5) && (h->flags & LZ_FLAG_FUSED_NORM) &&
-                  !(h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU | LZ_FLAG_OVERLAP_HALO)) && h->qplan.family == 2 &&
-                  h->tune[1] == 0 && h->tune[8] == 0 && h->rows_pad <= kThreeTermFusedMaxRows;
-  if (f3) {
-    LZ_TRY(run_loop_three_term_fused(h, n));
-    h->last_engine = 3;
-    small = true;  // (skips the six-launch loop below)
-  }
-  if (one_reduce) LZ_TRY(run_loop_onereduce(h, n));
-  // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
-  if (!one_reduce && !small) LZ_TRY(step_spmv(h, 0));
-  const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL);
-  if (!one_reduce && !small) LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
-  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-  const bool partial = (h->flags & LZ_FLAG_REORTH_PARTIAL) != 0;
-  // Partial re-orthogonalisation (opt-in): Simon's omega-recurrence on the host, fed with alpha_j and beta_{j+1}
-  // (two doubles copied back per step).  omega_{j,k} estimates v_j . v_k; a sweep is due when it exceeds sqrt(eps).
-  const double eps = 2.220446049250313e-16, thresh = 1.4901161193847656e-08;
-  std::vector<double> w_prev, w_cur, w_new, ha, hb;  // omega_{j-2,:}, omega_{j-1,:}, omega_{j,:}; alpha_k; beta_k (norm forming V[k])
-  if (partial) {
-    if (!h->h_pinned) LZ_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), 8 * sizeof(double), hipHostMallocDefault));
-    w_prev.assign((size_t)n + 1, 0.0);
-    w_cur.assign((size_t)n + 1, 0.0);
-    w_new.assign((size_t)n + 1, 0.0);
-    ha.assign((size_t)n + 1, 0.0);
-    hb.assign((size_t)n + 1, 0.0);
-    double nrm2 = 0.0;
-    LZ_HIP(h, hipMemcpyAsync(&nrm2, h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    LZ_HIP(h, hipStreamSynchronize(h->stream));
-    hb[0] = std::sqrt(nrm2);
-  }
-  bool force_next = false;
-  double normA = 0.0;
-  int sweeps = 0;
-  for (int j = 0; j < n && !one_reduce && !small; ++j) {
-    h->prof_iter = (j % pstride) == pstride / 2;  // centred sample: same mean j as the full run
-    const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
-    bool sweep = true;
-    if (partial) {
-      bool due = false;
-      if (j >= 1) {
-        // beta_j omega_{j,k} = beta_{k+1} omega_{j-1,k+1} + (alpha_k - alpha_{j-1}) omega_{j-1,k} + beta_k omega_{j-1,k-1}
-        //                      - beta_{j-1} omega_{j-2,k}  (+ rounding of size eps ||A||),   k <= j-2
-        std::fill(w_new.begin(), w_new.end(), 0.0);
-        w_new[(size_t)j] = 1.0;
-        w_new[(size_t)j - 1] = eps;
-        double worst = 0.0;
-        for (int k = 0; k + 2 <= j; ++k) {
-          double t = hb[(size_t)k + 1] * w_cur[(size_t)k + 1] + (ha[(size_t)k] - ha[(size_t)j - 1]) * w_cur[(size_t)k] -
-                     hb[(size_t)j - 1] * w_prev[(size_t)k];
-          if (k > 0) t += hb[(size_t)k] * w_cur[(size_t)k - 1];
-          t += (t < 0 ? -1.0 : 1.0) * 2.0 * eps * normA;
-          w_new[(size_t)k] = t / hb[(size_t)j];
-          worst = std::max(worst, std::fabs(w_new[(size_t)k]));
-        }
-        due = worst > thresh;
-        std::swap(w_prev, w_cur);
-        std::swap(w_cur, w_new);
-      }
-      sweep = (j == 0) || due || force_next;  // a due sweep also covers the next vector (both feed the recurrence)
-      force_next = due;
-      if (sweep)
-        for (int k = 0; k < j; ++k) w_cur[(size_t)k] = eps;
-    }
-    if (sweep) {
-      ++sweeps;
-      LZ_TRY(step_reorth(h, j, j + 1, true, bidx, true));
-    } else {
-      Scope sc(h, LZ_K_QTW, 16.0 * (double)h->rows, (double)h->rows);
-      launch_scale_store(h->d_V + (int64_t)j * h->ldv, h->d_r, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream);
-      LZ_TRY(check_launch(h, "scale_store"));
-    }
-    LZ_TRY(step_spmv(h, j));
-    // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
-    LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, !fused || partial));
-    if (partial) {
-      double* two = h->h_pinned;
-      LZ_HIP(h, hipMemcpyAsync(&two[0], h->d_alpha + j, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      LZ_HIP(h, hipMemcpyAsync(&two[1], h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      LZ_HIP(h, hipStreamSynchronize(h->stream));
-      ha[(size_t)j] = two[0];
-      hb[(size_t)j + 1] = std::sqrt(two[1]);
-      normA = std::max(normA, std::fabs(two[0]) + hb[(size_t)j] + hb[(size_t)j + 1]);
-    }
-  }
-  h->last_sweeps = (one_reduce || small) ? n : sweeps;
+  h->last_sweeps = sweeps;
   h->prof_iter = true;
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
   const double t3 = now();
   h->run_timed = true;
   LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  double onered_bad = 0.0;
+  if (one_reduce) LZ_HIP(h, hipMemcpyAsync(&onered_bad, h->d_nrm2 + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
+  if (one_reduce && onered_bad != 0.0) {
+    // cancellation guard of the one-reduce loop (k_onereduce_prepare): |r|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u lost too
+    // many digits at some step (|alpha| >> beta).  Every rank sees the same reduced sums, so every rank takes this branch:
+    // the solve is repeated on the default loop (two all-reduces per iteration), whose coefficients hold the bar.
+    h->run_timed = false;
+    const int keep = h->flags;
+    h->flags &= ~LZ_FLAG_ONE_REDUCE;
+    const int rc = lz_run(h, n, v0_local, alpha_out, beta_out);
+    h->flags = keep;
+    h->last_engine = LOOP_ONE_REDUCE_REPEATED;
+    return rc;
+  }
   if (dbg)
     fprintf(stderr, "[lz_run] alloc+memset %.3f ms, v0 upload %.3f ms, enqueue loop %.3f ms, drain+D2H %.3f ms\n", t1 - t0, t2 - t1,
             t3 - t2, now() - t3);
@@ -1687,7 +1768,13 @@ double* bi_row(lz_handle h, int which, int j) { return bi_base(h, which) + (int6
 // release has to write back the L2 lines the kernel just dirtied, which costs far more than the launch it saves - 157
 // vs 41 ms at M = 2.6e5, 250 vs 98 ms at M = 1e6, 178 vs 75 ms at M = 1e7, a tie at M = 9e4.  Default: two launches.  (A third arm, the fold deferred into the
 // consumer's prologue, tune[11] == 3, is no faster either: see bi_reorth.)
+#ifdef LZ_KBENCH
 unsigned* bi_ticket(lz_handle h) { return h->tune[11] == 2 ? reinterpret_cast<unsigned*>(h->d_bi + 7) : nullptr; }
+bool bi_defer(lz_handle h) { return h->tune[11] == 3; }
+#else  // both arms are retired from the product library (lz_set_tuning refuses knob 11 >= 2)
+unsigned* bi_ticket(lz_handle) { return nullptr; }
+bool bi_defer(lz_handle) { return false; }
+#endif
 
 int bi_alloc(lz_handle h, int n, int zero_rows) {
   if (h->kind != 1) return fail(h, LZ_ERR_STATE, "two-sided Lanczos needs a CSR matrix (lz_set_csr)");
@@ -1727,7 +1814,7 @@ int bi_reorth(lz_handle h, int jj, bool from_rs) {
   // k_bi_final's order: one launch per link instead of two, same bits.  Measured (tests/test_gpu_two_sided.py, device
   // time): 0.81-0.92x - a dependent launch costs ~4 us here and the emulated fold (16 shuffle trees per block) as much,
   // so the separate fold kernel stays the default.
-  const bool defer = h->tune[11] == 3 && !tk;
+  const bool defer = bi_defer(h) && !tk;
   double* pbuf[2] = {h->d_part, h->d_part + bi_partials_needed()};
   int cur = 0;  // buffer the next link writes its partials to
   const double* pend = nullptr;  // where the previous link's deferred partials are
@@ -1906,6 +1993,47 @@ int lz_get_basis(lz_handle h, double* V_out, int64_t ld) {
   return LZ_OK;
 }
 
+int lz_get_basis_block(lz_handle h, int64_t row0, int64_t nrows, double* V_out, int64_t ld) {
+  if (!h || !V_out) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, 0));
+  if (row0 < 0 || nrows < 1 || row0 + nrows > h->rows || ld < nrows) return fail(h, LZ_ERR_ARG, "lz_get_basis_block: bad row range or ld < nrows");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpy2DAsync(V_out, (size_t)ld * sizeof(double), h->d_V + row0, (size_t)h->ldv * sizeof(double),
+                             (size_t)nrows * sizeof(double), (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// ---- Ritz back-transform: resident or chunked -----------------------------------------------------------------------
+// rows [r0, r0 + nr) of Y = V^T-layout x S into `dst` (row-major, leading dimension n).  r0 is a multiple of 16 (the
+// S-stationary kernel moves whole 16-row tiles of V with 16-byte LDS-DMA pieces); dst needs round_up(nr, 16) + 16 rows.
+int ritz_rows_into(lz_handle h, int64_t r0, int64_t nr, double* dst) {
+  const int n = h->y_n;
+  Scope sc(h, LZ_K_RITZ, 16.0 * n * (double)nr + 8.0 * n * n, 2.0 * (double)nr * n * n);
+  LZ_HIP(h, launch_ritz_gemm(h->d_V + r0, h->ldv, nr, n, h->d_S, h->s_npad, dst, n, h->stream, h->tune[9],
+                             reinterpret_cast<unsigned long long*>(h->d_rclk)));
+  return check_launch(h, "ritz_gemm");
+}
+
+// columns [c0, c0 + nc) of Y for ALL rows into `dst` (rows x ldy): the chunked mode's way to hand whole Ritz vectors to
+// the quality sums (A y_i needs every row of y_i) without ever holding all n of them
+int ritz_cols_into(lz_handle h, int c0, int nc, double* dst, int64_t ldy) {
+  const int n = h->y_n;
+  Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)h->y_rows + 8.0 * nc * (double)h->y_rows, 2.0 * (double)h->y_rows * n * nc);
+  launch_ritz_gemm_cols(h->d_V, h->ldv, h->y_rows, n, h->d_S + c0, h->s_npad, nc, dst, ldy, h->stream);
+  return check_launch(h, "ritz_gemm(columns)");
+}
+
+size_t y_doubles(int64_t rows, int n) { return (size_t)(round_up(rows, 16) + 16) * (size_t)n + 64; }
+
+}  // namespace
+
+extern "C" {
+
 int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
   if (!h || !S) return LZ_ERR_ARG;
   LZ_TRY(require_basis(h, 0));
@@ -1914,37 +2042,108 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
   const int npad = (int)round_up(n, 16);
   std::vector<double> Sp((size_t)npad * npad, 0.0);
   for (int k = 0; k < n; ++k) memcpy(&Sp[(size_t)k * npad], S + (size_t)k * n, (size_t)n * sizeof(double));
-  double* dS = nullptr;
-  LZ_TRY(dev_alloc(h, dS, Sp.size()));
-  hipError_t e = hipMemcpyAsync(dS, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess && (!h->d_Y || h->y_rows != h->rows || h->y_n != n)) {
-    int rc = dev_alloc(h, h->d_Y, (size_t)(round_up(h->rows, 16) + 16) * n + 64);  // + slack: the S-stationary GEMM stores whole 16-row tiles (and 16 scratch rows), the Gram kernel reads 16-wide column tiles
-    if (rc != LZ_OK) {
-      hipFree(dS);
-      return rc;
+  if (!h->d_S || h->s_npad != npad) {
+    LZ_TRY(dev_alloc(h, h->d_S, Sp.size() + 64));
+    h->s_npad = npad;
+  }
+  if (!h->d_rclk) LZ_TRY(dev_alloc(h, h->d_rclk, 8));
+  LZ_HIP(h, hipMemsetAsync(h->d_rclk, 0, 8 * sizeof(uint64_t), h->stream));
+  LZ_HIP(h, hipMemcpyAsync(h->d_S, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));  // Sp is a local
+  // Resident when all of Y fits beside the basis (with 1 GiB to spare for the Gram partials and the runtime), else chunked.
+  // tune[16] > 0 forces the chunked mode with that many rows per chunk (tests).
+  const size_t full = y_doubles(h->rows, n);
+  bool chunked = h->tune[16] > 0;
+  size_t free_b = 0, total_b = 0;
+  if (!chunked && !(h->d_Y && !h->y_chunked && h->y_cap >= (int64_t)full)) {
+    LZ_TRY(dev_free(h, h->d_Y));
+    h->y_cap = 0;
+    LZ_HIP(h, hipMemGetInfo(&free_b, &total_b));
+    chunked = full * sizeof(double) + ((size_t)1 << 30) > free_b;
+  }
+  h->y_rows = h->rows;
+  h->y_n = n;
+  if (!chunked) {
+    if (!h->d_Y || h->y_cap < (int64_t)full) {
+      LZ_TRY(dev_alloc(h, h->d_Y, full));
+      h->y_cap = (int64_t)full;
     }
-    h->y_rows = h->rows;
-    h->y_n = n;
+    h->y_chunked = false;
+    h->y_chunk = h->rows;
+    LZ_TRY(ritz_rows_into(h, 0, h->rows, h->d_Y));
+    if (Y_out) LZ_HIP(h, hipMemcpyAsync(Y_out, h->d_Y, (size_t)h->rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    return LZ_OK;
   }
-  if (e == hipSuccess) {
-    Scope sc(h, LZ_K_RITZ, 16.0 * n * (double)h->rows + 8.0 * n * n, 2.0 * (double)h->rows * n * n);
-    launch_ritz_gemm(h->d_V, h->ldv, h->rows, n, dS, npad, h->d_Y, n, h->stream, h->tune[9]);
-    e = hipGetLastError();
+  // chunked: a bounded buffer (at most 4 GiB, at most a quarter of what is free), whole 16-row tiles
+  int64_t chunk = h->tune[16] > 0 ? h->tune[16] : 0;
+  if (chunk == 0) {
+    LZ_TRY(dev_free(h, h->d_Y));
+    h->y_cap = 0;
+    LZ_HIP(h, hipMemGetInfo(&free_b, &total_b));
+    const size_t budget = std::min<size_t>((size_t)4 << 30, free_b / 4);
+    chunk = (int64_t)(budget / ((size_t)n * sizeof(double)));
+    if (chunk < 4096) return fail(h, LZ_ERR_NOMEM, "lz_ritz_vectors: no device memory left for even a 4096-row chunk of Ritz vectors");
   }
-  if (e == hipSuccess && Y_out)
-    e = hipMemcpyAsync(Y_out, h->d_Y, (size_t)h->rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  hipFree(dS);
-  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_vectors: ") + hipGetErrorString(e));
+  chunk = std::min<int64_t>(round_up(chunk, 16), round_up(h->rows, 16));
+  const size_t need = y_doubles(chunk, n);
+  if (!h->d_Y || h->y_cap < (int64_t)need) {
+    LZ_TRY(dev_alloc(h, h->d_Y, need));
+    h->y_cap = (int64_t)need;
+  }
+  h->y_chunked = true;
+  h->y_chunk = chunk;
+  if (Y_out) return lz_get_ritz_rows(h, 0, h->rows, Y_out);
+  return LZ_OK;
+}
+
+int lz_get_ritz_rows(lz_handle h, int64_t row0, int64_t nrows, double* Y_out) {
+  if (!h || !Y_out) return LZ_ERR_ARG;
+  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_get_ritz_rows: call lz_ritz_vectors first");
+  if (row0 < 0 || nrows < 0 || row0 + nrows > h->y_rows) return fail(h, LZ_ERR_ARG, "lz_get_ritz_rows: row range outside [0, rows_local)");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  const int n = h->y_n;
+  if (!h->y_chunked) {
+    if (nrows > 0)
+      LZ_HIP(h, hipMemcpyAsync(Y_out, h->d_Y + (size_t)row0 * n, (size_t)nrows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    return LZ_OK;
+  }
+  if (!h->d_V || h->n != n || h->rows != h->y_rows) return fail(h, LZ_ERR_STATE, "lz_get_ritz_rows: the basis of the run is gone");
+  for (int64_t r = row0 & ~(int64_t)15; r < row0 + nrows; r += h->y_chunk) {
+    const int64_t nr = std::min<int64_t>(h->y_chunk, h->y_rows - r);
+    LZ_TRY(ritz_rows_into(h, r, nr, h->d_Y));
+    const int64_t a = std::max(r, row0), b = std::min(r + nr, row0 + nrows);
+    LZ_HIP(h, hipMemcpyAsync(Y_out + (size_t)(a - row0) * n, h->d_Y + (size_t)(a - r) * n, (size_t)(b - a) * n * sizeof(double),
+                             hipMemcpyDeviceToHost, h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));
+  }
   return LZ_OK;
 }
 
 int lz_get_ritz_vectors(lz_handle h, double* Y_out) {
   if (!h || !Y_out) return LZ_ERR_ARG;
   if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_get_ritz_vectors: call lz_ritz_vectors first");
+  return lz_get_ritz_rows(h, 0, h->y_rows, Y_out);
+}
+
+int lz_ritz_info(lz_handle h, int64_t* chunk_rows, double* clock4) {
+  if (!h) return LZ_ERR_ARG;
+  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_ritz_info: call lz_ritz_vectors first");
   LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipMemcpyAsync(Y_out, h->d_Y, (size_t)h->y_rows * h->y_n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  if (chunk_rows) *chunk_rows = h->y_chunked ? h->y_chunk : 0;
+  if (clock4) {
+    uint64_t c[8] = {0};
+    if (h->d_rclk) {
+      LZ_HIP(h, hipMemcpyAsync(c, h->d_rclk, sizeof c, hipMemcpyDeviceToHost, h->stream));
+      LZ_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    // [0] shader cycles, [1] ticks of the constant 100 MHz counter, [2] 16-row tiles, [3] MFMAs per tile and SIMD (x 64 = issue floor)
+    clock4[0] = c[1] ? 100.0 * (double)c[0] / (double)c[1] : 0.0;  // shader clock in MHz while the kernel ran
+    clock4[1] = c[2] ? (double)c[0] / (double)c[2] : 0.0;          // shader cycles per 16-row tile
+    clock4[2] = (double)c[3] / 4.0 * 64.0;                         // MFMA issue floor per tile: (MFMAs per tile / 4 SIMDs) x 64 cycles; c[3] holds 4x the per-SIMD count
+    clock4[3] = (double)c[2];
+  }
   return LZ_OK;
 }
 
@@ -1954,15 +2153,25 @@ int lz_ritz_gram(lz_handle h, double* gram_out) {
   LZ_HIP(h, hipSetDevice(h->dev));
   const int n = h->y_n;
   const int nz_max = 512;
+  const int64_t nchunks = h->y_chunked ? (h->y_rows + h->y_chunk - 1) / h->y_chunk : 1;
+  if (h->y_chunked && (!h->d_V || h->n != n || h->rows != h->y_rows)) return fail(h, LZ_ERR_STATE, "lz_ritz_gram: the basis of the run is gone");
   double* part = nullptr;
-  LZ_TRY(dev_alloc(h, part, (size_t)(nz_max + 1) * n * n));
-  double* dG = part + (size_t)nz_max * n * n;
+  LZ_TRY(dev_alloc(h, part, (size_t)(nz_max + nchunks + 1) * n * n));
+  double* cpart = part + (size_t)nz_max * n * n;  // one n x n slice per chunk, added in chunk order at the end
+  double* dG = cpart + (size_t)nchunks * n * n;
   int rc = LZ_OK;
-  {
-    Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)h->y_rows, 2.0 * (double)h->y_rows * n * n);
-    const int nz = launch_gram(h->d_Y, n, h->y_rows, n, part, nz_max, h->stream);
-    launch_sum_slices(part, nz, (int64_t)n * n, dG, h->stream);
+  for (int64_t q = 0; q < nchunks && rc == LZ_OK; ++q) {
+    const int64_t r = q * h->y_chunk, nr = std::min<int64_t>(h->y_chunk, h->y_rows - r);
+    if (h->y_chunked) rc = ritz_rows_into(h, r, nr, h->d_Y);
+    if (rc != LZ_OK) break;
+    Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)nr, 2.0 * (double)nr * n * n);
+    const int nz = launch_gram(h->d_Y, n, nr, n, part, nz_max, h->stream);
+    launch_sum_slices(part, nz, (int64_t)n * n, cpart + (size_t)q * n * n, h->stream);
     rc = check_launch(h, "gram");
+  }
+  if (rc == LZ_OK) {
+    launch_sum_slices(cpart, (int)nchunks, (int64_t)n * n, dG, h->stream);
+    rc = check_launch(h, "gram(sum)");
   }
   if (rc == LZ_OK) rc = comm_allreduce(h, dG, (int64_t)n * n);
   hipError_t e = hipSuccess;
@@ -1980,31 +2189,67 @@ int lz_ritz_quality(lz_handle h, double* out) {
   if (h->kind != 1 && !(h->world > 1 || h->tune[6])) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: CSR matrices only");
   LZ_HIP(h, hipSetDevice(h->dev));
   const int n = h->y_n;
+  // Chunked mode: whole Ritz vectors are formed a batch of columns at a time (Yb = V^T-layout x S[:, c0:c0+nb], all rows)
+  // and handed to the same kernels with ldy = nb.
+  double* Yb = nullptr;
+  int nb = n;
+  int64_t ldy = n;
+  if (h->y_chunked) {
+    if (!h->d_V || h->n != n || h->rows != h->y_rows) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: the basis of the run is gone");
+    size_t free_b = 0, total_b = 0;
+    LZ_HIP(h, hipMemGetInfo(&free_b, &total_b));
+    const size_t per_col = (size_t)(round_up(h->y_rows, 16) + 16) * sizeof(double);
+    int64_t fit = (int64_t)((free_b > ((size_t)1 << 30) ? free_b - ((size_t)1 << 30) : 0) / 2 / per_col);
+    if (h->tune[16] > 0) fit = 16;  // test knob: the smallest batch
+    nb = (int)std::min<int64_t>(round_up(n, 16), fit / 16 * 16);
+    if (nb < 16) return fail(h, LZ_ERR_NOMEM, "lz_ritz_quality: no device memory left for a 16-column batch of Ritz vectors");
+    ldy = nb;
+    LZ_TRY(dev_alloc(h, Yb, (size_t)(round_up(h->y_rows, 16) + 16) * nb + 64));
+  }
+  std::vector<double> sums(2 * (size_t)n);
+  int rc = LZ_OK;
+  hipError_t e = hipSuccess;
   if (h->world > 1 || h->tune[6]) {
     // Row-block partition: z = A y_i needs the neighbours' entries of y_i, so every Ritz vector takes the path a Lanczos
     // vector takes - copied into basis row 0 (saved and restored), exchanged (halo or all-gather), multiplied by the
     // SpMV kernel, whose epilogue already delivers y_i . z; ||z||^2 from the three-term kernel with zero coefficients.
     // One all-reduce of the 2 n sums at the end.
-    if (!h->d_V || h->n < 1 || h->y_rows != h->rows) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: the basis of the run is gone");
-    if ((size_t)2 * n > (size_t)2 * qtw_ldp(h->n + 2) + 8) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: coefficient buffer too small");
-    double* v0 = h->d_V;
-    LZ_HIP(h, hipMemcpyAsync(h->d_r2, v0, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    LZ_HIP(h, hipMemsetAsync(h->d_nrm2, 0, 2 * sizeof(double), h->stream));
-    h->halo_inflight_j = -1;
-    int rc = LZ_OK;
-    for (int i = 0; i < n && rc == LZ_OK; ++i) {
-      launch_extract_column(h->d_Y, n, i, h->rows, h->rows_pad, v0, h->stream);
-      rc = step_spmv(h, 0, h->d_c + i, false);
-      if (rc != LZ_OK) break;
-      const int np = launch_three_term(h->d_r, v0, nullptr, h->d_nrm2, h->d_nrm2, h->rows_pad, h->d_part, h->stream);
-      launch_final_sum(h->d_part, np, h->d_c + n + i, h->stream);
-      rc = check_launch(h, "ritz_quality(row-block)");
+    if (!h->d_V || h->n < 1 || h->y_rows != h->rows) rc = fail(h, LZ_ERR_STATE, "lz_ritz_quality: the basis of the run is gone");
+    if (rc == LZ_OK && (size_t)2 * n > (size_t)2 * qtw_ldp(h->n + 2) + 8) rc = fail(h, LZ_ERR_STATE, "lz_ritz_quality: coefficient buffer too small");
+    if (rc != LZ_OK) {
+      hipFree(Yb);
+      return rc;
     }
-    hipError_t e = hipMemcpyAsync(v0, h->d_r2, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream);  // basis row 0 back
+    double* v0 = h->d_V;
+    double* save = nullptr;  // basis row 0 is borrowed; in chunked mode the batches are formed from the INTACT basis first
+    e = hipMemcpyAsync(h->d_r2, v0, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+    (void)save;
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_nrm2, 0, 2 * sizeof(double), h->stream);
+    h->halo_inflight_j = -1;
+    for (int c0 = 0; c0 < n && rc == LZ_OK && e == hipSuccess; c0 += nb) {
+      const int nc = std::min(nb, n - c0);
+      const double* Ysrc = h->d_Y;
+      if (h->y_chunked) {
+        e = hipMemcpyAsync(v0, h->d_r2, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream);  // the batch GEMM reads basis row 0
+        if (e != hipSuccess) break;
+        rc = ritz_cols_into(h, c0, nc, Yb, ldy);
+        Ysrc = Yb;
+      }
+      for (int i = 0; i < nc && rc == LZ_OK; ++i) {
+        launch_extract_column(Ysrc, ldy, h->y_chunked ? i : c0 + i, h->rows, h->rows_pad, v0, h->stream);
+        rc = step_spmv(h, 0, h->d_c + c0 + i, false);
+        if (rc != LZ_OK) break;
+        const int np = launch_three_term(h->d_r, v0, nullptr, h->d_nrm2, h->d_nrm2, h->rows_pad, h->d_part, h->stream);
+        launch_final_sum(h->d_part, np, h->d_c + n + c0 + i, h->stream);
+        rc = check_launch(h, "ritz_quality(row-block)");
+      }
+    }
+    hipError_t e2 = hipMemcpyAsync(v0, h->d_r2, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream);  // basis row 0 back
+    if (e == hipSuccess) e = e2;
     if (rc == LZ_OK) rc = comm_allreduce(h, h->d_c, 2 * n);
-    std::vector<double> sums(2 * (size_t)n);
     if (rc == LZ_OK && e == hipSuccess) e = hipMemcpyAsync(sums.data(), h->d_c, sums.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(Yb);
     if (rc != LZ_OK) return rc;
     if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
     for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];
@@ -2012,20 +2257,36 @@ int lz_ritz_quality(lz_handle h, double* out) {
   }
   const size_t nblk = (size_t)((h->rows + 2047) / 2048);
   double* part = nullptr;
-  LZ_TRY(dev_alloc(h, part, (nblk + 1) * 2 * n));
-  double* dS = part + nblk * 2 * n;
-  int rc = LZ_OK;
-  {
-    Scope sc(h, LZ_K_RITZ, 12.0 * h->csr.nnz + 8.0 * n * (double)h->rows, 2.0 * (double)h->csr.nnz * n);
-    const int nb = launch_ritz_quality(h->csr, h->d_Y, n, n, part, h->stream);
-    launch_sum_slices(part, nb, 2 * (int64_t)n, dS, h->stream);
-    rc = check_launch(h, "ritz_quality");
+  rc = dev_alloc(h, part, (nblk + 1) * 2 * (size_t)nb);
+  if (rc != LZ_OK) {
+    hipFree(Yb);
+    return rc;
   }
-  std::vector<double> sums(2 * (size_t)n);
-  hipError_t e = hipSuccess;
-  if (rc == LZ_OK) e = hipMemcpyAsync(sums.data(), dS, sums.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  double* dSums = part + nblk * 2 * (size_t)nb;
+  for (int c0 = 0; c0 < n && rc == LZ_OK && e == hipSuccess; c0 += nb) {
+    const int nc = std::min(nb, n - c0);
+    const double* Ysrc = h->d_Y;
+    if (h->y_chunked) {
+      rc = ritz_cols_into(h, c0, nc, Yb, ldy);
+      Ysrc = Yb;
+      if (rc != LZ_OK) break;
+    }
+    {
+      Scope sc(h, LZ_K_RITZ, 12.0 * h->csr.nnz + 8.0 * nc * (double)h->rows, 2.0 * (double)h->csr.nnz * nc);
+      const int nblocks = launch_ritz_quality(h->csr, Ysrc, ldy, nc, part, h->stream);
+      launch_sum_slices(part, nblocks, 2 * (int64_t)nc, dSums, h->stream);
+      rc = check_launch(h, "ritz_quality");
+    }
+    std::vector<double> two(2 * (size_t)nc);
+    if (rc == LZ_OK) e = hipMemcpyAsync(two.data(), dSums, two.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    for (int i = 0; i < nc; ++i) {
+      sums[(size_t)c0 + i] = two[(size_t)i];
+      sums[(size_t)n + c0 + i] = two[(size_t)nc + i];
+    }
+  }
   hipFree(part);
+  hipFree(Yb);
   if (rc != LZ_OK) return rc;
   if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
   for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(kTPB) void k_gemm_tn(const double* __restrict__ A, 
     }
 }
 
+#ifdef LZ_KBENCH  // retired arms (measured slower): kernel-bench build only
 // Persistent variant for the Ritz back-transform (one K chunk, all columns in one group): the same 32 x NT*16 wave tile
 // and MFMA schedule, but a wave does not end with its tile - a grid of one workgroup per CU (one wave per SIMD: the tile
 // needs ~330 registers) walks the row tiles with a grid stride.  Why: with one short-lived workgroup per tile the CU
@@ -356,6 +357,8 @@ __global__ __launch_bounds__(NA == 2 ? 256 : 512) void k_gemm_tn_lds(const doubl
   }
 }
 
+#endif  // LZ_KBENCH
+
 // Ritz back-transform, S-STATIONARY kernel (variant 5; n in 193..208): S lives in registers, V streams through LDS.
 // Why.  The kernels above keep a tile of Y in the accumulators and re-read S every k-step: 13 operand fetches per 26 MFMAs,
 // and the MFMA stream with that fetch is what takes the time (15.5 of 16.1 ms).  Turned around, the
@@ -377,14 +380,14 @@ __global__ __launch_bounds__(NA == 2 ? 256 : 512) void k_gemm_tn_lds(const doubl
 template <int NT, int KS, int ABL = 0>  // ABL (kernel-bench build only): 1 no V loads, 2 no result stores
 __global__ __launch_bounds__(512) void k_gemm_tn_sreg(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
                                                      const double* __restrict__ B, int64_t ldb, int ncols,
-                                                     double* __restrict__ C, int64_t ldc) {
+                                                     double* __restrict__ C, int64_t ldc, unsigned long long* __restrict__ clk) {
   constexpr int FULL = NT / 4, REM = NT % 4, KH = KS / 2, KQ = (KS + 3) / 4;
   constexpr int TILE = 64 * KS;                  // doubles per staged tile: 4 KS basis rows x 16 matrix rows
   constexpr int NPC = TILE / 2 / 64;             // LDS-DMA instructions (64 x 16 bytes) per tile
   constexpr int NLD = (NPC + 3) / 4;             // per loader wave
   constexpr int IMG = FULL * 4 * 256;            // doubles per partial image: [wave s][panel j][reg g][lane]
   constexpr int PART = (REM > 0 ? REM : 1) * 4 * 256;  // K-split partials: [panel][wave s][reg][lane]
-  static_assert(KS % 2 == 0 && FULL >= 1 && 4 * FULL + REM + 4 < KH, "shape");
+  static_assert(KS % 2 == 0 && FULL >= 1 && 2 + 4 * FULL + REM <= KH, "shape");  // the storing waves' riders need one k-step each
   extern __shared__ double lds_sreg[];
   double* vt = lds_sreg;
   double* img = lds_sreg + 2 * TILE;
@@ -402,9 +405,14 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sreg(const double* __restrict__
   const int64_t first = (int64_t)blockIdx.x * per;
   const int64_t last = first + per < ntiles ? first + per : ntiles;
   if (first >= last) return;  // uniform over the block
-#ifdef LZ_KBENCH
-  const uint64_t kb_c0 = clock64(), kb_t0 = wall_clock64();  // shader-clock cycles vs the constant 100 MHz counter
-#endif
+  // In-kernel clock record (lz_ritz_info): shader-clock cycles (s_memtime) against the constant 100 MHz counter
+  // (s_memrealtime) over this workgroup's whole trip, taken by one wave of workgroup 0 - two scalar reads per launch.
+  const bool rec = clk != nullptr && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(w) == 0;  // wave-uniform: lives in SGPRs
+  uint64_t kb_c0 = 0, kb_t0 = 0;
+  if (rec) {
+    kb_c0 = clock64();
+    kb_t0 = wall_clock64();
+  }
   constexpr int PF = 4;  // fragments are read from LDS PF k-steps ahead of their MFMAs (explicit ring, fully unrolled loops)
   if (h == 1) {
     // ---------------- loader waves: second K half, the K-split panels, the LDS-DMA
@@ -559,14 +567,12 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sreg(const double* __restrict__
       }
     }
   }
-#ifdef LZ_KBENCH
-  if ((threadIdx.x == 0 || threadIdx.x == 256) && (blockIdx.x == 0 || blockIdx.x == 100)) {
-    const uint64_t c = clock64() - kb_c0, t = wall_clock64() - kb_t0;
-    printf("k_gemm_tn_sreg ABL=%d block %d wave %d: %llu shader cycles in %llu ticks of 10 ns: %.0f MHz, %d tiles, %.0f cycles per tile\n", ABL,
-           (int)blockIdx.x, w, (unsigned long long)c, (unsigned long long)t, t ? 100.0 * (double)c / (double)t : 0.0, (int)(last - first),
-           (double)c / (double)(last - first));
+  if (rec) {
+    clk[0] = clock64() - kb_c0;
+    clk[1] = wall_clock64() - kb_t0;
+    clk[2] = (unsigned long long)(last - first);
+    clk[3] = (unsigned long long)(NT * KS);  // MFMAs per 16-row tile over the four SIMDs
   }
-#endif
 }
 
 static void launch_gemm_tn(const double* A, int64_t lda, int64_t mdim, int64_t kcount, int64_t kchunk, int nz, const double* B,
@@ -587,25 +593,53 @@ static void launch_gemm_tn(const double* A, int64_t lda, int64_t mdim, int64_t k
 #undef LZ_TN
 }
 
-void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
-                      int64_t ldy, hipStream_t s, int variant) {
+// S-stationary launcher: one instantiation per (column tiles NT, k-steps KS).  More than 64 KiB of dynamic LDS needs the
+// per-kernel limit raised (once per instantiation; the result is checked).
+template <int NT, int KS>
+static hipError_t launch_sreg(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
+                              hipStream_t s, unsigned long long* clk) {
+  constexpr int FULL = NT / 4, REM = NT % 4;
+  constexpr size_t lds = (size_t)(2 * 64 * KS + 2 * FULL * 4 * 256 + 2 * (REM > 0 ? REM : 1) * 4 * 256) * sizeof(double);
+  static hipError_t attr = hipErrorNotReady;
+  if (attr == hipErrorNotReady)
+    attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_sreg<NT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((k_gemm_tn_sreg<NT, KS>), dim3(kNumCU), dim3(512), lds, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy, clk);
+  return hipSuccess;
+}
+
+// The S-stationary kernel covers 49 <= n <= 200: NT = ceil(n / 16) column tiles (4..13) and KS = ceil(n / 4) k-steps
+// rounded up to even (the two waves of a SIMD split them in halves); S is zero-padded to 16 NT rows and columns.
+static bool sreg_dispatch(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
+                          hipStream_t s, unsigned long long* clk, hipError_t* err) {
+  const int NT = (n + 15) / 16;
+  const int KS = (((n + 3) / 4) + 1) & ~1;
+#define LZ_SR(nt, ks)                                                                  \
+  if (NT == nt && KS == ks) {                                                          \
+    *err = launch_sreg<nt, ks>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk);            \
+    return true;                                                                       \
+  }
+  LZ_SR(4, 14) LZ_SR(4, 16) LZ_SR(5, 18) LZ_SR(5, 20) LZ_SR(6, 22) LZ_SR(6, 24) LZ_SR(7, 26) LZ_SR(7, 28) LZ_SR(8, 30) LZ_SR(8, 32)
+  LZ_SR(9, 34) LZ_SR(9, 36) LZ_SR(10, 38) LZ_SR(10, 40) LZ_SR(11, 42) LZ_SR(11, 44) LZ_SR(12, 46) LZ_SR(12, 48) LZ_SR(13, 50)
+#undef LZ_SR
+  return false;
+}
+
+#ifdef LZ_KBENCH
+// Kernel-bench build only: the retired Ritz GEMM kernels (variant 2 persistent waves, 3 / 4 S staged through LDS) and the
+// timing-only ablation arms (variant >= 10 / >= 20, n = 200) that compute wrong results on purpose.
+static bool kbench_ritz_arm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
+                            hipStream_t s, int variant, hipError_t* err) {
+  *err = hipSuccess;
   const int CT = (n + 15) / 16;
   const int64_t ntiles = (rows + 31) / 32;
-  // 0 (auto): the S-stationary kernel where it applies (193 <= n <= 200, enough row tiles for a persistent grid), else the
-  // one-workgroup-per-128-rows kernel; 1 forces the latter; 2..5 are the A/B arms
-  const bool sreg_ok = n > 192 && n <= 200 && (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 && npad >= 208 &&
-                       ntiles >= 2 * kNumCU * (kTPB / 64);
-  if (variant == 0 && sreg_ok) variant = 5;
-  if (variant == 0 || variant == 1 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) {  // also > 256 columns or too few tiles to loop over
-    launch_gemm_tn(V, ldv, rows, n, n, 1, Spad, npad, n, Y, ldy, 0, s);
-    return;
-  }
-#ifdef LZ_KBENCH
+  if (variant < 2 || variant == 5 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) return false;
   if (variant >= 20 && variant < 84 && CT == 13 && n == 200) {  // timing-only arms of the S-stationary kernel
     constexpr size_t lds50 = (size_t)(2 * 64 * 50 + 2 * 3 * 4 * 256 + 2 * 4 * 256) * sizeof(double);
     auto go = [&](auto kern) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds50);
-      hipLaunchKernelGGL(kern, dim3(kNumCU), dim3(512), lds50, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy);
+      *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds50);
+      if (*err == hipSuccess)
+        hipLaunchKernelGGL(kern, dim3(kNumCU), dim3(512), lds50, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy, (unsigned long long*)nullptr);
     };
     switch (variant - 20) {
       case 1: go(k_gemm_tn_sreg<13, 50, 1>); break;
@@ -613,7 +647,7 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
       case 3: go(k_gemm_tn_sreg<13, 50, 3>); break;
       default: go(k_gemm_tn_sreg<13, 50, 0>); break;
     }
-    return;
+    return true;
   }
   if (variant >= 10 && CT == 13) {  // timing-only ablation arms at n = 200
     const size_t ldsk = (size_t)2 * 16 * npad * sizeof(double);
@@ -627,20 +661,7 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
       case 6: go(k_gemm_tn_lds<13, 6>); break;
       default: go(k_gemm_tn_lds<13>); break;
     }
-    return;
-  }
-#endif
-  if (variant == 5 && sreg_ok) {
-    // S-stationary kernel: S in registers (25 k-steps x 3 panels per wave: 50 k-steps cover n <= 200), V tiles through
-    // LDS (reads whole 16-row tiles: ldv covers the padded rows)
-    static bool attr_done = false;  // more than 64 KiB of dynamic LDS: allowed once per kernel
-    constexpr size_t lds50 = (size_t)(2 * 64 * 50 + 2 * 3 * 4 * 256 + 2 * 4 * 256) * sizeof(double);
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_sreg<13, 50>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds50);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL((k_gemm_tn_sreg<13, 50>), dim3(kNumCU), dim3(512), lds50, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy);
-    return;
+    return true;
   }
   if (variant == 4) {  // one wave per SIMD with a 32-row tile, S through LDS: every staged fragment feeds two MFMAs
     const size_t lds = (size_t)2 * 16 * npad * sizeof(double);
@@ -654,9 +675,9 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
       default: break;
     }
 #undef LZ_TNL2
-    return;
+    return true;
   }
-  if (variant == 3) {  // A/B arm: two waves per SIMD, S through LDS
+  if (variant == 3) {  // two waves per SIMD, S through LDS
     const size_t lds = (size_t)2 * 16 * npad * sizeof(double);
 #define LZ_TNL(nt)                                                                                                            \
   case nt:                                                                                                                    \
@@ -668,19 +689,48 @@ void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const d
       default: break;
     }
 #undef LZ_TNL
-    return;
+    return true;
   }
-  const dim3 grid(kNumCU), block(kTPB);
+  if (variant == 2) {
+    const dim3 grid(kNumCU), block(kTPB);
 #define LZ_TNP(nt)                                                                                                  \
   case nt:                                                                                                          \
     hipLaunchKernelGGL((k_gemm_tn_persist<nt>), grid, block, 0, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy); \
     break;
-  switch (CT) {
-    LZ_TNP(1) LZ_TNP(2) LZ_TNP(3) LZ_TNP(4) LZ_TNP(5) LZ_TNP(6) LZ_TNP(7) LZ_TNP(8)
-    LZ_TNP(9) LZ_TNP(10) LZ_TNP(11) LZ_TNP(12) LZ_TNP(13) LZ_TNP(14) LZ_TNP(15) LZ_TNP(16)
-    default: break;
-  }
+    switch (CT) {
+      LZ_TNP(1) LZ_TNP(2) LZ_TNP(3) LZ_TNP(4) LZ_TNP(5) LZ_TNP(6) LZ_TNP(7) LZ_TNP(8)
+      LZ_TNP(9) LZ_TNP(10) LZ_TNP(11) LZ_TNP(12) LZ_TNP(13) LZ_TNP(14) LZ_TNP(15) LZ_TNP(16)
+      default: break;
+    }
 #undef LZ_TNP
+    return true;
+  }
+  return false;
+}
+#endif  // LZ_KBENCH
+
+hipError_t launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
+                            int64_t ldy, hipStream_t s, int variant, unsigned long long* clk) {
+  const int64_t ntiles = (rows + 31) / 32;
+  // 0 (auto): the S-stationary kernel where it applies (49 <= n <= 200, enough row tiles for a persistent grid, 16-byte
+  // aligned rows), else one workgroup per 128 rows; 1 forces the latter
+  const bool sreg_ok = n > 48 && n <= 200 && (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 && npad >= 16 * ((n + 15) / 16) &&
+                       ntiles >= 2 * kNumCU * (kTPB / 64);
+#ifdef LZ_KBENCH
+  if (hipError_t e; kbench_ritz_arm(V, ldv, rows, n, Spad, npad, Y, ldy, s, variant, &e)) return e;
+#endif
+  if (variant != 1 && sreg_ok) {
+    hipError_t e = hipSuccess;
+    if (sreg_dispatch(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e)) return e;
+  }
+  launch_gemm_tn(V, ldv, rows, n, n, 1, Spad, npad, n, Y, ldy, 0, s);
+  return hipSuccess;
+}
+
+// columns [0, ncols) of V^T-layout x B for all rows, B = a column block of the padded S (chunked Ritz-vector quality)
+void launch_ritz_gemm_cols(const double* V, int64_t ldv, int64_t rows, int kcount, const double* B, int ldb, int ncols, double* Y,
+                           int64_t ldy, hipStream_t s) {
+  launch_gemm_tn(V, ldv, rows, kcount, kcount, 1, B, ldb, ncols, Y, ldy, 0, s);
 }
 
 // out[i] = sum_z part[z*count + i] (fixed order)

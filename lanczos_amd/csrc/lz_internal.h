@@ -101,7 +101,7 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
                    int cG = 0, int cldp = 0);
 void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s);
 void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s);
-void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, hipStream_t s);
+void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, double* bad, hipStream_t s);
 // r = (r - alpha v_j) - beta v_jm1 ; part[b] = partial ||r||^2 ; returns number of partials
 int launch_three_term(double* r, const double* vj, const double* vjm1, const double* alpha, const double* beta,
                       int64_t len, double* part, hipStream_t s);
@@ -123,11 +123,15 @@ void launch_bi_two_term(int sub, int dots, double* r, double* sv, const double* 
 int bi_partials_needed();  // per partial buffer; the handle keeps two (deferred folds ping-pong between them)
 
 // Y(rows x n, row-major, ldy) = sum_k V[k][m] * S[k][i]   (FP64 MFMA)
-// variant 0/1: one workgroup per 128 rows, one wave per SIMD owning 32 rows x all columns (default: the fastest of the
-// three on MI355X, profiles/r02/ablate_pb_rows_and_ritz.json); 2: the same tile walked by persistent waves; 3: persistent
-// waves, two per SIMD with 16-row tiles, S staged through LDS; 4: the LDS kernel with one wave per SIMD and 32-row tiles
-void launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
-                      int64_t ldy, hipStream_t s, int variant = 0);
+// variant 0: the S-stationary kernel (S in registers, V tiles through LDS) for 49 <= n <= 200 when there are enough row
+// tiles for a persistent grid, else one workgroup per 128 rows, one wave per SIMD owning 32 rows x all columns; 1: the
+// latter always.  (The retired arms - persistent waves, S staged through LDS - live in the kernel-bench build.)
+// clk (optional, 8 words): in-kernel clock record of the S-stationary kernel, see lz_ritz_info.
+// Returns the error of the per-kernel LDS-limit raise (hipFuncSetAttribute) if that was needed and failed.
+hipError_t launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
+                            int64_t ldy, hipStream_t s, int variant = 0, unsigned long long* clk = nullptr);
+void launch_ritz_gemm_cols(const double* V, int64_t ldv, int64_t rows, int kcount, const double* B, int ldb, int ncols, double* Y,
+                           int64_t ldy, hipStream_t s);
 // G = Y^T Y as K-chunk partials (n x n each); returns the number of chunks (<= nz_max)
 int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part, int nz_max, hipStream_t s);
 void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s);

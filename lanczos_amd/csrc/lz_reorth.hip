@@ -510,6 +510,13 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   }
 }
 
+// LDS bytes left for ONE slice of w in the default (4x4x4 MFMA) kernel: a block stages ncol slices and parks ncol sets of four
+// coefficient runs of qtw_ldp(rows) doubles (one-reduce mode: two columns, and two more "rows" for the self terms)
+static int64_t qtw_room(int flags, int nrows_max) {
+  const int ncol = (flags & LZ_FLAG_ONE_REDUCE) ? 2 : 1;
+  return (int64_t)155 * 1024 / ncol - (int64_t)(kTPB / 64) * qtw_ldp(nrows_max + (ncol == 2 ? 2 : 0)) * 8;
+}
+
 QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
   QtwPlan p;
   int64_t target = (tune && tune[0] > 0) ? tune[0] : 0;
@@ -527,7 +534,7 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
     // the default kernel also parks four coefficient runs of qtw_ldp(n) doubles in LDS: with thousands of basis rows the
     // slice has to shrink to stay inside the 160 KiB of a CU (n = 4000 -> L <= 3072)
     int64_t lmax = (flags & LZ_FLAG_ONE_REDUCE) ? kQtwMaxL / 2 : kQtwMaxL;  // one-reduce mode stages two slices per block
-    const int64_t room = (int64_t)155 * 1024 - (int64_t)(kTPB / 64) * qtw_ldp(nrows_max) * 8;
+    const int64_t room = qtw_room(flags, nrows_max);
     if (room / 8 < lmax) lmax = std::max<int64_t>(512, room / 8 / 512 * 512);
     for (int64_t cand = lmax; cand >= 1024 && !found; cand -= 512) {
       const int64_t G = (len + cand - 1) / cand;
@@ -548,7 +555,7 @@ QtwPlan plan_qtw(int64_t len, int flags, const int* tune, int nrows_max) {
   // kernel family: 2 = 4x4x4 MFMA (default: matrix cores, line-coalesced loads), 1 = 16x16x4 MFMA (A/B arm),
   // 0 = VALU + shuffle reductions (LZ_FLAG_QTW_VALU)
   p.family = (flags & LZ_FLAG_QTW_VALU) ? 0 : ((flags & LZ_FLAG_QTW_MFMA) ? 1 : 2);
-  if (p.family == 2 && (int64_t)155 * 1024 - (int64_t)(kTPB / 64) * qtw_ldp(nrows_max) * 8 < L * 8)
+  if (p.family == 2 && qtw_room(flags, nrows_max) < L * 8)
     p.family = 0;  // ~5000 basis rows and more: the coefficient runs no longer fit next to any slice - VALU kernel, partials in HBM
   p.mfma = p.family != 0;
   p.variant = tune ? tune[1] : 0;
@@ -962,18 +969,23 @@ __global__ void k_fused_prepare(double* __restrict__ c, int j, double* __restric
 // (p_i = V_i.r'', q_i = V_i.u, m rows, second half at offset ldp, alpha = u.(A u) at ldp + m + 2):
 //   c_i = V_i . (r'' - alpha u) = p_i - alpha q_i,   c_m = |r'' - alpha u|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u
 // left in buf[0..m] exactly where the update kernel's raw-sums path expects [V_i.r ..., r.r]; alpha to alpha_slot.
-__global__ void k_onereduce_prepare(double* __restrict__ buf, int m, int ldp, double* __restrict__ alpha_slot) {
+// The three-sum form of |r|^2 cancels: its relative error is about eps (alpha^2 + beta^2) / beta^2.  Where that would
+// break the 1e-10 bar (|r|^2 below 1e-4 of r''.r'', or not positive at all: shifted spectra, a nearly converged Krylov
+// space) the kernel raises the sticky flag `bad`; lz_run then repeats the solve on the default two-reduce loop.
+__global__ void k_onereduce_prepare(double* __restrict__ buf, int m, int ldp, double* __restrict__ alpha_slot, double* __restrict__ bad) {
   const double a = buf[ldp + m + 2];
   for (int i = threadIdx.x; i < m; i += blockDim.x) buf[i] = buf[i] - a * buf[ldp + i];
   __syncthreads();
   if (threadIdx.x == 0) {
     const double rr = buf[m], uu = buf[ldp + m], ur = buf[ldp + m + 1];
-    buf[m] = (rr - 2.0 * a * ur) + a * a * uu;
+    const double v = (rr - 2.0 * a * ur) + a * a * uu;
+    if (!(v > 1e-4 * rr)) bad[0] = 1.0;
+    buf[m] = v;
     alpha_slot[0] = a;
   }
 }
-void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, hipStream_t s) {
-  hipLaunchKernelGGL(k_onereduce_prepare, dim3(1), dim3(kTPB), 0, s, buf, m, ldp, alpha_slot);
+void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, double* bad, hipStream_t s) {
+  hipLaunchKernelGGL(k_onereduce_prepare, dim3(1), dim3(kTPB), 0, s, buf, m, ldp, alpha_slot, bad);
 }
 
 void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s) {

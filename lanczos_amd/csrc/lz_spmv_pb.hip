@@ -332,6 +332,27 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
   }
 }
 
+// once per process and kernel: dynamic-LDS limit = the CU's 160 KiB (result remembered, returned on every call)
+constexpr size_t kPbLdsCuMax = 160 * 1024;
+hipError_t pb_raise_lds_limits() {
+  static hipError_t done = hipErrorNotReady;
+  if (done != hipErrorNotReady) return done;
+  hipError_t e = hipSuccess;
+  auto up = [&](const void* k) {
+    const hipError_t x = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPbLdsCuMax);
+    if (e == hipSuccess) e = x;
+  };
+  up(reinterpret_cast<const void*>(k_pb_products<4>));
+  up(reinterpret_cast<const void*>(k_pb_rows<0>));
+#ifdef LZ_KBENCH
+  up(reinterpret_cast<const void*>(k_pb_rows<1>));
+  up(reinterpret_cast<const void*>(k_pb_rows<2>));
+  up(reinterpret_cast<const void*>(k_pb_rows<7>));
+#endif
+  done = e;
+  return e;
+}
+
 template <class T>
 hipError_t pb_alloc(T*& p, size_t count) {
   void* q = nullptr;
@@ -460,20 +481,11 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   pb->segmax = segmax;
   pb->lds2 = (size_t)segmax * sizeof(double) + (size_t)(cap + 16) * sizeof(uint16_t);
   if (e == hipSuccess && segmax > kPbNQ * 2 * kPbThreads) e = hipErrorInvalidValue;  // cannot happen: the LDS bound is tighter
-  // both phases may need more than the default 64 KiB of dynamic LDS: allowed once per kernel, here, so that the
-  // launches themselves have no failure mode
-  if (e == hipSuccess && pb->lds2 > 160 * 1024) e = hipErrorInvalidValue;
-  if (e == hipSuccess && W * sizeof(double) > 65536)
-    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_products<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(W * sizeof(double))));
-  if (e == hipSuccess && pb->lds2 > 65536)
-    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pb->lds2));
-#ifdef LZ_KBENCH
-  if (e == hipSuccess && pb->lds2 > 65536) {
-    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pb->lds2));
-    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pb->lds2));
-    chk(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pb_rows<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pb->lds2));
-  }
-#endif
+  // Both phases may need more than the default 64 KiB of dynamic LDS.  The limit is a property of the KERNEL, shared by
+  // every layout in the process (H and H^T of a two-sided run, a second handle, ...): it is raised once to what the CU
+  // has - never to one matrix's need, which a later, smaller layout would lower again under the earlier one's launches.
+  if (e == hipSuccess && (pb->lds2 > kPbLdsCuMax || W * sizeof(double) > kPbLdsCuMax)) e = hipErrorInvalidValue;
+  if (e == hipSuccess) chk(pb_raise_lds_limits());
   if (e != hipSuccess) {
     pb_free(pb);
     return e;

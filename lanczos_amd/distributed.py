@@ -365,7 +365,7 @@ class DistributedLanczos:
 
     @classmethod
     def from_stencil(cls, dims, points, boot=None, device_id=0, backend="rccl", options=0, fused_norm=True, one_reduce=False,
-                     tuning=None, T_factor=1.0, weights4=(-6.0, 1.0, 0.0, 0.0), negate_T=True, potential_params=None):
+                     tuning=None, T_factor=1.0, weights4=(-6.0, 1.0, 0.0, 0.0), negate_T=True, potential_params=None, potential_local=None):
         """This rank's slab of the periodic ``Nx x Ny x Nz`` 7-/27-point stencil operator assembled DIRECTLY ON THE DEVICE
         (no host matrix at any size: BASELINE config C4's 1e8-row Laplacian is 8.4 GB of CSR): the halo plan comes from
         the slab's boundary rows alone (``partition.plan_stencil_slab``), the kernel renumbers the columns itself.
@@ -395,7 +395,7 @@ class DistributedLanczos:
             self.h.set_tuning(k, v)
         self.backend = backend
         self._init_comm(backend)
-        self.h.build_stencil3d_block(dims, points, T_factor, weights4, self.lo, self.hi - self.lo, ranges,
+        self.h.build_stencil3d_block(dims, points, T_factor, weights4, self.lo, self.hi - self.lo, ranges, potential=potential_local,
                                      potential_params=potential_params, negate_T=negate_T)
         if self.plan.mode == "halo":
             self.h.set_halo(self.plan.peers, self.plan.send_counts, self.plan.send_idx, self.plan.recv_counts)
@@ -459,6 +459,12 @@ class DistributedLanczos:
             v0_normalized_local = self.start_vector(seed, v0)[self.lo : self.hi]
         self.n = n
         self.alpha, self.beta = self.h.run(n, v0_normalized_local)
+        self.breakdown = bool(self.h.breakdown)
+        if self.breakdown:  # lz_run returned LZ_WARN_BREAKDOWN: the same signal the single-GPU class gives (_solver.py)
+            import warnings
+
+            warnings.warn("Lanczos breakdown: a residual norm beta reached zero (invariant subspace); H_eff contains rounding "
+                          "noise or non-finite entries, exactly as the reference's would", RuntimeWarning, stacklevel=2)
         idx = np.arange(n)
         H_eff = np.zeros((n, n))
         H_eff[idx, idx] = self.alpha

@@ -120,6 +120,19 @@ class Hamiltonian:
             return self._device_csr(points, None, True, potential_params=self.potential.device_params(self.L))
         return self._device_csr(points, self.potential_on_grid(), True)
 
+    def operator(self, points="27"):
+        """``H = -T + V`` as a closed-form descriptor (``_pool.StencilOperator``) instead of a SciPy matrix: hand it to
+        ``Lanczos(...)`` and the matrix is assembled on the device(s) - with ``Lanczos.devices`` every rank builds only its
+        own slab (``lz_build_stencil3d_block``) - and never exists on the host.  Same entries as ``build_H`` bit for bit
+        (host-evaluated potential) or to the last bits of exp/pow (``device_potential``)."""
+        from ._pool import StencilOperator
+
+        N = self.N
+        if self.device_potential and hasattr(self.potential, "device_params"):
+            return StencilOperator((N, N, N), int(points), self.T_factor, self._weights4(points), True,
+                                   potential_params=self.potential.device_params(self.L))
+        return StencilOperator((N, N, N), int(points), self.T_factor, self._weights4(points), True, potential=self.potential_on_grid())
+
     # ------------------------------------------------------------------ index helpers (Hamiltonian.py:73-128)
     def unravel_xyz(self, x, y, z):
         N = self.N

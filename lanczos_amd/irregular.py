@@ -5,7 +5,7 @@ import numpy as np
 import scipy.sparse
 
 from . import _capi
-from ._solver import LanczosBase, _CPU_MSG, _pack_matrix
+from ._solver import LanczosBase, _pack_matrix, _use_cuda_or_notice
 
 
 class IrrLanczos(LanczosBase):
@@ -29,11 +29,12 @@ class IrrLanczos(LanczosBase):
         check.  ``dtype`` other than float64 is not supported by the device path."""
         if n > self.M:
             raise ValueError("n cannot be larger than M!")
-        assert np.shape(self.H)[0] == np.shape(self.H)[1]
+        assert self.H.shape[0] == self.H.shape[1]
         self._say("+++ Executing Lanczos algorithm")
         self.n = n
-        if not use_cuda:
-            raise NotImplementedError(_CPU_MSG)
+        _use_cuda_or_notice(self, use_cuda)
+        if self._multi():
+            raise NotImplementedError("the two-sided variant runs on one GPU (devices must be None or a single entry)")
         if np.dtype(dtype) != np.float64:
             raise NotImplementedError("the device path computes in float64 only")
         M = self.M
@@ -56,11 +57,10 @@ class IrrLanczos(LanczosBase):
 
         kind, rowptr, colidx, vals = _pack_matrix(H)
         _, t_rowptr, t_colidx, t_vals = _pack_matrix(HT)
-        if self._handle is None:
-            self._handle = _capi.Handle(self.device_id)
-        h = self._handle
+        h = self._get_handle()
         h.set_options(self.options)
         h.set_csr(M, 0, rowptr, colidx, vals)
+        self._matrix_key = self._matrix_key_alt = None  # (the symmetric solver's cache key does not describe this upload)
         symmetric = (len(t_colidx) == len(colidx) and np.array_equal(t_rowptr, rowptr) and np.array_equal(t_colidx, colidx)
                      and np.array_equal(t_vals, vals))
         if symmetric:
@@ -122,8 +122,7 @@ class IrrLanczos(LanczosBase):
         """In place on row ``j`` of the four (n, M) arrays, the reference's default branch (IrrLanczos.py:408-441):
         project ``V1[j]`` on ``p_basis[:j]`` and ``V2[j]`` on ``q_basis[:j]`` (sequential Gram-Schmidt), rescale the
         pair to ``V1[j] . V2[j] = +-1``, then extend the two orthonormal bases by row ``j``.  Runs on the device."""
-        if not use_cuda:
-            raise NotImplementedError(_CPU_MSG)
+        _use_cuda_or_notice(LanczosBase, use_cuda)
         if mem_safe:
             raise NotImplementedError("mem_safe=True (IrrLanczos.py:397-407) is a different, unused arithmetic; "
                                       "only the default branch is implemented")

@@ -67,3 +67,21 @@ def hip():
 
     _capi.load_library()
     return _capi
+
+
+@pytest.fixture(scope="session")
+def kb(hip):
+    """The KERNEL-BENCH build (liblanczos_kbench.so, `make KBENCH=1`): the product's kernels plus the retired A/B arms (one-kernel
+    and one-launch-per-step engines, persistent / LDS-staged Ritz GEMMs, 16x16x4 Q^T w, ticket / deferred-fold two-sided
+    links).  The arms left the product library in round 3; their bit-identity tests load this build instead."""
+    import types
+
+    if not os.path.isfile(hip.KBENCH_LIB_PATH):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(ROOT, "lanczos_amd", "csrc"), "-j4", "KBENCH=1"], check=True)
+    lib = hip.load_library(hip.KBENCH_LIB_PATH)
+    ns = types.SimpleNamespace(**{k: getattr(hip, k) for k in dir(hip) if k.startswith("FLAG_")})
+    ns.lib = lib
+    ns.Handle = lambda device_id=0: hip.Handle(device_id, lib=lib)
+    return ns

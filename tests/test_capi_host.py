@@ -86,7 +86,7 @@ def test_call_surface_matches_reference():
         assert isinstance(getattr(Lanczos, prop), property)
 
 
-def test_error_behaviour_before_any_device_work():
+def test_error_behaviour_before_any_device_work(capsys):
     Lanczos.verbose = IrrLanczos.verbose = False
     H = synthetic.laplacian_2d_5pt(8, 8).to_scipy()
     s = Lanczos(H)
@@ -100,8 +100,16 @@ def test_error_behaviour_before_any_device_work():
         s.compare_eigs()
     with pytest.raises(ValueError, match="n cannot be larger than M!"):
         s.execute_Lanczos(65)
+    # use_cuda=False (3Ddeuteron.py:95): accepted - it announces itself and takes the ONLY compute path, the HIP one (so on
+    # this GPU-less box it fails loudly there, never in a NumPy fallback); strict_use_cuda restores round 2's refusal
+    s.strict_use_cuda = True
     with pytest.raises(NotImplementedError, match="device path only"):
         s.execute_Lanczos(10, use_cuda=False)
+    s.strict_use_cuda = False
+    if not has_gpu():
+        with pytest.raises(lanczos_amd.LanczosHipError, match="LZ_ERR_NODEVICE"):
+            s.execute_Lanczos(10, use_cuda=False)
+        assert "use_cuda=False: lanczos_amd has no NumPy path" in capsys.readouterr().out
     with pytest.raises(IndexError):
         s.execute_Lanczos(1)
     t = IrrLanczos(H)
@@ -111,8 +119,14 @@ def test_error_behaviour_before_any_device_work():
         t.execute_Lanczos(65)
     with pytest.raises(UnboundLocalError):
         t.execute_Lanczos(10, v0=np.ones(64))
+    t.strict_use_cuda = True
     with pytest.raises(NotImplementedError, match="device path only"):
         t.execute_Lanczos(10, use_cuda=False)
+    t.strict_use_cuda = False
+    t.devices = [0, 1]  # the two-sided variant is single-GPU
+    with pytest.raises(NotImplementedError, match="one GPU"):
+        t.execute_Lanczos(10)
+    t.devices = None
     import lanczos_amd._capi as capi
     ndev = C.c_int(-1)
     if capi.load_library().lz_device_count(C.byref(ndev)) != 0 or ndev.value == 0:

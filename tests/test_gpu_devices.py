@@ -1,0 +1,191 @@
+"""The multi-GPU path behind the DROP-IN class surface: ``Lanczos(H).execute_Lanczos(n)`` with ``Lanczos.devices`` set
+(/root/reference/Python/Regular/Lanczos.py:19-26,75-141 is single-process; SURVEY.md section 5 "Config / flags" names the
+``devices=`` hook).  The test box has ONE GPU and RCCL refuses two ranks per device, so the workers share GPU 0 and the
+collectives are staged through the host (``comm_backend = "host"``); every kernel and every line of the partition logic is
+the one the 8-GPU run uses.  Held to: the golden fixtures (1e-10 bar), and ``np.array_equal`` against
+``distributed.DistributedLanczos`` driven directly with the same number of ranks."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+import uuid
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from lanczos_amd import Hamiltonian, IrrLanczos, Lanczos, StencilOperator, synthetic
+from oracle import lanczos_ref as oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# one rank of the direct DistributedLanczos run the pool is compared with (same world, same backend)
+DIRECT = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["LZ_ROOT"])
+    from lanczos_amd import distributed, partition, synthetic
+    boot = distributed.SocketBootstrap()
+    cases = {
+        "lap2d": (lambda lo, hi: synthetic.laplacian_2d_5pt(96, 80, rows=(lo, hi)), 96 * 80, 40),
+        "c4_slab": (lambda lo, hi: synthetic.laplacian_3d_7pt(24, 24, 32, rows=(lo, hi)), 24 * 24 * 32, 200),
+        "c5": (lambda lo, hi: synthetic.laplacian_2d_5pt(160, 120, rows=(lo, hi)), 160 * 120, 500),
+        "graph": (lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, 30),
+    }
+    out = {}
+    for name, (build, M, n) in cases.items():
+        b = partition.row_bounds(M, boot.world)
+        lo, hi = b[boot.rank], b[boot.rank + 1]
+        s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host")
+        a, bt = s.execute_Lanczos(n)
+        s.get_H_eigs()
+        V = np.concatenate(boot.allgather_obj(s.V_local), axis=0)
+        Y = np.concatenate(boot.allgather_obj(s.H_eigvecs_local), axis=0)
+        if boot.rank == 0:
+            np.savez(os.path.join(os.environ["LZ_OUT"], name + ".npz"), alpha=a, beta=bt, V=V, Y=Y, theta=s.H_eigvals)
+        s.h.close()
+    boot.barrier()
+''')
+
+
+def _direct(tmp_path, world):
+    script = tmp_path / "direct.py"
+    script.write_text(DIRECT)
+    key = uuid.uuid4().hex[:12]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, LZ_ROOT=ROOT, LZ_OUT=str(tmp_path), RANK=str(r), WORLD_SIZE=str(world), LZ_RDZV_KEY=key, OMP_NUM_THREADS="2",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, out[-2000:] + err[-3000:]
+    return {n: dict(np.load(tmp_path / (n + ".npz"))) for n in ("lap2d", "c4_slab", "c5", "graph")}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_class_surface_with_devices_equals_distributed_lanczos(tmp_path, world):
+    ref = _direct(tmp_path, world)
+    Lanczos.verbose = IrrLanczos.verbose = False
+    inputs = {
+        "lap2d": (synthetic.laplacian_2d_5pt(96, 80).to_scipy(), 40),
+        "c4_slab": (synthetic.laplacian_3d_7pt(24, 24, 32).to_scipy(), 200),  # BASELINE C4 (z-slab partition, k = 200) at reduced size
+        "c5": (synthetic.laplacian_2d_5pt(160, 120).to_scipy(), 500),         # BASELINE C5 (k = 500) at reduced size
+        "graph": (synthetic.random_graph_laplacian(6000, 20000, seed=4).to_scipy(), 30),
+    }
+    for name, (H, n) in inputs.items():
+        cls = IrrLanczos if name == "graph" else Lanczos  # the Irregular facade goes through the same pool
+        s = cls(H)
+        s.devices = [0] * world
+        s.comm_backend = "host"
+        (s.execute_LanczosOld if name == "graph" else s.execute_Lanczos)(n)
+        d = ref[name]
+        assert s._handle.world == world and s._handle.exchange_mode() == ("allgather" if name == "graph" else "halo")
+        assert np.array_equal(np.diag(s.H_eff), d["alpha"]) and np.array_equal(np.diag(s.H_eff, 1), d["beta"]), name
+        assert np.array_equal(s.H_eff, s.H_eff.T) and s.H_eff.shape == (n, n)
+        assert np.array_equal(s.H_eigvals, d["theta"]), name
+        assert s.V.shape == (H.shape[0], n) and np.array_equal(s.V, d["V"]), name
+        assert s.H_eigvecs.shape == (H.shape[0], n) and np.array_equal(s.H_eigvecs, d["Y"]), name
+        # windows of V / H_eigvecs that straddle a rank boundary
+        lo, hi = H.shape[0] // world - 7, H.shape[0] // world + 41
+        assert np.array_equal(s.V_rows(lo, hi), d["V"][lo:hi]) and np.array_equal(s.H_eigvecs_rows(lo, hi), d["Y"][lo:hi])
+        if name == "lap2d":  # print_good_eigs' quality sums as a collective, against NumPy on the gathered Ritz vectors
+            q = s._eigvec_quality()
+            Z = H @ d["Y"]
+            qref = np.einsum("ri,ri->i", Z, d["Y"]) ** 2 / np.einsum("ri,ri->i", Z, Z)
+            assert np.abs(q - qref).max() <= 1e-12 * np.abs(qref).max()
+            uploads = s._handle.matrix_uploads
+            s.execute_Lanczos(n)  # same H: the workers keep their row blocks
+            assert s._handle.matrix_uploads == uploads and np.array_equal(np.diag(s.H_eff), d["alpha"])
+        # against the CPU oracle on the whole matrix (north-star bar on the prefix the reference arithmetic determines)
+        ao, bo, _ = oracle.execute_lanczos(H, n, economy=True)
+        prefix, mask = (n, np.ones(n, bool)) if n < 100 else oracle.stable_masks(H, n, ao, bo)
+        scale = max(np.abs(ao).max(), np.abs(bo).max())
+        assert np.abs(d["alpha"] - ao)[:prefix].max() <= 1e-10 * scale and np.abs(d["beta"] - bo)[: prefix - 1].max() <= 1e-10 * scale, name
+        th = np.linalg.eigvalsh(oracle.build_h_eff(ao, bo))
+        assert np.abs(s.H_eigvals - th)[mask].max() <= 1e-10 * np.abs(th).max(), name
+        s.close()
+
+
+@pytest.mark.parametrize("name", ["lap2d_32x32_n30", "lap3d_8x8x8_n40", "graph_M2000_E7000_n40", "c1_dense512_n20", "deuteron3d_N12_27pt_n100",
+                                  "ragged_M700_n25", "lap2d_8x8_n2"])
+def test_golden_fixtures_through_two_workers(name):
+    """the reference's own outputs (tests/golden, generated by importing the reference) through ``devices = [0, 0]``: the
+    same comparison tests/test_gpu_lanczos.py::test_golden makes on one GPU"""
+    d, H = load_golden(name)
+    n, seed = int(d["n"]), int(d["seed"])
+    v0 = d["v0"] if "v0" in d else None
+    Lanczos.verbose = False
+    s = Lanczos(H.toarray() if name.startswith("c1_dense") else H)
+    s.devices = [0, 0]
+    s.comm_backend = "host"
+    s.execute_Lanczos(n, seed=seed, v0=v0)
+    alpha, beta = np.diag(s.H_eff), np.diag(s.H_eff, 1)
+    scale = max(np.abs(d["alpha"]).max(), np.abs(d["beta"]).max())
+    prefix, mask = oracle.stable_masks(H, n, d["alpha"], d["beta"], seed=seed, v0=v0)
+    assert np.abs(alpha - d["alpha"])[:prefix].max() <= 1e-10 * scale
+    assert np.abs(beta - d["beta"])[: max(prefix - 1, 1)].max() <= 1e-10 * scale
+    if prefix == n:
+        assert np.abs(s.H_eigvals - d["H_eigvals"]).max() <= 1e-10 * np.abs(d["H_eigvals"]).max()
+    else:
+        conv = oracle.converged_ritz(d["alpha"], d["beta"])
+        nearest = np.abs(s.H_eigvals[None, :] - conv[:, None]).min(axis=1)
+        assert nearest.max() <= 1e-10 * np.abs(d["H_eigvals"]).max()
+    assert s.V.shape == (int(d["M"]), n) and s.H_eigvecs.shape == (int(d["M"]), n)
+    if "V" in d:
+        vrows = oracle.stable_basis_rows(H, n, d["V"], seed=seed, v0=v0)
+        ref = d["V"][:vrows].T
+        assert np.abs(s.V[:, :vrows] - ref).max() <= 1e-10 * np.abs(ref).max()
+    s.close()
+
+
+def test_stencil_operator_on_one_and_on_three_workers():
+    """``Hamiltonian.operator()``: the matrix is assembled on the device(s) - each worker its own slab - and never exists on
+    the host; same entries as ``build_H`` (the reference builder's bits), same run."""
+    Hamiltonian.verbose = Lanczos.verbose = False
+    N, n = 14, 60
+    os.makedirs("T_matrices", exist_ok=True)
+    ham = Hamiltonian(N, 25, synthetic.deuteron_potential, 197.327**2 / (2 * 469.4592) / (25.0 / N) ** 2)
+    H = ham.build_H("27")
+    op = ham.operator("27")
+    assert isinstance(op, StencilOperator) and op.shape == H.shape
+    Hop = op.to_scipy()
+    assert (Hop != H).nnz == 0 and np.array_equal(Hop.indices, H.indices)
+    s0 = Lanczos(H)
+    s0.execute_Lanczos(n, seed=78)
+    s1 = Lanczos(op)
+    s1.execute_Lanczos(n, seed=78)
+    assert np.array_equal(s0.H_eff, s1.H_eff) and np.array_equal(s0.V, s1.V)
+    s3 = Lanczos(op)
+    s3.devices = [0, 0, 0]
+    s3.comm_backend = "host"
+    s3.execute_Lanczos(n, seed=78)
+    sH = Lanczos(H)
+    sH.devices = [0, 0, 0]
+    sH.comm_backend = "host"
+    sH.execute_Lanczos(n, seed=78)
+    assert np.array_equal(s3.H_eff, sH.H_eff) and np.array_equal(s3.V, sH.V)  # slab assembled on the device == slab cut from the host matrix
+    scale = np.abs(s0.H_eff).max()
+    assert np.abs(s3.H_eff - s0.H_eff).max() <= 1e-10 * scale
+    assert np.abs(s3.H_eigvals - s0.H_eigvals)[:4].max() <= 1e-10 * scale
+    for s in (s0, s1, s3, sH):
+        s.close()
+
+
+def test_bench_self_spawn_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` without a launcher: the parent (which never touches the GPU) spawns both ranks, rank 0
+    prints ONE JSON line - the plumbing the driver's first multi-GPU run will go through."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "host", "--device", "0", "--workload", "lap2d_5pt_M1e6_k100",
+           "--steps", "1", "--warmup", "1", "--prewarm-s", "0.1", "--arm-timeout", "600"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["comm"] == "host" and line["config"]["exchange"] == "halo"
+    assert line["comm_calls_per_step"] == 3 * 100 + 2  # (k + 1) exchanges + (k + 1) alpha all-reduces + k coefficient all-reduces
+    assert line["partial_reorth"] is not None and line["one_reduce_arm"] is not None  # both extra arms ran
+    assert "stalled" not in line and line["value"] > 0 and line["roofline"]["kernel"] in ("qtw", "update", "spmv")

@@ -88,7 +88,7 @@ WORKER = textwrap.dedent('''
         out[name] = dict(mode=s.plan.mode, da=float(np.abs(a - ao)[:prefix].max()), db=float(np.abs(bta - bo)[:max(prefix - 1, 1)].max()),
                          dth=float(np.abs(theta - th_o)[mask].max() / np.abs(th_o).max()), prefix=int(prefix), nmask=int(mask.sum()),
                          scale=float(max(np.abs(ao).max(), np.abs(bo).max())),
-                         dV=float(np.abs(V[:, :8] - Vo[:8, lo:hi].T).max()), dY=float(np.abs(Y - V @ S).max()),
+                         dV=float(np.abs(V[:, :8] - Vo[:8, lo:hi].T).max() / np.abs(Vo[:8]).max()), dY=float(np.abs(Y - V @ S).max()),
                          orth=float(np.abs(boot.allreduce_sum(V.T @ V) - np.eye(n)).max()),
                          comm_launches=comm_launches, sweeps=sweeps, n=n, device_built_equal=device_built_equal, dq=dq)
     res = boot.allgather_obj(out)
@@ -134,7 +134,8 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
             # short runs: 1e-11 absolute on every coefficient; the k = 200 / 500 runs: the north-star bar (1e-10 of the
             # spectral scale) on the stable prefix, whose end is by definition where coefficients start to move at 1e-12
             ctol = 1e-11 if r["n"] < 100 else 1e-10 * r["scale"]
-            assert r["da"] < ctol and r["db"] < ctol and r["dth"] < 1e-10 and r["dV"] < 1e-9 and r["dY"] < 1e-12, (name, r)
+            # dV: the first 8 basis vectors relative to their largest entry (1e-10, the same bar as the coefficients)
+            assert r["da"] < ctol and r["db"] < ctol and r["dth"] < 1e-10 and r["dV"] < 1e-10 and r["dY"] < 1e-12, (name, r)
             assert r["comm_launches"] > 0 and r["sweeps"] == r["n"] and r["orth"] < 1e-12, (name, r)
         # collectives per run: default (fused norm) = (n + 1) exchanges + (n + 1) alpha all-reduces + n coefficient
         # all-reduces; one-reduce = (n + 1) exchanges + n combined all-reduces + the last alpha

@@ -110,8 +110,10 @@ def test_c3_random_graph_full_size():
 
 def test_c4_lap3d_7pt_full_size():
     """C4: regular 3-D 7-point Laplacian, M = 1e8 (500 x 500 x 400), k = 200 - the whole 160 GB basis resident on ONE
-    MI355X (the 8-GPU form of this config splits the same rows into z-slabs; tests/test_gpu_distributed.py runs that
-    partition at reduced size).  No room for a second M x k array: orthonormality is checked on sampled basis rows."""
+    MI355X (the 8-GPU form of this config splits the same rows into z-slabs; tests/test_gpu_distributed.py and
+    tests/test_gpu_devices.py run that partition at reduced size).  There is no room for a second M x k array beside the
+    basis, so `get_H_eigs` / `H_eigvals` / `H_eigvecs` (Lanczos.py:145-163) run in the CHUNKED mode: the device keeps S and
+    re-forms Y = V S a few million rows at a time - for the Gram matrix of the two asserts, and for every fetch."""
     dims, n = (500, 500, 400), 200
     A = synthetic.laplacian_3d_7pt(*dims)
     H = A.to_scipy()
@@ -124,9 +126,21 @@ def test_c4_lap3d_7pt_full_size():
     H_eff = s.H_eff.copy()
     assert np.isfinite(H_eff).all() and np.array_equal(H_eff, H_eff.T)
     _prefix_against_oracle(H, H_eff, scale)
-    theta = np.linalg.eigvalsh(H_eff)
+    theta = s.H_eigvals  # lazily get_H_eigs(): eigh(H_eff), the chunked back-transform, both asserts on the device Gram matrix
+    assert np.array_equal(theta, np.linalg.eigvalsh(H_eff)) or np.abs(theta - np.linalg.eigvalsh(H_eff)).max() < 1e-13
     assert theta.min() > -1e-11 and theta.max() < 12 + 1e-11
     h = s._handle
+    info = h.ritz_info()
+    assert info["chunk_rows"] > 0 and info["chunk_rows"] % 16 == 0, info  # 160 GB + 160 GB do not fit: chunked
+    G = h.ritz_gram()  # accumulated chunk by chunk
+    assert np.abs(G - np.eye(n)).max() < 1e-12
+    # H_eigvecs on sampled row windows (start, middle across a chunk boundary, ragged end) against V S formed on the host
+    S = np.linalg.eigh(H_eff)[1]
+    c = info["chunk_rows"]
+    for lo, hi in ((0, 48), (c - 21, c + 43), (3 * c + 5, 3 * c + 37), (M - 40, M)):
+        Yw = s.H_eigvecs_rows(lo, hi)
+        Vw = s.V_rows(lo, hi)
+        assert Yw.shape == (hi - lo, n) and np.abs(Yw - Vw @ S).max() <= 1e-13
     rows = [0, 1, 2, 50, 101, 150, 198, 199]
     Vs = np.stack([h.basis_get_row(i) for i in rows])
     assert np.abs(Vs @ Vs.T - np.eye(len(rows))).max() < 1e-12

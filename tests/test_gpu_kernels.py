@@ -238,3 +238,29 @@ def test_reference_static_reorthogonalize(hip):
     c = np.sum(V[3] * V, axis=1)
     np.testing.assert_allclose(W[3], 2 * V[3] - np.sum(c[:, None] * V, axis=0), rtol=0, atol=1e-14)
     assert np.array_equal(np.delete(W, 3, 0), np.delete(V, 3, 0))
+
+
+def test_two_phase_layouts_of_different_size_coexist(hip):
+    """the dynamic-LDS limit of k_pb_products / k_pb_rows is a property of the KERNEL, shared by every layout in
+    the process.  It used to be set to each new layout's own need, so a later, smaller layout (H^T of a two-sided run, a
+    second handle) lowered it under the earlier one's launches.  Two layouts alive at once, the smaller built second; both
+    must keep multiplying (bit-identical to SciPy)."""
+    A1 = synthetic.random_graph_laplacian((1 << 20) + 4096, 3_600_000, seed=5)   # auto: two-phase, a full-LDS layout
+    A2 = synthetic.random_graph_laplacian(300_000, 1_000_000, seed=6)            # forced, with a small tile capacity
+    h1 = hip.Handle(0)
+    h1.set_csr(A1.shape[0], 0, A1.rowptr, A1.colidx, A1.vals)
+    assert h1.spmv_plan() == "two-phase"
+    x1 = np.random.default_rng(1).standard_normal(A1.shape[0])
+    y1 = A1.to_scipy() @ x1
+    assert np.array_equal(h1.spmv_host(x1), y1)
+    h2 = hip.Handle(0)
+    h2.set_tuning(14, 2)
+    h2.set_tuning(10, 3000)
+    h2.set_csr(A2.shape[0], 0, A2.rowptr, A2.colidx, A2.vals)
+    assert h2.spmv_plan() == "two-phase"
+    x2 = np.random.default_rng(2).standard_normal(A2.shape[0])
+    assert np.array_equal(h2.spmv_host(x2), A2.to_scipy() @ x2)
+    assert np.array_equal(h1.spmv_host(x1), y1)  # the first layout's launches still fit their kernel's limit
+    h2.close()
+    assert np.array_equal(h1.spmv_host(x1), y1)
+    h1.close()

@@ -62,7 +62,8 @@ def test_golden(name):
         # summation order; the vectors lose determinacy a few steps before the coefficients do)
         vrows = oracle.stable_basis_rows(H, n, d["V"], seed=seed, v0=v0)
         assert vrows >= min(prefix, 20) - 5 and vrows >= min(n, 10)
-        np.testing.assert_allclose(s.V[:, :vrows], d["V"][:vrows].T, rtol=0, atol=1e-9)
+        ref = d["V"][:vrows].T  # entries of size ~ 1 / sqrt(M): the bar is RELATIVE to the largest of them
+        assert np.abs(s.V[:, :vrows] - ref).max() <= 1e-10 * np.abs(ref).max()
     if "H_eigvecs_first3" in d:
         # Ritz vectors of the three lowest Ritz values against the reference's, sign-fixed.  A Ritz vector is only as well
         # determined as its Ritz value is isolated in T (sin(angle) ~ |dT| / gap), and - when the run outlives the stable
@@ -76,7 +77,9 @@ def test_golden(name):
                 continue
             y, yr = s.H_eigvecs[:, i], ref_Y[:, i]
             y = y * np.sign(y @ yr)
-            np.testing.assert_allclose(y, yr, rtol=0, atol=1e-9)
+            # sin(angle) ~ |dT| / gap: the bar scales with how isolated the Ritz value is (never looser than 1e-9 relative)
+            tol = min(1e-9, 1e-10 * max(1.0, 1e-2 * np.abs(ref_th).max() / gap)) * np.abs(yr).max()
+            assert np.abs(y - yr).max() <= tol, (i, np.abs(y - yr).max(), tol)
             compared += 1
         assert compared >= 1 or n <= 2
     # same checks get_H_eigs ran in the reference
@@ -131,7 +134,7 @@ def test_seeded_vs_oracle(build, n):
     theta = np.linalg.eigvalsh(oracle.build_h_eff(a, b))
     assert ritz_close(s.H_eigvals, theta)
     scale = max(np.abs(a).max(), np.abs(b).max())
-    assert np.abs(np.diag(s.H_eff) - a).max() <= 1e-9 * scale
+    assert np.abs(np.diag(s.H_eff) - a).max() <= 1e-10 * scale and np.abs(np.diag(s.H_eff, 1) - b).max() <= 1e-10 * scale
     # Lanczos invariants on the device result
     Vd = s.V
     assert np.abs(Vd.T @ Vd - np.eye(n)).max() < 1e-12
@@ -179,11 +182,12 @@ def test_error_surface_on_device():
 
 
 @pytest.mark.parametrize("flags", [2, 4, 16, 4 | 16, 32, 8, 16 | 256])
-def test_kernel_variants_agree(flags):
-    """16x16x4-MFMA (2) and VALU (4) Q^T w arms, fused-norm (16, also with VALU), generic CSR-stream (32) and scalar
-    SpMV (8) arms, and the one-all-reduce-per-iteration loop (256: pass 1 dots two columns at once, alpha and |r|^2
-    come out of the same reduced buffer) against the default path (4x4x4-MFMA Q^T w, fixed-K SpMV)."""
-    from lanczos_amd import _capi
+def test_kernel_variants_agree(flags, hip, kb):
+    """VALU (4) Q^T w arm, fused-norm (16, also with VALU), generic CSR-stream (32) and scalar SpMV (8) arms, and the
+    one-all-reduce-per-iteration loop (256: pass 1 dots two columns at once, alpha and |r|^2 come out of the same reduced
+    buffer) against the default path (4x4x4-MFMA Q^T w, fixed-K SpMV); the retired 16x16x4-MFMA Q^T w arm (2) in the
+    kernel-bench build."""
+    _capi = kb if flags == 2 else hip
 
     A = synthetic.laplacian_2d_5pt(300, 200)
     M = A.shape[0]
@@ -409,22 +413,64 @@ def test_breakdown_status_through_the_c_abi(hip):
     h.close()
 
 
-def test_ablation_knobs_are_rejected_by_the_product_library(hip):
+def test_ablation_knobs_are_rejected_by_the_product_library(hip, kb):
     h = hip.Handle(0)
-    for idx, val in [(1, 21), (1, 27), (1, 31), (1, 37), (3, 1), (3, 15), (16, 0), (-1, 0), (0, -5)]:
+    # timing-only ablations (1 >= 20, 3), out-of-range knobs, and the A/B arms retired in round 3: the one-kernel /
+    # one-launch-per-step engines (15 = 2, 3, 5), the persistent / LDS-staged / forced S-stationary Ritz GEMM arms (9 >= 2),
+    # the ticket / deferred-fold two-sided links (11 >= 2)
+    for idx, val in [(1, 21), (1, 27), (1, 31), (1, 37), (3, 1), (3, 15), (24, 0), (-1, 0), (0, -5),
+                     (15, 2), (15, 3), (15, 5), (9, 2), (9, 3), (9, 4), (9, 5), (9, 21), (11, 2), (11, 3)]:
         assert h.lib.lz_set_tuning(h._h, idx, val) == -1, (idx, val)  # LZ_ERR_ARG
     assert b"lz_set_tuning" in h.lib.lz_last_error(h._h)
-    for idx, val in [(1, 0), (1, 10), (1, 13), (8, 2), (7, 8), (13, 1), (13, 0)]:
+    for idx, val in [(1, 0), (1, 10), (1, 13), (8, 2), (7, 8), (13, 1), (13, 0), (15, 0), (15, 1), (9, 0), (9, 1), (11, 0), (11, 1), (16, 4096), (16, 0)]:
         assert h.lib.lz_set_tuning(h._h, idx, val) == 0, (idx, val)
+    assert h.lib.lz_set_options(h._h, hip.FLAG_QTW_MFMA) == -1 and b"retired" in h.lib.lz_last_error(h._h)  # the 16x16x4 Q^T w arm
+    assert h.lib.lz_set_options(h._h, hip.FLAG_QTW_VALU | hip.FLAG_FUSED_NORM) == 0  # (the VALU kernel is the fallback for > 5000 basis rows)
+    h.close()
+    k = kb.Handle(0)  # the kernel-bench build still takes them
+    for idx, val in [(15, 2), (15, 5), (9, 3), (11, 3), (1, 21)]:
+        assert k.lib.lz_set_tuning(k._h, idx, val) == 0, (idx, val)
+    assert k.lib.lz_set_options(k._h, hip.FLAG_QTW_MFMA) == 0
+    k.close()
+
+
+def _ritz_case(H_handle, dims, n):
+    A = synthetic.laplacian_2d_5pt(*dims)
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    h = H_handle
+    h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    a, b = h.run(n, v0)
+    V = h.get_basis()
+    T = np.diag(a) + np.diag(b, 1) + np.diag(b, -1)
+    S = np.linalg.eigh(T)[1]
+    return V, S
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("dims,n", [((300, 250), 50), ((512, 256), 200), ((331, 211), 197)])
+def test_retired_ritz_gemm_arms_in_the_kernel_bench_build(kb, variant, dims, n):
+    """2: the 32-row tile walked by persistent waves; 3: two waves per SIMD with 16-row tiles, S staged through LDS; 4: one wave
+    per SIMD, 32-row tiles, S through LDS - measured slower than the defaults, kept correct."""
+    h = kb.Handle(0)
+    h.set_tuning(9, variant)
+    V, S = _ritz_case(h, dims, n)
+    np.testing.assert_allclose(h.ritz_vectors(S), V.T @ S, rtol=0, atol=1e-13)
     h.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
-@pytest.mark.parametrize("dims,n", [((300, 250), 50), ((331, 211), 37), ((512, 256), 200), ((331, 211), 197), ((331, 211), 193)])
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("dims,n", [((300, 250), 50), ((331, 211), 37), ((512, 256), 200), ((331, 211), 197), ((331, 211), 193),
+                                    ((300, 250), 49), ((300, 250), 64), ((300, 250), 65), ((300, 250), 100), ((331, 211), 111),
+                                    ((300, 250), 150), ((331, 211), 192), ((300, 250), 201), ((300, 250), 126), ((257, 256), 178),
+                                    ((300, 250), 80), ((300, 250), 85), ((300, 250), 96), ((300, 250), 117), ((300, 250), 133),
+                                    ((300, 250), 141), ((300, 250), 158), ((300, 250), 165), ((300, 250), 173)])
 def test_ritz_backtransform_kernels(hip, variant, dims, n):
-    """Y = V S (Lanczos.py:153-156) by the FP64-MFMA kernels - 0: automatic choice (5 where it applies, else 1); 1: one workgroup per 128 rows, one wave per SIMD with a
-    32-row x n tile; 2: the same tile walked by persistent waves; 3: persistent, two waves per SIMD with 16-row
-    tiles, S staged through LDS; 4: persistent, one wave per SIMD with a 32-row tile, S through LDS; 5: S held in registers, 16-row tiles of V through LDS (n in 193..200) - against NumPy on the fetched basis, ragged row and column counts included."""
+    """Y = V S (Lanczos.py:153-156) by the FP64-MFMA kernels - 0: automatic choice: the S-stationary kernel (S held in
+    registers, 16-row tiles of V through LDS) for every 49 <= n <= 200 - each (column tiles, k-steps) instantiation is hit
+    by some case here - else the Y-stationary one; 1: the Y-stationary kernel always (one workgroup per 128 rows, one wave
+    per SIMD with a 32-row x n tile) - against NumPy on the fetched basis, ragged row and column counts included."""
     A = synthetic.laplacian_2d_5pt(*dims)
     M = A.shape[0]
     v0 = synthetic.reference_start_vector(M)
@@ -440,4 +486,93 @@ def test_ritz_backtransform_kernels(hip, variant, dims, n):
     np.testing.assert_allclose(Y, V.T @ S, rtol=0, atol=1e-13)
     G = h.ritz_gram()
     assert np.abs(G - np.eye(n)).max() < 1e-12
+    info = h.ritz_info()
+    assert info["chunk_rows"] == 0
+    if variant == 0 and 49 <= n <= 200:  # the S-stationary kernel ran and left its clock record
+        assert info["tiles"] > 0 and 500 < info["clock_mhz"] < 3000 and info["cycles_per_tile"] >= info["mfma_floor_cycles_per_tile"] > 0, info
+    else:
+        assert info["tiles"] == 0
+    # the same vectors re-formed in row chunks (what BASELINE C4 needs on one GPU: no room for a second M x n array)
+    h.set_tuning(16, 20000)
+    h.ritz_vectors(S, fetch=False)
+    assert h.ritz_info()["chunk_rows"] == 20000
+    np.testing.assert_allclose(h.ritz_fetch(), Y, rtol=0, atol=1e-13)
+    lo, hi = 19993, 40011  # a window across a chunk boundary, not tile aligned
+    np.testing.assert_allclose(h.ritz_fetch_rows(lo, hi), Y[lo:hi], rtol=0, atol=1e-13)
+    Gc = h.ritz_gram()
+    assert np.abs(Gc - G).max() < 1e-13
+    q_chunked = h.ritz_quality()
+    h.set_tuning(16, 0)
+    h.ritz_vectors(S, fetch=False)
+    assert np.abs(q_chunked - h.ritz_quality()).max() <= 1e-12
     h.close()
+
+
+def test_matrix_stays_on_the_device_across_calls_and_use_cuda_false_runs_the_hip_path(capsys):
+    """(a) `execute_Lanczos(400, use_cuda=False, seed=78)` is how the reference's largest script calls the solver
+    (3Ddeuteron.py:95): accepted unedited - one notice line, then the HIP path, held to the reference's NumPy output of the
+    same call (golden fixture) at the north-star bar.  (b) A second call on the same object repacks / uploads nothing while
+    H's content hash is unchanged (C3 paid ~1 GB H2D + a 2.6 GB layout build per call); an in-place edit of H is seen."""
+    d, H = load_golden("deuteron3d_N12_27pt_n100")
+    n = int(d["n"])
+    Lanczos.verbose = False
+    s = Lanczos(H)
+    s.execute_Lanczos(n, use_cuda=False, seed=int(d["seed"]))
+    assert "use_cuda=False: lanczos_amd has no NumPy path; running the HIP path" in capsys.readouterr().out
+    prefix, mask = oracle.stable_masks(H, n, d["alpha"], d["beta"], seed=int(d["seed"]))
+    scale = max(np.abs(d["alpha"]).max(), np.abs(d["beta"]).max())
+    assert np.abs(np.diag(s.H_eff) - d["alpha"])[:prefix].max() <= 1e-10 * scale
+    conv = oracle.converged_ritz(d["alpha"], d["beta"])
+    assert np.abs(s.H_eigvals[None, :] - conv[:, None]).min(axis=1).max() <= RTOL * np.abs(d["H_eigvals"]).max()
+    assert s._handle.matrix_uploads == 1
+    H_eff1 = s.H_eff.copy()
+    s.execute_Lanczos(n, seed=int(d["seed"]))  # self.H is now the CSR the first call published (Lanczos.py:137): same arrays, same hash
+    assert s._handle.matrix_uploads == 1 and np.array_equal(H_eff1, s.H_eff)
+    s.H.data[3] += 0.5  # edited in place: the hash moves, the matrix goes up again
+    s.execute_Lanczos(12, seed=1)
+    assert s._handle.matrix_uploads == 2 and not np.array_equal(s.H_eff, H_eff1[:12, :12])
+    s.strict_use_cuda = True
+    with pytest.raises(NotImplementedError, match="device path only"):
+        s.execute_Lanczos(12, use_cuda=False)
+    # a dense ndarray stays the resident dense operator although self.H becomes a CSR copy after the first call
+    A = synthetic.dense_symmetric(512, seed=0)
+    t = Lanczos(A)
+    t.execute_Lanczos(20)
+    He = t.H_eff.copy()
+    assert t._handle.spmv_plan() == "dense" and t._handle.matrix_uploads == 1
+    t.execute_Lanczos(20)
+    assert t._handle.spmv_plan() == "dense" and t._handle.matrix_uploads == 1 and np.array_equal(He, t.H_eff)
+    t.cache_matrix = False
+    t.execute_Lanczos(20)
+    assert t._handle.matrix_uploads == 2
+
+
+def test_one_reduce_cancellation_guard(hip):
+    """LZ_FLAG_ONE_REDUCE forms |r|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u, whose relative error grows like
+    eps (alpha^2 + beta^2) / beta^2.  On a strongly shifted operator (|alpha| ~ 1e4 >> beta ~ 2: the three sums
+    cancel to 1e-8 of their size) the guard in k_onereduce_prepare fires and lz_run repeats the solve on the default loop:
+    no NaN, no silent loss of the 1e-10 bar - and lz_last_engine says so.  Unshifted: the one-reduce loop itself runs."""
+    import scipy.sparse
+
+    A = synthetic.laplacian_2d_5pt(120, 100).to_scipy()
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    for shift, engine in ((0.0, "one-reduce"), (1.0e4, "one-reduce-repeated")):
+        H = (A + shift * scipy.sparse.identity(M, format="csr")).tocsr()
+        H.sort_indices()
+        out = []
+        for flags in (hip.FLAG_FUSED_NORM, hip.FLAG_FUSED_NORM | hip.FLAG_ONE_REDUCE):
+            h = hip.Handle(0)
+            h.set_options(flags)
+            h.set_csr(M, 0, H.indptr, H.indices, H.data)
+            a, b = h.run(40, v0)
+            out.append((a, b, h.last_engine(), h.breakdown))
+            h.close()
+        (a0, b0, e0, bd0), (a1, b1, e1, bd1) = out
+        assert e1 == engine and e0 in ("three-term-fused", "fused") and not bd0 and not bd1
+        assert np.isfinite(a1).all() and np.isfinite(b1).all() and b1.min() > 0
+        if engine == "one-reduce-repeated":
+            assert np.array_equal(a0, a1) and np.array_equal(b0, b1)  # the repeat IS the default loop
+        else:
+            assert np.abs(a1 - a0).max() < 1e-11 and np.abs(b1 - b0).max() < 1e-11

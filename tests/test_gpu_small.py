@@ -1,7 +1,9 @@
-"""The small-problem engine (lanczos_amd/csrc/lz_small.hip): the whole run as ONE cooperative kernel for the sizes of the
-reference's own scripts (1Dbox.py N = 500, 1Ddeuteron.py N = n = 1001) and BASELINE config C1 (dense 512, k = 20).
-It reproduces the multi-kernel path BIT FOR BIT (same reduction trees, same MFMA sequence, same element-wise
-arithmetic); it is opt-in because on MI355X it is not faster (the printed timings)."""
+"""Loop structures for the sizes of the reference's own scripts (1Dbox.py N = 500, 1Ddeuteron.py N = n = 1001) and BASELINE
+config C1 (dense 512, k = 20).  Product library: the fused three-launch path (small problems) and the five-launch loop
+(mid-size), each BIT FOR BIT equal to the plain six-launch loop.  Kernel-bench build (fixture `kb`,
+liblanczos_kbench.so): the two RETIRED engines - the whole run as one cooperative kernel (lz_small.hip) and one launch per
+step - which reproduce the same bits (same reduction trees, same MFMA sequence, same element-wise arithmetic) but
+measured no faster on MI355X (the printed timings), so they left the product in round 3."""
 import time
 
 import numpy as np
@@ -54,10 +56,10 @@ def _run(hip, H, n, engine_off, flags=None, knob=None):
 
 
 @pytest.mark.parametrize("name", list(_cases()))
-def test_engine_is_bit_identical_to_the_kernel_path(hip, name):
+def test_engine_is_bit_identical_to_the_kernel_path(hip, kb, name):
     H, n = _cases()[name]
-    a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True)
-    a0, b0, V0, e0, t0 = _run(hip, H, n, engine_off=False)
+    a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True)   # product library, plain six-launch loop
+    a0, b0, V0, e0, t0 = _run(kb, H, n, engine_off=False)   # kernel-bench build, one-kernel engine
     assert e1 == "kernels" and e0 == "small"
     assert np.array_equal(a0, a1) and np.array_equal(b0, b1), (np.abs(a0 - a1).max(), np.abs(b0 - b1).max())
     assert np.array_equal(V0, V1), np.abs(V0 - V1).max()
@@ -87,14 +89,14 @@ def test_fused_launch_path_is_bit_identical_and_faster(hip, name):
 
 
 @pytest.mark.parametrize("name", list(_fused_cases()))
-def test_step_kernels_are_bit_identical(hip, name):
+def test_step_kernels_are_bit_identical(hip, kb, name):
     """A/B arm (tuning knob 15 = 5; padded rows <= 1280, n <= 64, short CSR rows or dense): ONE launch per step - every block
     redoes the vector work of the step and multiplies its share of the rows - against the plain six-launch path: same bits
     (and slower than the default three-launch path: the printed timings are the record).  Where the conditions do not hold
     the knob falls back to the fused-launch path."""
     H, n = _fused_cases()[name]
     a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True, knob=1)
-    a0, b0, V0, e0, t0 = _run(hip, H, n, engine_off=False, knob=5)
+    a0, b0, V0, e0, t0 = _run(kb, H, n, engine_off=False, knob=5)
     M = H.shape[0]
     import scipy.sparse
     long_rows = scipy.sparse.issparse(H) and np.diff(H.tocsr().indptr).max() > 32
@@ -128,12 +130,12 @@ def test_three_term_fused_loop_is_bit_identical(hip, name):
     print(f"\n[three-term-fused] {name}: six launches {1e3 * t1:.3f} ms, five launches {1e3 * t0:.3f} ms, x{t1 / t0:.2f}")
 
 
-def test_device_scope_arm_is_bit_identical_too(hip):
+def test_device_scope_arm_is_bit_identical_too(hip, kb):
     """tuning knob 15 = 3: the same kernel on a plain grid with device-scope coherence (what it costs when the blocks do
     NOT share an XCD) - an A/B arm, same bits."""
     H, n = _cases()["c1_dense512_k20"]
     a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True)
-    h = hip.Handle(0)
+    h = kb.Handle(0)
     h.set_options(hip.FLAG_FUSED_NORM)
     h.set_tuning(15, 3)
     h.set_dense(H)
@@ -144,19 +146,24 @@ def test_device_scope_arm_is_bit_identical_too(hip):
     h.close()
 
 
-def test_engine_is_not_used_where_it_does_not_apply(hip):
+def test_loop_selection(hip, kb):
+    """choose_loop (lz_api.hip) through lz_last_engine: the product library knows three loops + one-reduce; the retired
+    engines answer only in the kernel-bench build, and only where they apply."""
     rag = load_golden("ragged_M700_n25")[1]  # a 700-entry row: one lane per row would be a chain of dependent loads
-    assert _run(hip, rag, 25, engine_off=False)[3] == "kernels"
+    assert _run(kb, rag, 25, engine_off=False)[3] == "kernels"
     H = synthetic.laplacian_2d_5pt(40, 40).to_scipy()  # 1600 rows > 1280
-    assert _run(hip, H, 10, engine_off=False)[3] == "kernels"
+    assert _run(kb, H, 10, engine_off=False)[3] == "kernels"
     Hs = synthetic.laplacian_2d_5pt(20, 20).to_scipy()
-    assert _run(hip, Hs, 10, engine_off=False, flags=0)[3] == "kernels"  # not fused-norm mode
-    assert _run(hip, Hs, 10, engine_off=True)[3] == "kernels"  # knob 15 = 1: the plain path
-    assert _run(hip, Hs, 10, engine_off=False, knob=0)[3] == "fused"  # the default for small problems
-    assert _run(hip, Hs, 10, engine_off=False, knob=5)[3] == "step"  # the one-launch-per-step arm
-    assert _run(hip, synthetic.laplacian_2d_5pt(80, 80).to_scipy(), 10, engine_off=False, knob=0)[3] == "three-term-fused"  # 6400 rows: 13 slices
-    assert _run(hip, Hs, 10, engine_off=False, flags=hip.FLAG_FUSED_NORM | hip.FLAG_REORTH_PARTIAL)[3] == "kernels"
-    assert _run(hip, Hs, 10, engine_off=False)[3] == "small"
+    assert _run(kb, Hs, 10, engine_off=False, flags=0)[3] == "kernels"  # not fused-norm mode
+    assert _run(kb, Hs, 10, engine_off=False, knob=5)[3] == "step"  # the one-launch-per-step arm
+    assert _run(kb, Hs, 10, engine_off=False, flags=hip.FLAG_FUSED_NORM | hip.FLAG_REORTH_PARTIAL)[3] == "kernels"
+    assert _run(kb, Hs, 10, engine_off=False)[3] == "small"
+    for lib in (hip, kb):
+        assert _run(lib, Hs, 10, engine_off=True)[3] == "kernels"  # knob 15 = 1: the plain path
+        assert _run(lib, Hs, 10, engine_off=False, knob=0)[3] == "fused"  # the default for small problems
+        assert _run(lib, Hs, 10, engine_off=False, knob=0, flags=0)[3] == "kernels"  # reference order (scale, then dot): plain loop
+        assert _run(lib, synthetic.laplacian_2d_5pt(80, 80).to_scipy(), 10, engine_off=False, knob=0)[3] == "three-term-fused"  # 6400 rows: 13 slices
+        assert _run(lib, Hs, 10, engine_off=False, knob=0, flags=hip.FLAG_FUSED_NORM | hip.FLAG_ONE_REDUCE)[3] == "one-reduce"
 
 
 def test_drop_in_class_on_the_reference_scripts_sizes():

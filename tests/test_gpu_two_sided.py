@@ -154,7 +154,7 @@ def test_run_to_run_bit_reproducibility_and_handle_reuse():
 @pytest.mark.parametrize("build,n", [(lambda: synthetic.random_graph_laplacian(5000, 17000, seed=2).to_scipy(), 14),
                                      (lambda: synthetic.laplacian_2d_5pt(300, 300).to_scipy(), 20),
                                      (lambda: synthetic.laplacian_2d_5pt(1000, 700).to_scipy(), 10)])
-def test_deferred_fold_links_are_bit_identical(build, n):
+def test_deferred_fold_links_are_bit_identical(build, n, kb):
     """A/B arm of the Gram-Schmidt links (tuning knob 11 = 3: one launch each, the fold of a link's four sums rides in the next
     link's prologue, in the fold kernel's own order) against the default two-launch links: identical H_eff and bases; timed
     (device time) - the arm measured 0.81-0.92x, which is why it is not the default."""
@@ -163,6 +163,9 @@ def test_deferred_fold_links_are_bit_identical(build, n):
     out = []
     for knob in (0, 3):
         s = IrrLanczos(A)
+        if knob:  # the retired arm lives in the kernel-bench build: this object's handle is created on that library
+            s._handle = kb.Handle(0)
+            s._handle_devices = ((0,), s.comm_backend)
         s.execute_Lanczos(3, seed=4)  # creates the handle (and loads the code objects)
         s._handle.set_tuning(11, knob)
         s.execute_Lanczos(n, seed=4)
