@@ -359,6 +359,110 @@ __global__ __launch_bounds__(NA == 2 ? 256 : 512) void k_gemm_tn_lds(const doubl
 
 #endif  // LZ_KBENCH
 
+// Ritz back-transform for n <= 128: S RESIDENT IN LDS, Y-stationary waves, no barrier after the prologue.
+// Why a third kernel.  The S-stationary kernel pays ~1400 cycles per 16-row tile for its barrier, partial-tile hand-over and
+// ring refill whatever n is (measured in round 3: 11 874 cycles per tile against an MFMA floor of 10 400 at n = 200, but 4 286
+// against 2 912 at n = 100 - 0.68 in cycles, 0.49 of peak at BASELINE C2).  For n <= 128 the whole of S (<= 128 KB) fits the
+// CU's LDS, so nothing has to be staged, handed over or synchronised: every wave owns whole 16-row tiles of Y (NT
+// accumulators), streams its own V fragments from HBM through a register ring that runs across tile boundaries, and reads
+// its B operands out of LDS - stored in MFMA-fragment order (the fragment of k-step t and column tile b is 64 consecutive
+// doubles: conflict-free ds_read_b64), one LDS read per MFMA, fetched one k-step ahead.  WPS waves per SIMD hide each
+// other's memory instructions (with one wave per SIMD every vector-memory instruction costs ~165 cycles of MFMA issue,
+// DESIGN.md section 4).  S is zero-padded to 4 KS rows, so the padding k-steps and the ragged last column tile add zeros.
+template <int NT, int KS, int WPS>
+__global__ __launch_bounds__(256 * WPS) void k_gemm_tn_sl(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
+                                                         const double* __restrict__ B, int64_t ldb, int ncols,
+                                                         double* __restrict__ C, int64_t ldc, unsigned long long* __restrict__ clk) {
+  constexpr int NW = 4 * WPS;  // waves per workgroup
+  constexpr int PA = 8;        // V fragments in flight per wave (k-steps ahead)
+  extern __shared__ double sS[];  // [KS][NT][64]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int f = w; f < KS * NT; f += NW) {  // fragment f = (t, b): S[4 t + lk][16 b + lr] (rows / columns inside the padded S)
+    const int t = f / NT, b = f - t * NT;
+    sS[f * 64 + lane] = B[(int64_t)(4 * t + lk) * ldb + 16 * b + lr];
+  }
+  const bool rec = clk != nullptr && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(w) == 0;
+  uint64_t c0 = 0, t0 = 0;
+  if (rec) {
+    c0 = clock64();
+    t0 = wall_clock64();
+  }
+  __syncthreads();
+  const int64_t ntiles = (mdim + 15) / 16;
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
+  const int64_t wave = (int64_t)blockIdx.x * NW + w;
+  // V cursor: (tile, k-step) of the next fragment to request; runs ahead of the MFMAs, across tile boundaries
+  int64_t pt = wave;
+  int ps = 0;
+  auto issue_a = [&](double& x) {
+    const int64_t t = pt < ntiles ? pt : ntiles - 1;  // past the last tile: a valid address, never used
+    int64_t m = t * 16 + lr;
+    m = m < mdim ? m : mdim - 1;                       // rows past the end: finite values, results not stored
+    int kr = 4 * ps + lk;
+    kr = kr < kcount ? kr : kcount - 1;                // padding k-steps: finite values times the zero rows of S
+    x = __builtin_nontemporal_load(A + (int64_t)kr * lda + m);
+    if (++ps == KS) {
+      ps = 0;
+      pt += nwaves;
+    }
+  };
+  double ra[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) issue_a(ra[p]);
+  int64_t mytiles = 0;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves, ++mytiles) {
+    double4_t acc[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double bcur[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bcur[b] = sS[b * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const double a = ra[t % PA];
+      issue_a(ra[t % PA]);
+      double bnxt[NT];
+      if (t + 1 < KS) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bnxt[b] = sS[((t + 1) * NT + b) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one k-step of operands in flight, not all KS of them (the loop is fully unrolled)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[b], acc[b], 0, 0, 0);
+      if (t + 1 < KS) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bcur[b] = bnxt[b];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // results: D[row = lk + 4 g][col = lr] of column tile b
+    const int64_t m0 = tile * 16;
+    double* cb = C + (m0 + lk) * ldc + lr;
+    if (m0 + 16 <= mdim) {  // wave-uniform: only the very last tile can be ragged in rows
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        if (16 * b + lr < ncols) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) __builtin_nontemporal_store(acc[b][g], cb + (int64_t)(4 * g) * ldc + 16 * b);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (16 * b + lr < ncols && m0 + lk + 4 * g < mdim) cb[(int64_t)(4 * g) * ldc + 16 * b] = acc[b][g];
+    }
+  }
+  if (rec) {
+    clk[0] = clock64() - c0;
+    clk[1] = wall_clock64() - t0;
+    clk[2] = (unsigned long long)mytiles;
+    clk[3] = (unsigned long long)(NT * KS * NW);  // MFMAs per "tile slot" over the four SIMDs: NW waves each do NT KS per tile they own
+  }
+}
+
 // Ritz back-transform, S-STATIONARY kernel (variant 5; n in 193..208): S lives in registers, V streams through LDS.
 // Why.  The kernels above keep a tile of Y in the accumulators and re-read S every k-step: 13 operand fetches per 26 MFMAs,
 // and the MFMA stream with that fetch is what takes the time (15.5 of 16.1 ms).  Turned around, the
@@ -608,8 +712,43 @@ static hipError_t launch_sreg(const double* V, int64_t ldv, int64_t rows, int n,
   return hipSuccess;
 }
 
-// The S-stationary kernel covers 49 <= n <= 200: NT = ceil(n / 16) column tiles (4..13) and KS = ceil(n / 4) k-steps
-// rounded up to even (the two waves of a SIMD split them in halves); S is zero-padded to 16 NT rows and columns.
+// S-in-LDS launcher (n <= 128)
+template <int NT, int KS, int WPS>
+static hipError_t launch_sl(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
+                            hipStream_t s, unsigned long long* clk) {
+  constexpr size_t lds = (size_t)KS * NT * 64 * sizeof(double);
+  static hipError_t attr = hipErrorNotReady;
+  if (attr == hipErrorNotReady)
+    attr = lds > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_sl<NT, KS, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                       : hipSuccess;
+  if (attr != hipSuccess) return attr;
+  const int64_t ntiles = (rows + 15) / 16;
+  const int grid = (int)std::min<int64_t>(kNumCU, (ntiles + 4 * WPS - 1) / (4 * WPS));
+  hipLaunchKernelGGL((k_gemm_tn_sl<NT, KS, WPS>), dim3(grid), dim3(256 * WPS), lds, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy, clk);
+  return hipSuccess;
+}
+
+template <int WPS>
+static bool sl_dispatch(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
+                        hipStream_t s, unsigned long long* clk, hipError_t* err) {
+  const int NT = (n + 15) / 16;
+  const int KS = (((n + 3) / 4) + 1) & ~1;
+#define LZ_SL(nt, ks)                                                                    \
+  if (NT == nt && KS == ks) {                                                            \
+    *err = launch_sl<nt, ks, WPS>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk);           \
+    return true;                                                                         \
+  }
+  LZ_SL(1, 2) LZ_SL(1, 4) LZ_SL(2, 6) LZ_SL(2, 8) LZ_SL(3, 10) LZ_SL(3, 12) LZ_SL(4, 14) LZ_SL(4, 16)
+  if constexpr (WPS == 2) {  // (four waves per SIMD have 128 registers each: enough for <= 4 column tiles only)
+    LZ_SL(5, 18) LZ_SL(5, 20) LZ_SL(6, 22) LZ_SL(6, 24) LZ_SL(7, 26) LZ_SL(7, 28) LZ_SL(8, 30) LZ_SL(8, 32)
+  }
+#undef LZ_SL
+  return false;
+}
+
+// The S-stationary kernel covers 129 <= n <= 200 (below that S fits the LDS: k_gemm_tn_sl): NT = ceil(n / 16) column tiles
+// (9..13) and KS = ceil(n / 4) k-steps rounded up to even (the two waves of a SIMD split them in halves); S is zero-padded
+// to 16 NT rows and columns.
 static bool sreg_dispatch(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
                           hipStream_t s, unsigned long long* clk, hipError_t* err) {
   const int NT = (n + 15) / 16;
@@ -619,7 +758,6 @@ static bool sreg_dispatch(const double* V, int64_t ldv, int64_t rows, int n, con
     *err = launch_sreg<nt, ks>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk);            \
     return true;                                                                       \
   }
-  LZ_SR(4, 14) LZ_SR(4, 16) LZ_SR(5, 18) LZ_SR(5, 20) LZ_SR(6, 22) LZ_SR(6, 24) LZ_SR(7, 26) LZ_SR(7, 28) LZ_SR(8, 30) LZ_SR(8, 32)
   LZ_SR(9, 34) LZ_SR(9, 36) LZ_SR(10, 38) LZ_SR(10, 40) LZ_SR(11, 42) LZ_SR(11, 44) LZ_SR(12, 46) LZ_SR(12, 48) LZ_SR(13, 50)
 #undef LZ_SR
   return false;
@@ -712,13 +850,21 @@ static bool kbench_ritz_arm(const double* V, int64_t ldv, int64_t rows, int n, c
 hipError_t launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
                             int64_t ldy, hipStream_t s, int variant, unsigned long long* clk) {
   const int64_t ntiles = (rows + 31) / 32;
-  // 0 (auto): the S-stationary kernel where it applies (49 <= n <= 200, enough row tiles for a persistent grid, 16-byte
-  // aligned rows), else one workgroup per 128 rows; 1 forces the latter
-  const bool sreg_ok = n > 48 && n <= 200 && (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 && npad >= 16 * ((n + 15) / 16) &&
+  // 0 (auto): n <= 128 and at least 4096 rows: S resident in LDS (k_gemm_tn_sl; 6 = the same with four waves per SIMD);
+  // 129 <= n <= 200: the S-stationary kernel where it applies (enough row tiles for a persistent grid, 16-byte aligned
+  // rows); else one workgroup per 128 rows.  1 forces the latter.
+  const bool sreg_ok = n > 128 && n <= 200 && (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 && npad >= 16 * ((n + 15) / 16) &&
                        ntiles >= 2 * kNumCU * (kTPB / 64);
+  const bool sl_ok = n <= 128 && rows >= 4096 && npad >= 16 * ((n + 15) / 16);
 #ifdef LZ_KBENCH
   if (hipError_t e; kbench_ritz_arm(V, ldv, rows, n, Spad, npad, Y, ldy, s, variant, &e)) return e;
 #endif
+  if (variant != 1 && sl_ok) {
+    hipError_t e = hipSuccess;
+    if (variant == 6 && n <= 64 ? sl_dispatch<4>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e)
+                                : sl_dispatch<2>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e))
+      return e;
+  }
   if (variant != 1 && sreg_ok) {
     hipError_t e = hipSuccess;
     if (sreg_dispatch(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e)) return e;
