@@ -225,9 +225,10 @@ int lz_get_ritz_rows(lz_handle h, int64_t row0, int64_t nrows, double* Y_out);
  * S and a buffer of that many rows, and lz_get_ritz_rows / lz_get_ritz_vectors / lz_ritz_gram / lz_ritz_quality re-form the
  * rows (or column batches) they need from the basis: a 16-row tile of Y depends only on the same 16 columns of V.
  * lz_set_tuning(h, 16, rows) forces the chunked mode (tests).
- * clock4 (may be NULL; zeros unless the S-stationary kernel ran): {shader clock in MHz while the kernel ran (s_memtime
- * cycles / s_memrealtime ticks of the constant 100 MHz counter, one workgroup's whole trip), shader cycles per 16-row
- * tile, the MFMA issue floor in cycles per tile (MFMAs per tile and SIMD x 64), tiles walked by that workgroup}. */
+ * clock4 (may be NULL; zeros unless one of the persistent kernels ran - n <= 200 with enough rows): {shader clock in MHz while
+ * the kernel ran (s_memtime cycles / s_memrealtime ticks of the constant 100 MHz counter over workgroup 0's trip), shader
+ * cycles workgroup 0 needed per 16-row tile of one of its waves, the MFMA issue floor for that in cycles (MFMAs per tile
+ * and SIMD x 64), 16-row tiles walked by that wave}. */
 int lz_ritz_info(lz_handle h, int64_t* chunk_rows, double* clock4);
 /* Device-side versions of the two checks get_H_eigs runs on Y (Lanczos.py:157-158,
  * 288-323): column norms (n) and the (n, n) Gram matrix Y^T Y, computed on the

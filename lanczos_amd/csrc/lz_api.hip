@@ -2046,8 +2046,10 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
     LZ_TRY(dev_alloc(h, h->d_S, Sp.size() + 64));
     h->s_npad = npad;
   }
-  if (!h->d_rclk) LZ_TRY(dev_alloc(h, h->d_rclk, 8));
-  LZ_HIP(h, hipMemsetAsync(h->d_rclk, 0, 8 * sizeof(uint64_t), h->stream));
+  if (!h->d_rclk) LZ_TRY(dev_alloc(h, h->d_rclk, 8 + 256));
+  LZ_HIP(h, hipMemsetAsync(h->d_rclk, 0, (8 + 256) * sizeof(uint64_t), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_rclk + 4, 0xFF, sizeof(uint64_t), h->stream));  // [4], [6]: min over waves of their entry tick
+  LZ_HIP(h, hipMemsetAsync(h->d_rclk + 6, 0xFF, sizeof(uint64_t), h->stream));
   LZ_HIP(h, hipMemcpyAsync(h->d_S, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));  // Sp is a local
   // Resident when all of Y fits beside the basis (with 1 GiB to spare for the Gram partials and the runtime), else chunked.
@@ -2141,8 +2143,24 @@ int lz_ritz_info(lz_handle h, int64_t* chunk_rows, double* clock4) {
     // [0] shader cycles, [1] ticks of the constant 100 MHz counter, [2] 16-row tiles, [3] MFMAs per tile and SIMD (x 64 = issue floor)
     clock4[0] = c[1] ? 100.0 * (double)c[0] / (double)c[1] : 0.0;  // shader clock in MHz while the kernel ran
     clock4[1] = c[2] ? (double)c[0] / (double)c[2] : 0.0;          // shader cycles per 16-row tile
+    // S-in-LDS kernels: the waves of a SIMD are not in lockstep (the oldest wins the issue arbitration and finishes early), so
+    // the honest figure is workgroup 0's whole span (first wave in .. last wave out, S staging included) at the measured clock
+    if (c[7] > c[6] && c[6] != 0 && c[6] != ~0ull && c[2]) clock4[1] = (double)(c[7] - c[6]) * clock4[0] / 100.0 / (double)c[2];
     clock4[2] = (double)c[3] / 4.0 * 64.0;                         // MFMA issue floor per tile: (MFMAs per tile / 4 SIMDs) x 64 cycles; c[3] holds 4x the per-SIMD count
     clock4[3] = (double)c[2];
+    if (getenv("LZ_DEBUG_TIMING") && c[5] > c[4] && c[4] != ~0ull) {
+      fprintf(stderr, "[lz_ritz_info] kernel-internal span (first wave in .. last wave out) %.1f us; wave 0's tile loop %.1f us\n",
+              (double)(c[5] - c[4]) * 0.01, (double)c[1] * 0.01);
+      std::vector<uint64_t> wg(256);
+      if (hipMemcpy(wg.data(), h->d_rclk + 8, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
+        fprintf(stderr, "[lz_ritz_info] workgroup exit times (us after the first wave in), by workgroup id:");
+        for (int i = 0; i < 256; ++i) {
+          if (i % 16 == 0) fprintf(stderr, "\n   ");
+          fprintf(stderr, " %6.1f", wg[i] > c[4] ? (double)(wg[i] - c[4]) * 0.01 : -1.0);
+        }
+        fprintf(stderr, "\n");
+      }
+    }
   }
   return LZ_OK;
 }

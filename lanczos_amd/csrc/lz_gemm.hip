@@ -374,13 +374,32 @@ __global__ __launch_bounds__(256 * WPS) void k_gemm_tn_sl(const double* __restri
                                                          const double* __restrict__ B, int64_t ldb, int ncols,
                                                          double* __restrict__ C, int64_t ldc, unsigned long long* __restrict__ clk) {
   constexpr int NW = 4 * WPS;  // waves per workgroup
-  constexpr int PA = 8;        // V fragments in flight per wave (k-steps ahead)
+  constexpr int PA = NT <= 7 ? 16 : 8;  // V fragments in flight per wave (k-steps ahead; 8 where the accumulators leave no room)
   extern __shared__ double sS[];  // [KS][NT][64]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
-  for (int f = w; f < KS * NT; f += NW) {  // fragment f = (t, b): S[4 t + lk][16 b + lr] (rows / columns inside the padded S)
-    const int t = f / NT, b = f - t * NT;
-    sS[f * 64 + lane] = B[(int64_t)(4 * t + lk) * ldb + 16 * b + lr];
+  if (clk != nullptr && lane == 0) {
+    const unsigned long long now = wall_clock64();
+    atomicMin(clk + 4, now);                        // first wave in (kernel-internal span)
+    if (blockIdx.x == 0) atomicMin(clk + 6, now);   // workgroup 0 in
+  }
+  {
+    // S -> LDS, fragment f = (t, b): S[4 t + lk][16 b + lr] (rows / columns inside the zero-padded S).  ALL of a wave's loads
+    // are issued before the first LDS store: as a load -> store loop the ~22 dependent round trips per wave took ~70 us of a
+    // 450 us kernel (measured with the in-kernel clock, round 3).
+    constexpr int NF = (KS * NT + NW - 1) / NW;
+    double tmp[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int f = w + i * NW;
+      const int t = f / NT, b = f - t * NT;
+      tmp[i] = f < KS * NT ? B[(int64_t)(4 * t + lk) * ldb + 16 * b + lr] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int f = w + i * NW;
+      if (f < KS * NT) sS[f * 64 + lane] = tmp[i];
+    }
   }
   const bool rec = clk != nullptr && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(w) == 0;
   uint64_t c0 = 0, t0 = 0;
@@ -392,26 +411,32 @@ __global__ __launch_bounds__(256 * WPS) void k_gemm_tn_sl(const double* __restri
   const int64_t ntiles = (mdim + 15) / 16;
   const int64_t nwaves = (int64_t)gridDim.x * NW;
   const int64_t wave = (int64_t)blockIdx.x * NW + w;
-  // V cursor: (tile, k-step) of the next fragment to request; runs ahead of the MFMAs, across tile boundaries
-  int64_t pt = wave;
-  int ps = 0;
-  auto issue_a = [&](double& x) {
-    const int64_t t = pt < ntiles ? pt : ntiles - 1;  // past the last tile: a valid address, never used
+  // V fragments: k-step t of a tile is the 4 basis rows 4 t + lk at the 16 matrix rows m0 + lr.  The ring slot of step t is
+  // t % PA; the fragment of step t + PA is requested when step t's has been consumed - from the NEXT tile once t + PA >= KS -
+  // so all indices are compile-time and the per-step address work is one 64-bit add (the run-time cursor of the first
+  // version cost ~15 integer VALU instructions per k-step: as many issue cycles as one of its 7 MFMAs).
+  const int64_t stride4 = 4 * lda;  // doubles between consecutive k-steps of one lane
+  auto tile_base = [&](int64_t tile) {  // lane's pointer to (basis row lk, matrix row m0 + lr), both clamped into the array
+    const int64_t t = tile < ntiles ? tile : ntiles - 1;  // past the last tile: a valid address, never used
     int64_t m = t * 16 + lr;
-    m = m < mdim ? m : mdim - 1;                       // rows past the end: finite values, results not stored
-    int kr = 4 * ps + lk;
-    kr = kr < kcount ? kr : kcount - 1;                // padding k-steps: finite values times the zero rows of S
-    x = __builtin_nontemporal_load(A + (int64_t)kr * lda + m);
-    if (++ps == KS) {
-      ps = 0;
-      pt += nwaves;
-    }
+    m = m < mdim ? m : mdim - 1;                           // rows past the end: finite values, results not stored
+    return A + (int64_t)lk * lda + m;
   };
+  auto frag = [&](const double* base, int t) {  // t is a compile-time constant at every call site
+    if (t >= KS - 2) {  // only the last two k-steps can reach past basis row kcount - 1 (S has zero rows there: any finite value will do)
+      int kr = 4 * t + lk;
+      kr = kr < kcount ? kr : kcount - 1;
+      return __builtin_nontemporal_load(base + (int64_t)(kr - lk) * lda);
+    }
+    return __builtin_nontemporal_load(base + (int64_t)t * stride4);
+  };
+  const double* cur = tile_base(wave);
   double ra[PA];
 #pragma unroll
-  for (int p = 0; p < PA; ++p) issue_a(ra[p]);
+  for (int p = 0; p < PA; ++p) ra[p] = frag(cur, p < KS ? p : KS - 1);
   int64_t mytiles = 0;
   for (int64_t tile = wave; tile < ntiles; tile += nwaves, ++mytiles) {
+    const double* nxt = tile_base(tile + nwaves);
     double4_t acc[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -421,7 +446,7 @@ __global__ __launch_bounds__(256 * WPS) void k_gemm_tn_sl(const double* __restri
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
       const double a = ra[t % PA];
-      issue_a(ra[t % PA]);
+      if (PA < KS) ra[t % PA] = t + PA < KS ? frag(cur, t + PA) : frag(nxt, t + PA - KS);
       double bnxt[NT];
       if (t + 1 < KS) {
 #pragma unroll
@@ -436,6 +461,19 @@ __global__ __launch_bounds__(256 * WPS) void k_gemm_tn_sl(const double* __restri
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (PA >= KS) {  // tiny n: the whole next tile's fragments are requested at once
+#pragma unroll
+      for (int p = 0; p < PA; ++p) ra[p] = frag(nxt, p < KS ? p : KS - 1);
+    } else if constexpr (KS % PA != 0) {
+      // the fragments already requested for the next tile (its steps 0 .. PA-1) sit KS % PA slots further on: rotate the
+      // ring by that compile-time amount so that slot t % PA holds step t again - a few register moves per tile
+      double tmp[PA];
+#pragma unroll
+      for (int i = 0; i < PA; ++i) tmp[i] = ra[(i + KS) % PA];
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = tmp[i];
+    }
+    cur = nxt;
     // results: D[row = lk + 4 g][col = lr] of column tile b
     const int64_t m0 = tile * 16;
     double* cb = C + (m0 + lk) * ldc + lr;
@@ -460,6 +498,172 @@ __global__ __launch_bounds__(256 * WPS) void k_gemm_tn_sl(const double* __restri
     clk[1] = wall_clock64() - t0;
     clk[2] = (unsigned long long)mytiles;
     clk[3] = (unsigned long long)(NT * KS * NW);  // MFMAs per "tile slot" over the four SIMDs: NW waves each do NT KS per tile they own
+  }
+  if (clk != nullptr && lane == 0) {
+    const unsigned long long now = wall_clock64();
+    atomicMax(clk + 5, now);  // last wave out
+    if (blockIdx.x == 0) atomicMax(clk + 7, now);  // workgroup 0 out
+    if (blockIdx.x < 256) atomicMax(clk + 8 + blockIdx.x, now);  // per-workgroup exit tick (diagnostic: LZ_DEBUG_TIMING)
+  }
+}
+
+// The same kernel with 32-ROW tiles (the default for n <= 128): half the vector-memory and LDS instructions per MFMA.
+// Measured on the 16-row version (in-kernel clocks, round 3): the oldest wave of a SIMD runs at 0.93-0.96 of the MFMA issue
+// floor, but the SIMD as a whole (both waves) only at ~0.80 - every vector-memory instruction takes MFMA issue time from the
+// SIMD (~50-165 cycles each), and a 16-row tile costs KS loads + 4 NT stores per NT KS MFMAs.  Here
+//  * one 16-byte load per k-step brings V[k][m0 + 2 lr] and V[k][m0 + 2 lr + 1]: the A fragments of TWO 16-row tiles, the
+//    even and the odd rows of a 32-row block; every B fragment read from LDS feeds two MFMAs;
+//  * column tiles are PAIRED with interleaved columns (tile 2p holds the even, tile 2p+1 the odd columns of the 32-column
+//    group p - a permutation applied once, when S is copied into LDS), so a lane's results for a pair are two ADJACENT
+//    columns of one row: one 16-byte store per pair, rows written in 256-byte runs.  An unpaired last tile keeps 8-byte stores.
+// Per 32 rows: KS loads and 8 ceil(NT / 2) stores per 2 NT KS MFMAs (n = 100: 57 instead of 106).
+// Wave ids are dealt w-major (id = w gridDim + block), so that the waves with one tile more than the others sit on different
+// SIMDs of a workgroup.
+typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte store to an 8-byte aligned address (odd n)
+template <int NT, int KS>
+__global__ __launch_bounds__(512) void k_gemm_tn_sl2(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
+                                                    const double* __restrict__ B, int64_t ldb, int ncols,
+                                                    double* __restrict__ C, int64_t ldc, unsigned long long* __restrict__ clk) {
+  constexpr int NW = 8;
+  constexpr int PA = NT == 7 ? 6 : 8;  // 16-byte V fragments in flight per wave (7 column tiles: 224 accumulator registers leave room for 6)
+  constexpr int NP = NT / 2;  // paired column tiles
+  extern __shared__ double sS[];  // [KS][NT][64]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  if (clk != nullptr && lane == 0) {
+    const unsigned long long now = wall_clock64();
+    atomicMin(clk + 4, now);                        // first wave in (kernel-internal span)
+    if (blockIdx.x == 0) atomicMin(clk + 6, now);   // workgroup 0 in
+  }
+  {
+    constexpr int NF = (KS * NT + NW - 1) / NW;
+    double tmp[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int f = w + i * NW;
+      const int t = f / NT, b = f - t * NT;
+      const int col = (b | 1) < NT ? 32 * (b >> 1) + 2 * lr + (b & 1) : 16 * b + lr;  // paired tiles: interleaved columns
+      tmp[i] = f < KS * NT ? B[(int64_t)(4 * t + lk) * ldb + col] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      const int f = w + i * NW;
+      if (f < KS * NT) sS[f * 64 + lane] = tmp[i];
+    }
+  }
+  const bool rec = clk != nullptr && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(w) == 0;
+  uint64_t c0 = 0, t0 = 0;
+  if (rec) {
+    c0 = clock64();
+    t0 = wall_clock64();
+  }
+  __syncthreads();
+  const int64_t ntiles = (mdim + 31) / 32;
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
+  const int64_t wave = (int64_t)w * gridDim.x + blockIdx.x;
+  const int64_t stride4 = 4 * lda;
+  auto tile_base = [&](int64_t tile) {
+    const int64_t t = tile < ntiles ? tile : ntiles - 1;
+    int64_t m = t * 32 + 2 * lr;
+    m = m < mdim ? m : ((mdim - 1) & ~(int64_t)1);  // a pair past the end: a valid (even) address, results not stored
+    return A + (int64_t)lk * lda + m;
+  };
+  auto frag = [&](const double* base, int t) {  // t is a compile-time constant at every call site
+    if (t >= KS - 2) {
+      int kr = 4 * t + lk;
+      kr = kr < kcount ? kr : kcount - 1;
+      return __builtin_nontemporal_load(reinterpret_cast<const d2v_t*>(base + (int64_t)(kr - lk) * lda));
+    }
+    return __builtin_nontemporal_load(reinterpret_cast<const d2v_t*>(base + (int64_t)t * stride4));
+  };
+  const double* cur = tile_base(wave);
+  d2v_t ra[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) ra[p] = frag(cur, p < KS ? p : KS - 1);
+  int64_t mytiles = 0;
+  for (int64_t tile = wave; tile < ntiles; tile += nwaves, ++mytiles) {
+    const double* nxt = tile_base(tile + nwaves);
+    double4_t accE[NT], accO[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      accE[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      accO[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    double bcur[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bcur[b] = sS[b * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const d2v_t a = ra[t % PA];
+      if (PA < KS) ra[t % PA] = t + PA < KS ? frag(cur, t + PA) : frag(nxt, t + PA - KS);
+      double bnxt[NT];
+      if (t + 1 < KS) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bnxt[b] = sS[((t + 1) * NT + b) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        accE[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bcur[b], accE[b], 0, 0, 0);
+        accO[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bcur[b], accO[b], 0, 0, 0);
+      }
+      if (t + 1 < KS) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b) bcur[b] = bnxt[b];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (PA >= KS) {
+#pragma unroll
+      for (int p = 0; p < PA; ++p) ra[p] = frag(nxt, p < KS ? p : KS - 1);
+    } else if constexpr (KS % PA != 0) {
+      d2v_t tmp[PA];
+#pragma unroll
+      for (int i = 0; i < PA; ++i) tmp[i] = ra[(i + KS) % PA];
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = tmp[i];
+    }
+    cur = nxt;
+    // results: accE[b][g] = Y[m0 + 2 (lk + 4 g)][col(b, lr)], accO: the row below it
+    const int64_t m0 = tile * 32;
+    const bool whole = m0 + 32 <= mdim;  // wave-uniform: only the very last tile can be ragged in rows
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t rE = m0 + 2 * (lk + 4 * g);
+      double* pE = C + rE * ldc;
+      double* pO = pE + ldc;
+      const bool okE = whole || rE < mdim, okO = whole || rE + 1 < mdim;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int col = 32 * p + 2 * lr;
+        if (col + 1 < ncols) {
+          if (okE) __builtin_nontemporal_store((d2u_t){accE[2 * p][g], accE[2 * p + 1][g]}, reinterpret_cast<d2u_t*>(pE + col));
+          if (okO) __builtin_nontemporal_store((d2u_t){accO[2 * p][g], accO[2 * p + 1][g]}, reinterpret_cast<d2u_t*>(pO + col));
+        } else if (col < ncols) {
+          if (okE) __builtin_nontemporal_store(accE[2 * p][g], pE + col);
+          if (okO) __builtin_nontemporal_store(accO[2 * p][g], pO + col);
+        }
+      }
+      if constexpr (NT & 1) {
+        const int col = 16 * (NT - 1) + lr;
+        if (col < ncols) {
+          if (okE) __builtin_nontemporal_store(accE[NT - 1][g], pE + col);
+          if (okO) __builtin_nontemporal_store(accO[NT - 1][g], pO + col);
+        }
+      }
+    }
+  }
+  if (rec) {
+    clk[0] = clock64() - c0;
+    clk[1] = wall_clock64() - t0;
+    clk[2] = (unsigned long long)(2 * mytiles);  // in 16-row tiles
+    clk[3] = (unsigned long long)(NT * KS * NW);
+  }
+  if (clk != nullptr && lane == 0) {
+    const unsigned long long now = wall_clock64();
+    atomicMax(clk + 5, now);
+    if (blockIdx.x == 0) atomicMax(clk + 7, now);  // workgroup 0 out: with [6], the span the whole workgroup (not only its oldest wave) needed
+    if (blockIdx.x < 256) atomicMax(clk + 8 + blockIdx.x, now);
   }
 }
 
@@ -639,7 +843,8 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sreg(const double* __restrict__
           const int r = t - 2, j = r >> 2, g = r & 3;
           const double v = pacc[j][g] + other;
           if (r + 1 < 4 * FULL) other = iprev[(r + 1) * 64];
-          if (!(ABL & 2)) __builtin_nontemporal_store(v, prow[g] + 64 * j);
+          // (with REM == 0 the LAST full panel group can be ragged: columns >= ncols belong to the next row of C)
+          if (!(ABL & 2) && (REM > 0 || j + 1 < FULL || 16 * (s + 4 * j) + lr < ncols)) __builtin_nontemporal_store(v, prow[g] + 64 * j);
         }
         if (t >= 2 + 4 * FULL && t < 2 + 4 * FULL + REM) {
           const int i = t - 2 - 4 * FULL;
@@ -663,7 +868,8 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sreg(const double* __restrict__
       for (int j = 0; j < FULL; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          __builtin_nontemporal_store(pacc[j][g] + iprev[(j * 4 + g) * 64], cprev + (lk + 4 * g) * ldc + 16 * (s + 4 * j) + lr);
+          if (REM > 0 || j + 1 < FULL || 16 * (s + 4 * j) + lr < ncols)
+            __builtin_nontemporal_store(pacc[j][g] + iprev[(j * 4 + g) * 64], cprev + (lk + 4 * g) * ldc + 16 * (s + 4 * j) + lr);
 #pragma unroll
       for (int i = 0; i < REM; ++i) {
         const double v = ksplit(pprev, i);
@@ -732,16 +938,46 @@ template <int WPS>
 static bool sl_dispatch(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
                         hipStream_t s, unsigned long long* clk, hipError_t* err) {
   const int NT = (n + 15) / 16;
-  const int KS = (((n + 3) / 4) + 1) & ~1;
+  const int KS = (n + 3) / 4;  // exact: 4 NT - 3 .. 4 NT (no even rounding here: every wave owns all of K)
 #define LZ_SL(nt, ks)                                                                    \
   if (NT == nt && KS == ks) {                                                            \
     *err = launch_sl<nt, ks, WPS>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk);           \
     return true;                                                                         \
   }
-  LZ_SL(1, 2) LZ_SL(1, 4) LZ_SL(2, 6) LZ_SL(2, 8) LZ_SL(3, 10) LZ_SL(3, 12) LZ_SL(4, 14) LZ_SL(4, 16)
-  if constexpr (WPS == 2) {  // (four waves per SIMD have 128 registers each: enough for <= 4 column tiles only)
-    LZ_SL(5, 18) LZ_SL(5, 20) LZ_SL(6, 22) LZ_SL(6, 24) LZ_SL(7, 26) LZ_SL(7, 28) LZ_SL(8, 30) LZ_SL(8, 32)
+#define LZ_SL4(nt) LZ_SL(nt, 4 * nt - 3) LZ_SL(nt, 4 * nt - 2) LZ_SL(nt, 4 * nt - 1) LZ_SL(nt, 4 * nt)
+  LZ_SL4(1) LZ_SL4(2) LZ_SL4(3) LZ_SL4(4) LZ_SL4(5) LZ_SL4(6) LZ_SL4(7) LZ_SL4(8)
+#undef LZ_SL4
+#undef LZ_SL
+  return false;
+}
+
+template <int NT, int KS>
+static hipError_t launch_sl2(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
+                             hipStream_t s, unsigned long long* clk) {
+  constexpr size_t lds = (size_t)KS * NT * 64 * sizeof(double);
+  static hipError_t attr = hipErrorNotReady;
+  if (attr == hipErrorNotReady)
+    attr = lds > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_sl2<NT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                       : hipSuccess;
+  if (attr != hipSuccess) return attr;
+  const int64_t ntiles = (rows + 31) / 32;
+  const int grid = (int)std::min<int64_t>(kNumCU, (ntiles + 7) / 8);
+  hipLaunchKernelGGL((k_gemm_tn_sl2<NT, KS>), dim3(grid), dim3(512), lds, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy, clk);
+  return hipSuccess;
+}
+
+static bool sl2_dispatch(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
+                         hipStream_t s, unsigned long long* clk, hipError_t* err) {
+  const int NT = (n + 15) / 16;
+  const int KS = (n + 3) / 4;
+#define LZ_SL(nt, ks)                                                            \
+  if (NT == nt && KS == ks) {                                                    \
+    *err = launch_sl2<nt, ks>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk);       \
+    return true;                                                                 \
   }
+#define LZ_SL4(nt) LZ_SL(nt, 4 * nt - 3) LZ_SL(nt, 4 * nt - 2) LZ_SL(nt, 4 * nt - 1) LZ_SL(nt, 4 * nt)
+  LZ_SL4(1) LZ_SL4(2) LZ_SL4(3) LZ_SL4(4) LZ_SL4(5) LZ_SL4(6) LZ_SL4(7) LZ_SL4(8)
+#undef LZ_SL4
 #undef LZ_SL
   return false;
 }
@@ -850,19 +1086,20 @@ static bool kbench_ritz_arm(const double* V, int64_t ldv, int64_t rows, int n, c
 hipError_t launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
                             int64_t ldy, hipStream_t s, int variant, unsigned long long* clk) {
   const int64_t ntiles = (rows + 31) / 32;
-  // 0 (auto): n <= 128 and at least 4096 rows: S resident in LDS (k_gemm_tn_sl; 6 = the same with four waves per SIMD);
+  // 0 (auto): n <= 128 and at least 4096 rows: S resident in LDS (k_gemm_tn_sl2, 32-row tiles; 6 = k_gemm_tn_sl, 16-row tiles);
   // 129 <= n <= 200: the S-stationary kernel where it applies (enough row tiles for a persistent grid, 16-byte aligned
   // rows); else one workgroup per 128 rows.  1 forces the latter.
   const bool sreg_ok = n > 128 && n <= 200 && (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 && npad >= 16 * ((n + 15) / 16) &&
                        ntiles >= 2 * kNumCU * (kTPB / 64);
-  const bool sl_ok = n <= 128 && rows >= 4096 && npad >= 16 * ((n + 15) / 16);
+  const bool sl_ok = n > 32 && n <= 128 && rows >= 4096 && npad >= 16 * ((n + 15) / 16);  // (n <= 32 is a pure stream: the many short-lived workgroups of k_gemm_tn keep more loads in flight)
 #ifdef LZ_KBENCH
   if (hipError_t e; kbench_ritz_arm(V, ldv, rows, n, Spad, npad, Y, ldy, s, variant, &e)) return e;
 #endif
   if (variant != 1 && sl_ok) {
     hipError_t e = hipSuccess;
-    if (variant == 6 && n <= 64 ? sl_dispatch<4>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e)
-                                : sl_dispatch<2>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e))
+    const bool pairs_ok = (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0;  // 16-byte loads of V
+    if (variant != 6 && pairs_ok ? sl2_dispatch(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e)
+                                 : sl_dispatch<2>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e))
       return e;
   }
   if (variant != 1 && sreg_ok) {

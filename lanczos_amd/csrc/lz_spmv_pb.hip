@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
 }
 
 // once per process and kernel: dynamic-LDS limit = the CU's 160 KiB (result remembered, returned on every call)
-constexpr size_t kPbLdsCuMax = 160 * 1024;
+constexpr size_t kPbLdsCuMax = 160 * 1024 - 1024;  // the CU's 160 KiB less the kernels' static LDS (the attribute counts dynamic bytes only)
 hipError_t pb_raise_lds_limits() {
   static hipError_t done = hipErrorNotReady;
   if (done != hipErrorNotReady) return done;

@@ -460,7 +460,7 @@ def test_retired_ritz_gemm_arms_in_the_kernel_bench_build(kb, variant, dims, n):
     h.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 6])
 @pytest.mark.parametrize("dims,n", [((300, 250), 50), ((331, 211), 37), ((512, 256), 200), ((331, 211), 197), ((331, 211), 193),
                                     ((300, 250), 49), ((300, 250), 64), ((300, 250), 65), ((300, 250), 100), ((331, 211), 111),
                                     ((300, 250), 150), ((331, 211), 192), ((300, 250), 201), ((300, 250), 126), ((257, 256), 178),
@@ -470,10 +470,13 @@ def test_retired_ritz_gemm_arms_in_the_kernel_bench_build(kb, variant, dims, n):
                                     ((300, 250), 70), ((300, 250), 128), ((300, 250), 129)])
 def test_ritz_backtransform_kernels(hip, variant, dims, n):
     """Y = V S (Lanczos.py:153-156) by the FP64-MFMA kernels - 0: automatic choice: S resident in LDS, Y-stationary waves
-    without barriers for n <= 128; the S-stationary kernel (S held in registers, 16-row tiles of V through LDS) for
+    without barriers for 32 < n <= 128; the S-stationary kernel (S held in registers, 16-row tiles of V through LDS) for
     129 <= n <= 200 - every (column tiles, k-steps) instantiation of either is hit by some case here - else (n > 200) the
-    one-workgroup-per-128-rows kernel; 1: the latter always (one wave per SIMD with a 32-row x n tile) - against NumPy on the
-    fetched basis, ragged row and column counts included."""
+    one-workgroup-per-128-rows kernel; 1: the latter always (one wave per SIMD with a 32-row x n tile); 6: the 16-row-tile
+    form of the S-in-LDS kernel (what runs when V is not 16-byte aligned) - against NumPy on the fetched basis, ragged row
+    and column counts included."""
+    if variant == 6 and not 32 < n <= 128:
+        pytest.skip("variant 6 differs from 0 only for 32 < n <= 128")
     A = synthetic.laplacian_2d_5pt(*dims)
     M = A.shape[0]
     v0 = synthetic.reference_start_vector(M)
@@ -491,7 +494,7 @@ def test_ritz_backtransform_kernels(hip, variant, dims, n):
     assert np.abs(G - np.eye(n)).max() < 1e-12
     info = h.ritz_info()
     assert info["chunk_rows"] == 0
-    if variant == 0 and n <= 200:  # the S-in-LDS (n <= 128) or the S-stationary kernel ran and left its clock record
+    if variant in (0, 6) and 32 < n <= 200:  # the S-in-LDS (n <= 128) or the S-stationary kernel ran and left its clock record
         assert info["tiles"] > 0 and 500 < info["clock_mhz"] < 3000 and info["cycles_per_tile"] >= info["mfma_floor_cycles_per_tile"] > 0, info
     else:
         assert info["tiles"] == 0

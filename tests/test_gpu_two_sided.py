@@ -131,10 +131,16 @@ def test_error_behaviour():
         s.execute_Lanczos(4, v0=np.ones(64))
     with pytest.raises(UnboundLocalError):
         s.execute_Lanczos(1)
+    s.strict_use_cuda = True
     with pytest.raises(NotImplementedError):
         s.execute_Lanczos(4, use_cuda=False)
     with pytest.raises(ValueError, match="Lanczos Algorithm has not been called."):
         s.H_eff
+    s.strict_use_cuda = False
+    s.execute_Lanczos(4, use_cuda=False)  # accepted: one notice line, then the HIP path
+    t = IrrLanczos(A)
+    t.execute_Lanczos(4)
+    assert np.array_equal(s.H_eff, t.H_eff)
 
 
 def test_run_to_run_bit_reproducibility_and_handle_reuse():
