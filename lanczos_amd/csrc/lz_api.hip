@@ -987,8 +987,13 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   pb_free(A.pb);
   const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
-    LZ_HIP(h, pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]));
+    const hipError_t pe = pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]);
+    A.host_colidx = nullptr;  // (the caller's arrays are only valid during this call)
+    A.host_vals = nullptr;
+    LZ_HIP(h, pe);
   }
+  A.host_colidx = nullptr;
+  A.host_vals = nullptr;
   return LZ_OK;
 }
 
@@ -1026,6 +1031,8 @@ int upload_csr(lz_handle h, CsrDev& A, const char* who, int64_t rows, int64_t nc
   }
   *fixed_k_out = fixed_k;
   *max_nnz_out = max_nnz;
+  A.host_colidx = colidx;  // for pb_build (fill_csr_meta, same API call): diagonal split, fp32-exact value check
+  A.host_vals = vals;
   return LZ_OK;
 }
 

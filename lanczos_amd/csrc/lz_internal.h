@@ -36,12 +36,15 @@ struct CsrDev {
   double avg_row_nnz = 0;
   double far_frac = 0;        // share of entries whose column is > 2^18 away from their row: no L2 reuse of x to speak of
   struct PbDev* pb = nullptr; // column-blocked two-phase layout (lz_spmv_pb.hip), built when the matrix has no column locality
+  const int32_t* host_colidx = nullptr;  // the caller's arrays, valid ONLY inside lz_set_csr / lz_set_csr_transpose (pb_build reads them)
+  const double* host_vals = nullptr;
 };
 
 // ---- column-blocked two-phase SpMV (lz_spmv_pb.hip): gathers out of LDS only; y bit-identical to the CSR-stream kernel
 hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob = 0);  // *out == nullptr: not applicable
 void pb_free(PbDev*& pb);
 int pb_num_partials(const PbDev* pb);
+void pb_layout_info(const PbDev* pb, int64_t* np, int* in_bytes_x2, int* diag);
 int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s);
 
 // launch wrappers (all asynchronous on `s`)

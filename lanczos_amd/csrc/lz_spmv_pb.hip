@@ -26,6 +26,15 @@
 // two dependent scattered round trips per workgroup, 0.99 ms - slower than the gather it replaced.  Measurements:
 // profiles/r02/ablate_pb_rows_and_ritz.json)
 //
+// Round 3 - fewer bytes (3.02 GB per SpMV against 1.16 GB of CSR-algorithmic bytes):
+//   * the DIAGONAL never takes the round trip through T2.  x[row] is an access phase 2 makes anyway (coalesced, for the fused
+//     alpha = x . A x), so phase 2 forms a_ii x_i itself from a per-row array `dvals` and parks it in LDS behind the
+//     segment; `perm` points the row's sum at it, at the diagonal's position in CSR order - same products, same additions.
+//     For D - Adj that is every eighth entry: 28.5 -> 8 bytes each.  (Square single-rank matrices only: in a row-block
+//     partition a row's own column is not its local index.)
+//   * matrix values travel as fp32 where EVERY value is exactly representable in fp32 (Laplacians, adjacency and stencil
+//     weights are small integers): the kernel widens them back - bit-identical products, 4 bytes less per entry.
+//
 // The layout is built on the device at lz_set_csr time (integer kernels with LDS histograms); the slot an entry gets
 // inside its tile depends on atomic order, which is harmless: `perm` is a bijection onto the tile whatever that order
 // is, so every run produces the same bits.
@@ -60,7 +69,10 @@ struct PbDev {
   uint16_t* perm = nullptr;    // nnz: CSR position -> slot within its row block's segment
   uint16_t* pcol = nullptr;    // np (stream order): column - cb * W
   uint32_t* gdst = nullptr;    // np / 8: slot in T2 of every group of 8 stream entries
-  double* pvals = nullptr;     // np
+  double* pvals = nullptr;     // np (values that need fp64)
+  float* pvals32 = nullptr;    // np (every value exactly representable in fp32: half the bytes, same products)
+  double* dvals = nullptr;     // rows: the diagonal entry of every row (0 where a row has none); nullptr: diagonal not split off
+  int maxrows = 0;             // longest row block (rows)
   double* T2 = nullptr;        // np products
   int segmax = 0;              // longest padded segment (products)
   int ncu = 256;               // compute units of the device: phase 2's persistent grid
@@ -71,9 +83,10 @@ namespace {
 
 __host__ __device__ __forceinline__ int pad8(int n) { return (n + kPbPad - 1) & ~(kPbPad - 1); }
 
-// per row block: tile lengths (entries per column block) and the padded segment length
+// per row block: tile lengths (entries per column block) and the padded segment length.  `diag`: entries with
+// column == row are not part of the stream (phase 2 forms them itself)
 __global__ __launch_bounds__(256) void k_pb_hist(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-                                                 const int32_t* __restrict__ rbptr, int W, int nCB, int32_t* __restrict__ len,
+                                                 const int32_t* __restrict__ rbptr, int W, int nCB, int diag, int32_t* __restrict__ len,
                                                  int32_t* __restrict__ segtot) {
   extern __shared__ int hist[];
   __shared__ int tot;
@@ -81,8 +94,11 @@ __global__ __launch_bounds__(256) void k_pb_hist(const int32_t* __restrict__ row
   for (int c = threadIdx.x; c < nCB; c += blockDim.x) hist[c] = 0;
   if (threadIdx.x == 0) tot = 0;
   __syncthreads();
-  const int k0 = rowptr[rbptr[rb]], k1 = rowptr[rbptr[rb + 1]];
-  for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) atomicAdd(&hist[colidx[k] / W], 1);
+  for (int row = rbptr[rb] + threadIdx.x; row < rbptr[rb + 1]; row += blockDim.x)
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+      const int col = colidx[k];
+      if (!(diag && col == row)) atomicAdd(&hist[col / W], 1);
+    }
   __syncthreads();
   int mine = 0;
   for (int c = threadIdx.x; c < nCB; c += blockDim.x) {
@@ -108,12 +124,13 @@ __global__ __launch_bounds__(256) void k_pb_scan_rb(const int32_t* __restrict__ 
 }
 
 // place every entry (and every pad slot): stream position, 16-bit local column, destination in T2, CSR -> slot map
+template <class VT>
 __global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
                                                   const double* __restrict__ vals, const int32_t* __restrict__ rbptr, int W, int nCB,
                                                   const int32_t* __restrict__ cbptr, const int32_t* __restrict__ len,
                                                   const int32_t* __restrict__ toff, const int2* __restrict__ rbseg,
                                                   uint16_t* __restrict__ perm, uint16_t* __restrict__ pcol,
-                                                  uint32_t* __restrict__ gdst, double* __restrict__ pvals) {
+                                                  uint32_t* __restrict__ gdst, VT* __restrict__ pvals, double* __restrict__ dvals) {
   extern __shared__ int sm[];
   int* cursor = sm;          // nCB
   int* ls = sm + nCB;        // nCB + 1: first slot of every tile inside the segment
@@ -129,21 +146,28 @@ __global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ ro
   }
   __syncthreads();
   const uint32_t segbase = (uint32_t)rbseg[rb].x;
-  const int k0 = rowptr[rbptr[rb]], k1 = rowptr[rbptr[rb + 1]];
-  for (int k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-    const int col = colidx[k];
-    const int cb = col / W;
-    const int p = atomicAdd(&cursor[cb], 1);
-    const int64_t t = (int64_t)cbptr[cb] + toff[(int64_t)rb * nCB + cb] + p;
-    pvals[t] = vals[k];
-    pcol[t] = (uint16_t)(col - cb * W);
-    perm[k] = (uint16_t)(ls[cb] + p);
-  }
+  const int dbase = rbseg[rb].y;  // the diagonal products sit right behind this row block's padded segment in phase 2's LDS image
+  const int r0 = rbptr[rb];
+  for (int row = r0 + threadIdx.x; row < rbptr[rb + 1]; row += blockDim.x)
+    for (int k = rowptr[row]; k < rowptr[row + 1]; ++k) {
+      const int col = colidx[k];
+      if (dvals != nullptr && col == row) {  // the diagonal: phase 2 forms vals[k] * x[row] itself, in LDS slot dbase + local row
+        dvals[row] = vals[k];
+        perm[k] = (uint16_t)(dbase + (row - r0));
+        continue;
+      }
+      const int cb = col / W;
+      const int p = atomicAdd(&cursor[cb], 1);
+      const int64_t t = (int64_t)cbptr[cb] + toff[(int64_t)rb * nCB + cb] + p;
+      pvals[t] = (VT)vals[k];
+      pcol[t] = (uint16_t)(col - cb * W);
+      perm[k] = (uint16_t)(ls[cb] + p);
+    }
   for (int c = threadIdx.x; c < nCB; c += blockDim.x) {
     const int n = len[(int64_t)rb * nCB + c];
     const int64_t t0 = (int64_t)cbptr[c] + toff[(int64_t)rb * nCB + c];  // a multiple of 8: every tile is padded
     for (int p = n; p < pad8(n); ++p) {  // pad slots: zero-valued entries, so that whole sectors are written
-      pvals[t0 + p] = 0.0;
+      pvals[t0 + p] = (VT)0;
       pcol[t0 + p] = 0;
     }
     for (int g = 0; g < pad8(n) / kPbPad; ++g) gdst[(t0 >> kPbPadLog) + g] = segbase + (uint32_t)(ls[c] + kPbPad * g);
@@ -152,8 +176,15 @@ __global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ ro
 
 // ---- phase 1: T2[gdst[t / 8] + t % 8] = pvals[t] * v[columns], column block in LDS.  A lane takes PAIRS of entries (one
 // 16-byte value load, one 4-byte column load, a 16-byte product store); four lanes share a group's destination.
-template <int U>
-__global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __restrict__ cbptr, const double* __restrict__ pvals,
+__device__ __forceinline__ double2 pb_ld_vals(const double* pv, int64_t pair) { return ld_stream<1>(reinterpret_cast<const double2*>(pv) + pair); }
+__device__ __forceinline__ double2 pb_ld_vals(const float* pv, int64_t pair) {
+  typedef float f2v_t __attribute__((ext_vector_type(2)));
+  const f2v_t v = __builtin_nontemporal_load(reinterpret_cast<const f2v_t*>(pv) + pair);
+  return make_double2((double)v.x, (double)v.y);  // exact: the layout keeps fp32 only where every value round-trips
+}
+
+template <int U, class VT>
+__global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __restrict__ cbptr, const VT* __restrict__ pvals,
                                                            const uint16_t* __restrict__ pcol, const uint32_t* __restrict__ gdst,
                                                            const double* __restrict__ x, int64_t ncols, int W,
                                                            double* __restrict__ T2) {
@@ -171,7 +202,6 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
   }
   __syncthreads();
   const int64_t p0 = (int64_t)cbptr[cb] >> 1, p1 = (int64_t)cbptr[cb + 1] >> 1;  // stream positions are multiples of 8
-  const double2* pv2 = reinterpret_cast<const double2*>(pvals);
   const uint32_t* pc2 = reinterpret_cast<const uint32_t*>(pcol);
   for (int64_t pb = p0 + threadIdx.x; pb < p1; pb += (int64_t)U * kPbThreads) {
     double2 a[U];
@@ -180,7 +210,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
     for (int u = 0; u < U; ++u) {
       const int64_t p = pb + (int64_t)u * kPbThreads;
       const bool ok = p < p1;
-      a[u] = ok ? ld_stream<1>(pv2 + p) : make_double2(0.0, 0.0);
+      a[u] = ok ? pb_ld_vals(pvals, p) : make_double2(0.0, 0.0);
       c[u] = ok ? __builtin_nontemporal_load(pc2 + p) : 0u;
       d[u] = ok ? __builtin_nontemporal_load(gdst + (p >> (kPbPadLog - 1))) : 0u;
     }
@@ -209,12 +239,13 @@ struct PbTile {
   u4v_t pm[kPbNP];
   int ka[kPbNR], kb[kPbNR];
   double xo[kPbNR];
+  double dv[kPbNR];  // the rows' diagonal entries (dvals), 0 without the diagonal split
 };
 
 template <int ABL>
 __device__ __forceinline__ void pb_tile_load(PbTile& t, int4 hd, int2 sg, const int32_t* __restrict__ rowptr,
                                              const uint16_t* __restrict__ perm, const double* __restrict__ T2,
-                                             const double* __restrict__ xown) {
+                                             const double* __restrict__ xown, const double* __restrict__ dvals) {
   const double2* src = reinterpret_cast<const double2*>(T2 + sg.x);  // 64-byte aligned, a multiple of 8 products long
   const int n2 = sg.y >> 1;
 #pragma unroll
@@ -235,10 +266,12 @@ __device__ __forceinline__ void pb_tile_load(PbTile& t, int4 hd, int2 sg, const 
     const int row = hd.x + threadIdx.x + i * kPbThreads;
     t.ka[i] = t.kb[i] = 0;
     t.xo[i] = 0.0;
+    t.dv[i] = 0.0;
     if (row < hd.x + hd.y) {
       t.ka[i] = rowptr[row];  // raw: nothing here may wait for a load (the consumer subtracts the window base)
       t.kb[i] = rowptr[row + 1];
       t.xo[i] = xown[row];
+      if (dvals != nullptr) t.dv[i] = __builtin_nontemporal_load(dvals + row);
     }
   }
 }
@@ -248,19 +281,20 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
                                                        const int32_t* __restrict__ rowptr, const uint16_t* __restrict__ perm,
                                                        const double* __restrict__ T2, int segcap, int nRB,
                                                        const double* __restrict__ xown, double* __restrict__ y,
-                                                       double* __restrict__ part) {
-  extern __shared__ double seg[];  // segcap products, then the aligned window of the row block's perm entries
+                                                       double* __restrict__ part, const double* __restrict__ dvals) {
+  extern __shared__ double seg[];  // per row block: its padded segment of products | one diagonal product per row | the aligned window of its perm entries
   __shared__ double red[kPbThreads / 64];
-  uint16_t* perm_s = reinterpret_cast<uint16_t*>(seg + segcap);
   int rb = blockIdx.x;  // the grid is never larger than nRB
   int4 hd = rbhead[rb];
   int2 sg = rbseg[rb];
   PbTile t;
-  pb_tile_load<ABL>(t, hd, sg, rowptr, perm, T2, xown);
+  pb_tile_load<ABL>(t, hd, sg, rowptr, perm, T2, xown, dvals);
   for (;;) {
     // registers -> LDS.  The explicit vmcnt(0) tells the compiler's wait-count pass, on every path, that nothing is
     // outstanding from here on - otherwise the predicated loads below make it wait in the middle of the next prefetch.
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    const int dbase = sg.y;  // (a multiple of 8)
+    uint16_t* perm_s = reinterpret_cast<uint16_t*>(seg + ((dbase + (dvals != nullptr ? hd.y : 0) + 1) & ~1));
     {
       double2* dst = reinterpret_cast<double2*>(seg);
       const int n2 = sg.y >> 1;
@@ -284,6 +318,9 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
       ka[i] = t.ka[i];
       kb[i] = t.kb[i];
       xo[i] = t.xo[i];
+      // the diagonal's product a_ii * x_i, formed here (the same fp64 multiply phase 1 would have made) and parked behind the
+      // segment, where this row's perm entry for the diagonal points
+      if (dvals != nullptr && threadIdx.x + i * kPbThreads < hd.y) seg[dbase + threadIdx.x + i * kPbThreads] = t.dv[i] * xo[i];
       // keep the compiler from folding "- kbase" into the prefetch (it would wait for the loads right where they are issued)
       asm volatile("" : "+v"(ka[i]), "+v"(kb[i]));
     }
@@ -296,7 +333,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
     if (more) {
       hd = rbhead[rb];
       sg = rbseg[rb];
-      pb_tile_load<ABL>(t, hd, sg, rowptr, perm, T2, xown);
+      pb_tile_load<ABL>(t, hd, sg, rowptr, perm, T2, xown, dvals);
     }
     double d = 0.0;
 #pragma unroll
@@ -342,7 +379,8 @@ hipError_t pb_raise_lds_limits() {
     const hipError_t x = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPbLdsCuMax);
     if (e == hipSuccess) e = x;
   };
-  up(reinterpret_cast<const void*>(k_pb_products<4>));
+  up(reinterpret_cast<const void*>(k_pb_products<4, double>));
+  up(reinterpret_cast<const void*>(k_pb_products<4, float>));
   up(reinterpret_cast<const void*>(k_pb_rows<0>));
 #ifdef LZ_KBENCH
   up(reinterpret_cast<const void*>(k_pb_rows<1>));
@@ -373,13 +411,16 @@ void pb_free(PbDev*& pb) {
   hipFree(pb->pcol);
   hipFree(pb->gdst);
   hipFree(pb->pvals);
+  hipFree(pb->pvals32);
+  hipFree(pb->dvals);
   hipFree(pb->T2);
   delete pb;
   pb = nullptr;
 }
 
 // Build the two-phase layout for the device CSR matrix A.  Returns hipSuccess with *out == nullptr when the matrix does
-// not qualify (a single row longer than the LDS tile).
+// not qualify (a single row longer than the LDS tile).  A.host_colidx / A.host_vals (the caller's arrays, valid during
+// lz_set_csr) switch on the diagonal split and the fp32 value stream where they apply.
 hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob) {
   *out = nullptr;
   if (A.rows <= 0 || A.nnz <= 0) return hipSuccess;
@@ -388,19 +429,46 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   if (W < 256) W = 256;
   if (W > kPbMaxW) W = kPbMaxW;
   const int nCB = (int)((A.ncols + W - 1) / W);
-  // Products per row block: phase 2 keeps the padded segment (<= cap + 7 nCB products) and an aligned window of
-  // cap + 16 perm entries in LDS.
-  const int cap_max = std::min((int)((kPbLdsMax - 32 - (int64_t)(kPbPad - 1) * nCB * 8) / 10), kPbNP * 8 * kPbThreads - 16);
-  int cap = cap_knob > 0 ? cap_knob : cap_max;  // as large as fits: longer tiles, less padding (measured best)
-  if (cap > cap_max) cap = cap_max;
-  if (cap < 256 || A.max_row_nnz > cap) return hipSuccess;
+  // The diagonal split needs a row's own column to be its local index: the whole square matrix on this rank.
+  const bool diag = A.host_colidx != nullptr && A.rows == A.ncols;
+  bool f32 = A.host_vals != nullptr;
+  if (f32)
+    for (int64_t k = 0; k < A.nnz; ++k) {
+      const double v = A.host_vals[k];
+      if ((double)(float)v != v) {  // (NaN fails too: such a matrix keeps its fp64 stream)
+        f32 = false;
+        break;
+      }
+    }
+  // Row blocks.  Phase 2 keeps in LDS: the padded segment (off-diagonal products + at most 7 pad slots per column block),
+  // one diagonal product per row, and an aligned window of the block's perm entries (2 bytes per CSR entry).
+  const int64_t lds_budget = kPbLdsMax - 32 - (int64_t)(kPbPad - 1) * nCB * 8 - 32;
+  const int ent_max = kPbNP * 8 * kPbThreads - 16;                       // perm window held in registers by the prefetch
+  const int off_max = kPbNQ * 2 * kPbThreads - (kPbPad - 1) * nCB - 16;  // products held in registers by the prefetch
+  if (lds_budget < 4096 || off_max < 256) return hipSuccess;
+  int cap = cap_knob > 0 ? cap_knob : ent_max;  // entries per row block: as many as fit (longer tiles, less padding: measured best)
+  if (cap > ent_max) cap = ent_max;
+  if (cap < 256) return hipSuccess;
   std::vector<int32_t> rb;
   rb.push_back(0);
+  int maxrows = 0, maxent = 0;
   for (int64_t r = 0; r < A.rows;) {
-    int64_t e = r;
-    const int64_t k0 = rowptr_host[r];
-    while (e < A.rows && e - r < kPbMaxRows && (int64_t)rowptr_host[e + 1] - k0 <= cap) ++e;
-    rb.push_back((int32_t)e);  // e > r: no row is longer than cap
+    int64_t e = r, ent = 0, off = 0;
+    while (e < A.rows && e - r < kPbMaxRows) {
+      const int64_t nr = (int64_t)rowptr_host[e + 1] - rowptr_host[e];
+      int64_t nd = 0;
+      if (diag)
+        for (int64_t k = rowptr_host[e]; k < rowptr_host[e + 1]; ++k) nd += A.host_colidx[k] == e;
+      const int64_t ent2 = ent + nr, off2 = off + nr - nd, rows2 = e - r + 1;
+      if (ent2 > cap || off2 > off_max || 8 * off2 + (diag ? 8 * rows2 : 0) + 2 * (ent2 + 16) > lds_budget) break;
+      ent = ent2;
+      off = off2;
+      ++e;
+    }
+    if (e == r) return hipSuccess;  // a single row does not fit: not applicable (the CSR-stream kernel handles it)
+    rb.push_back((int32_t)e);
+    maxrows = std::max(maxrows, (int)(e - r));
+    maxent = std::max(maxent, (int)ent);
     r = e;
   }
   const int nRB = (int)rb.size() - 1;
@@ -408,8 +476,9 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   pb->nCB = nCB;
   pb->nRB = nRB;
   pb->W = (int)W;
-  pb->cap = cap;
+  pb->cap = maxent;
   pb->nnz = A.nnz;
+  pb->maxrows = maxrows;
   hipError_t e = hipSuccess;
   {
     int dev = 0, cus = 0;
@@ -429,6 +498,10 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   chk(pb_alloc(toff, (size_t)nRB * nCB));
   chk(pb_alloc(tot, (size_t)nCB));
   chk(pb_alloc(segtot, (size_t)nRB));
+  if (diag) {
+    chk(pb_alloc(pb->dvals, (size_t)A.rows));
+    if (e == hipSuccess) chk(hipMemsetAsync(pb->dvals, 0, (size_t)A.rows * sizeof(double), s));
+  }
   std::vector<int4> head((size_t)nRB);
   for (int b = 0; b < nRB; ++b)
     head[(size_t)b] = make_int4(rb[(size_t)b], rb[(size_t)b + 1] - rb[(size_t)b], rowptr_host[rb[(size_t)b]],
@@ -436,7 +509,8 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   if (e == hipSuccess) chk(hipMemcpyAsync(pb->rbhead, head.data(), head.size() * sizeof(int4), hipMemcpyHostToDevice, s));
   if (e == hipSuccess) chk(hipMemcpyAsync(pb->rbptr, rb.data(), rb.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_pb_hist, dim3(nRB), dim3(256), (size_t)nCB * sizeof(int), s, A.rowptr, A.colidx, pb->rbptr, (int)W, nCB, len, segtot);
+    hipLaunchKernelGGL(k_pb_hist, dim3(nRB), dim3(256), (size_t)nCB * sizeof(int), s, A.rowptr, A.colidx, pb->rbptr, (int)W, nCB, diag ? 1 : 0, len,
+                       segtot);
     hipLaunchKernelGGL(k_pb_scan_rb, dim3((nCB + 255) / 256), dim3(256), 0, s, len, toff, nRB, nCB, tot);
     chk(hipGetLastError());
   }
@@ -462,15 +536,31 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
     if (np != run) e = hipErrorUnknown;  // cannot happen: both count every tile's padded length once
   }
   pb->np = np;
-  chk(pb_alloc(pb->pcol, (size_t)np));
-  chk(pb_alloc(pb->gdst, (size_t)np / kPbPad));
-  chk(pb_alloc(pb->pvals, (size_t)np));
-  chk(pb_alloc(pb->T2, (size_t)np));
+  pb->segmax = segmax;
+  // phase 2's LDS image of row block b: [0, seg_b) products | [seg_b, seg_b + rows_b) diagonal products | perm window of ent_b + 16 entries
+  size_t lds2 = 0;
+  for (int b = 0; b < nRB; ++b) {
+    const size_t dprod = diag ? (size_t)head[(size_t)b].y : 0;
+    lds2 = std::max(lds2, ((st[(size_t)b] + dprod + 1) & ~(size_t)1) * sizeof(double) + (size_t)(head[(size_t)b].w + 16 + 8) * sizeof(uint16_t));
+  }
+  pb->lds2 = lds2;
+  chk(pb_alloc(pb->pcol, (size_t)np + 8));
+  chk(pb_alloc(pb->gdst, (size_t)np / kPbPad + 8));
+  if (f32)
+    chk(pb_alloc(pb->pvals32, (size_t)np + 8));
+  else
+    chk(pb_alloc(pb->pvals, (size_t)np + 8));
+  chk(pb_alloc(pb->T2, (size_t)np + 8));
   if (e == hipSuccess) chk(hipMemcpyAsync(pb->cbptr, cbp.data(), cbp.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
   if (e == hipSuccess) chk(hipMemcpyAsync(pb->rbseg, seg.data(), seg.size() * sizeof(int2), hipMemcpyHostToDevice, s));
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_pb_place, dim3(nRB), dim3(256), (size_t)(2 * nCB + 1) * sizeof(int), s, A.rowptr, A.colidx, A.vals, pb->rbptr, (int)W,
-                       nCB, pb->cbptr, len, toff, pb->rbseg, pb->perm, pb->pcol, pb->gdst, pb->pvals);
+    const size_t sm = (size_t)(2 * nCB + 1) * sizeof(int);
+    if (f32)
+      hipLaunchKernelGGL(k_pb_place<float>, dim3(nRB), dim3(256), sm, s, A.rowptr, A.colidx, A.vals, pb->rbptr, (int)W, nCB, pb->cbptr, len, toff,
+                         pb->rbseg, pb->perm, pb->pcol, pb->gdst, pb->pvals32, pb->dvals);
+    else
+      hipLaunchKernelGGL(k_pb_place<double>, dim3(nRB), dim3(256), sm, s, A.rowptr, A.colidx, A.vals, pb->rbptr, (int)W, nCB, pb->cbptr, len, toff,
+                         pb->rbseg, pb->perm, pb->pcol, pb->gdst, pb->pvals, pb->dvals);
     chk(hipGetLastError());
     chk(hipStreamSynchronize(s));
   }
@@ -478,9 +568,7 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   hipFree(toff);
   hipFree(tot);
   hipFree(segtot);
-  pb->segmax = segmax;
-  pb->lds2 = (size_t)segmax * sizeof(double) + (size_t)(cap + 16) * sizeof(uint16_t);
-  if (e == hipSuccess && segmax > kPbNQ * 2 * kPbThreads) e = hipErrorInvalidValue;  // cannot happen: the LDS bound is tighter
+  if (e == hipSuccess && segmax > kPbNQ * 2 * kPbThreads) e = hipErrorInvalidValue;  // cannot happen: the row blocks were cut to fit
   // Both phases may need more than the default 64 KiB of dynamic LDS.  The limit is a property of the KERNEL, shared by
   // every layout in the process (H and H^T of a two-sided run, a second handle, ...): it is raised once to what the CU
   // has - never to one matrix's need, which a later, smaller layout would lower again under the earlier one's launches.
@@ -500,12 +588,17 @@ int pb_num_partials(const PbDev* pb) { return pb->nRB; }
 // Returns the number of partials.
 int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s) {
   const size_t lds1 = (size_t)pb->W * sizeof(double);
-  hipLaunchKernelGGL(k_pb_products<4>, dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, pb->gdst, x, A.ncols, pb->W,
-                     pb->T2);
+  if (pb->pvals32)
+    hipLaunchKernelGGL((k_pb_products<4, float>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals32, pb->pcol, pb->gdst, x, A.ncols,
+                       pb->W, pb->T2);
+  else
+    hipLaunchKernelGGL((k_pb_products<4, double>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, pb->gdst, x, A.ncols,
+                       pb->W, pb->T2);
   const int grid = std::min(pb->nRB, pb->ncu);  // one segment fills a CU's LDS: one persistent workgroup per CU
-#define LZ_PB_ROWS(abl)                                                                                                            \
-  hipLaunchKernelGGL(k_pb_rows<abl>, dim3(grid), dim3(kPbThreads), pb->lds2, s, pb->rbhead, pb->rbseg, A.rowptr, pb->perm, pb->T2, pb->segmax, \
-                     pb->nRB, x_own, y, part)
+  const int segcap = pb->segmax;
+#define LZ_PB_ROWS(abl)                                                                                                        \
+  hipLaunchKernelGGL(k_pb_rows<abl>, dim3(grid), dim3(kPbThreads), pb->lds2, s, pb->rbhead, pb->rbseg, A.rowptr, pb->perm, pb->T2, segcap, \
+                     pb->nRB, x_own, y, part, pb->dvals)
 #ifdef LZ_KBENCH  // timing-only ablation arms (wrong results): 1 no product loads, 2 no perm loads, 7 neither and no LDS gathers
   if (A.ablation == 1) {
     LZ_PB_ROWS(1);
@@ -523,6 +616,14 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
   LZ_PB_ROWS(0);
 #undef LZ_PB_ROWS
   return pb->nRB;
+}
+
+// what the layout moves per SpMV, for the traffic accounting in DESIGN.md / bench.py: {stream entries incl. padding, bytes per
+// stream entry of phase 1's input, 1 if the diagonal is split off}
+void pb_layout_info(const PbDev* pb, int64_t* np, int* in_bytes_x2, int* diag) {
+  *np = pb->np;
+  *in_bytes_x2 = (pb->pvals32 ? 8 : 16) + 4 + 1;  // twice (value + 2-byte column + 4 bytes of destination per 8 entries)
+  *diag = pb->dvals != nullptr;
 }
 
 }  // namespace lz
