@@ -49,8 +49,9 @@ enum lz_status {
 enum lz_flags {
   LZ_FLAG_NONE = 0,
   LZ_FLAG_PROFILE = 1,        /* bracket every hot kernel with hipEvents (lz_get_timings) */
-  LZ_FLAG_QTW_MFMA = 2,       /* A/B arm: the v_mfma_f64_16x16x4_f64 Q^T w kernel (default is the 4x4x4 MFMA kernel) */
-  LZ_FLAG_QTW_VALU = 4,       /* A/B arm: the VALU + wave-shuffle Q^T w kernel                                       */
+  LZ_FLAG_QTW_MFMA = 2,       /* kernel-bench build only (retired A/B arm, 20 % slower): the v_mfma_f64_16x16x4_f64 Q^T w
+                                 kernel; the product library refuses it (default: the 4x4x4 MFMA kernel)              */
+  LZ_FLAG_QTW_VALU = 4,       /* the VALU + wave-shuffle Q^T w kernel (also the automatic fallback beyond ~5000 basis rows) */
   LZ_FLAG_SPMV_SCALAR = 8,    /* force the plain one-thread-per-row CSR kernel            */
   LZ_FLAG_FUSED_NORM = 16,    /* ||r||^2 rides with the Q^T r sums: pass 1 dots the raw residual, the update kernel forms
                                  beta, c_i = (V_i.r)/beta and V[j] = r/beta (one pass over V[j] and, at N > 1, one all-reduce
@@ -63,7 +64,11 @@ enum lz_flags {
                                  coefficients V_i.(r'' - alpha_j v_j) = V_i.r'' - alpha_j V_i.v_j and |r|^2 = r''.r'' - 2 alpha_j
                                  v_j.r'' + alpha_j^2 v_j.v_j all come out of one reduced buffer (implies LZ_FLAG_FUSED_NORM).
                                  Same mathematics, different rounding (the three-term update subtracts beta v_{j-1} first, |r|^2
-                                 is formed from three sums): within the 1e-10 bar, not bit-identical to the default. */
+                                 is formed from three sums whose relative error is ~eps (alpha^2 + beta^2) / beta^2): not
+                                 bit-identical to the default, and within 1e-10 only while |alpha| is not >> beta.  A guard
+                                 watches exactly that: when |r|^2 falls below 1e-4 of r''.r'' (or is not positive) at any
+                                 step, lz_run REPEATS the solve on the default loop and lz_last_engine reports 5 - the
+                                 delivered coefficients then are the default loop's, bit for bit.                      */
   LZ_FLAG_REORTH_PARTIAL = 64 /* opt-in: partial re-orthogonalisation (Simon 1984).  The reference sweeps the whole basis
                                  every step; with this flag the sweep (same kernels, same arithmetic) runs only when the
                                  omega-recurrence estimate of the loss of orthogonality exceeds sqrt(eps), on that and the
@@ -102,16 +107,26 @@ int lz_create(lz_handle* out, int device_id);
 int lz_destroy(lz_handle h);
 const char* lz_last_error(lz_handle h); /* h may be NULL: last error of lz_create */
 int lz_set_options(lz_handle h, int flags);
-/* Tuning knobs (index 0: Q^T w slice length per block, 1: Q^T w kernel variant, 2/4: CSR-stream rows /
- * entries per block, 5: fixed-K rows per block, 6: issue the collectives even when world == 1, 7: profile only every
- * value-th iteration of lz_run, 8: update-kernel variant (1 cached loads, 2 one position per lane, 3/4/5 slice owner with
- * 8/4/1 positions per lane), 9: Ritz back-transform kernel (0 auto: S-stationary for 193 <= n <= 200, else one workgroup per
- * 128 rows; 1 the latter always; 2..5 A/B arms), 11: two-sided Gram-Schmidt links (0/1: streaming kernel + fold kernel per link; A/B arms: 2 single launch with a last-block fold, 3 fold deferred into the next link's prologue), 12: 1 = no row-stride skew, 13: 1 = NaN-poison a
- * fresh basis allocation before the required parts are cleared (test knob), 14: irregular SpMV plan (0 auto: the column-blocked
- * two-phase kernels for matrices without column locality, 1 never, 2 always), 10: its products per row block, 15: loop structure (0 auto: fused-launch path for small problems, three-term recurrence folded into pass 1 up to 4e6 rows per rank; 1 plain six-launch loop; A/B arms: 2 one-kernel engine, 3 engine on a plain grid, 5 one launch per step)); they take effect
- * at the next lz_set_csr / lz_basis_alloc / lz_run.  Results never depend on them beyond summation order.  The
- * timing-only ablation arms (knob 1 values >= 20, knob 3) exist only in the kernel-bench build (make KBENCH=1,
- * liblanczos_kbench.so, tools/kbench.py); this library returns LZ_ERR_ARG for them. */
+/* Tuning knobs; they take effect at the next lz_set_csr / lz_basis_alloc / lz_run / lz_ritz_vectors, and results never depend
+ * on them beyond summation order.
+ *    0  Q^T w slice length per block            1  Q^T w kernel variant (unroll / rows per tile)
+ *    2 / 4  CSR-stream rows / entries per block  5  fixed-K rows per block
+ *    6  issue the collectives even when world == 1 (tests of the RCCL calls with a 1-rank communicator)
+ *    7  profile only every value-th iteration of lz_run
+ *    8  update-kernel variant (1 cached loads, 2 one position per lane, 3/4/5 slice owner with 8/4/1 positions per lane)
+ *    9  Ritz back-transform kernel: 0 auto (33..128 columns: S resident in LDS, 32-row tiles; 129..200: S-stationary, S in
+ *       registers; else one workgroup per 128 rows), 1 the latter always, 6 the 16-row-tile form of the S-in-LDS kernel
+ *   10  irregular SpMV: entries per row block   12  1 = no row-stride skew
+ *   13  1 = NaN-poison a fresh basis allocation before the required parts are cleared (test knob)
+ *   14  irregular SpMV plan (0 auto: the column-blocked two-phase kernels for matrices without column locality, 1 never, 2 always)
+ *   15  loop structure (0 auto: three launches per step for small problems, five up to 4e6 rows per rank, else six; 1 six always)
+ *   16  rows per chunk of the CHUNKED Ritz mode (0 auto: chunked only when Y does not fit beside the basis; > 0 forces it: tests)
+ *   11  two-sided Gram-Schmidt links (0 / 1: streaming kernel + fold kernel per link)
+ * The product library returns LZ_ERR_ARG for everything that lives only in the kernel-bench build (make KBENCH=1 ->
+ * liblanczos_kbench.so, loaded by tools/ and by the tests of those arms): the timing-only ablation arms (knob 1 >= 20,
+ * knob 3) and the A/B arms retired in round 3 because they measured slower - the one-kernel and one-launch-per-step engines
+ * (15 = 2, 3, 5), the persistent / LDS-staged Ritz GEMMs (9 = 2, 3, 4), the ticket / deferred-fold two-sided links
+ * (11 = 2, 3), and LZ_FLAG_QTW_MFMA (lz_set_options). */
 int lz_set_tuning(lz_handle h, int index, int value);
 /* "hip=<path of the libamdhip64 this library is bound to>;rccl=<path of the librccl it dlopened, or empty>".
  * RCCL is always taken from the directory of that HIP runtime (LZ_RCCL_PATH overrides): see DESIGN.md section 5. */
@@ -242,15 +257,15 @@ int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
 int lz_last_sweeps(lz_handle h, int* sweeps);
-/* How the last lz_run was executed.  0: six launches per step.  4: the opt-in per-step kernels (lz_set_tuning(h, 15, 5); rows <= 1280
- * padded, n <= 64, one rank, fused-norm mode, short CSR rows or dense): ONE launch per step, every block redoes the vector work of
- * the step and multiplies its share of the rows - bit-identical, but slower than the three launches it replaces.  2: the fused-launch path of small problems (a vector of at
- * most eight pass-1 slices, one rank, fused-norm mode): the second-stage reductions and the three-term recurrence ride
- * in the prologue of their consumer kernels - three launches per step, bit-identical results; lz_set_tuning(h, 15, 1)
- * switches it off.  3: the default loop of problems up to 4e6 rows per rank in fused-norm mode with the full sweep: the three-term
- * recurrence rides in the prologue of the next step's pass 1 (five launches per step, bit-identical; knob 15 = 1 switches it
- * off; not with LZ_FLAG_OVERLAP_HALO).  1: the opt-in one-kernel engine (lz_small.hip, lz_set_tuning(h, 15, 2): rows <= 1280; correct and
- * bit-identical, but on MI355X no faster than the launches it replaces - DESIGN.md section 4). */
+/* How the last lz_run was executed (choose_loop, lz_api.hip).  0: six launches per step (also: partial re-orthogonalisation,
+ * every kernel A/B arm, more than 4e6 rows per rank).  2: the fused-launch path of small problems (a vector of at most eight
+ * pass-1 slices, one rank, fused-norm mode): the second-stage reductions and the three-term recurrence ride in the prologue
+ * of their consumer kernels - three launches per step, bit-identical results.  3: up to 4e6 rows per rank in fused-norm mode
+ * with the full sweep: the three-term recurrence rides in the prologue of the next step's pass 1 (five launches per step,
+ * bit-identical; not with LZ_FLAG_OVERLAP_HALO).  lz_set_tuning(h, 15, 1) selects 0 in both cases.  6: LZ_FLAG_ONE_REDUCE.
+ * 5: a one-reduce run whose cancellation guard fired and that was repeated on the default loop.  1 / 4: the one-kernel and
+ * one-launch-per-step engines of the kernel-bench build (retired from the product library in round 3: bit-identical, not
+ * faster - DESIGN.md section 4). */
 int lz_last_engine(lz_handle h, int* engine);
 
 /* ---- single steps (unit parity tests drive the kernels one by one) ------ */
