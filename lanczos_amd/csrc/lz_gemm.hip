@@ -1,4 +1,6 @@
 // FP64-MFMA kernels: Ritz back-transform Y = V^T-layout x S, Gram matrix Y^T Y, Ritz-vector quality sums.
+#include <type_traits>
+
 #include "lz_device.h"
 
 namespace lz {
@@ -520,14 +522,23 @@ __global__ __launch_bounds__(256 * WPS) void k_gemm_tn_sl(const double* __restri
 // Wave ids are dealt w-major (id = w gridDim + block), so that the waves with one tile more than the others sit on different
 // SIMDs of a workgroup.
 typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));  // 16-byte store to an 8-byte aligned address (odd n)
-template <int NT, int KS>
+// A RAGGED LAST COLUMN TILE (n not a multiple of 16) runs on v_mfma_f64_4x4x4_4b_f64: its A fragment has the SAME lane
+// layout as the 16x16x4 one (A[blk][i][k] in lane 16 k + 4 blk + i = 16 k + row, measured: lz_reorth.hip), its four blocks are
+// the four 4-row groups of the tile against ONE 4-column panel of S (B[blk][k][j] in lane 16 k + 4 blk + j: the same
+// S[4 t + k][c + j] in every block), and it occupies the matrix pipe for 16 cycles instead of 64 (PMC: 16 busy cycles per 256
+// MACs on either shape).  n = 100 = 6 x 16 + 4: 6 x 64 + 16 = 400 cycles per k-step and row tile - the ideal 100 / 16 x 64 -
+// instead of 7 x 64 = 448.  R4 = ceil(r / 4) such panels replace the last tile when its r columns are <= 12.
+template <int NT, int KS, int ABL = 0, bool USE4 = true>  // ABL (kernel-bench build only, wrong results): 1 no V loads, 2 no LDS operand reads, 4 no result stores
 __global__ __launch_bounds__(512) void k_gemm_tn_sl2(const double* __restrict__ A, int64_t lda, int64_t mdim, int kcount,
                                                     const double* __restrict__ B, int64_t ldb, int ncols,
                                                     double* __restrict__ C, int64_t ldc, unsigned long long* __restrict__ clk) {
   constexpr int NW = 8;
-  constexpr int PA = NT == 7 ? 6 : 8;  // 16-byte V fragments in flight per wave (7 column tiles: 224 accumulator registers leave room for 6)
-  constexpr int NP = NT / 2;  // paired column tiles
-  extern __shared__ double sS[];  // [KS][NT][64]
+  constexpr int R4 = (4 * NT == KS || !USE4) ? 0 : KS - 4 * (NT - 1);  // KS = ceil(n / 4): 4 (NT - 1) + ceil(r / 4)
+  constexpr int NF = R4 ? NT - 1 : NT;                        // full 16-column tiles
+  constexpr int NP = NF / 2;                                  // paired column tiles
+  constexpr int FR = NF + R4;                                 // B fragments per k-step
+  constexpr int PA = NF >= 7 ? 6 : 8;  // 16-byte V fragments in flight per wave (7-8 full tiles: 224+ accumulator registers leave room for 6)
+  extern __shared__ double sS[];  // [KS][FR][64]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   if (clk != nullptr && lane == 0) {
@@ -536,19 +547,20 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sl2(const double* __restrict__ 
     if (blockIdx.x == 0) atomicMin(clk + 6, now);   // workgroup 0 in
   }
   {
-    constexpr int NF = (KS * NT + NW - 1) / NW;
-    double tmp[NF];
+    constexpr int NFR = (KS * FR + NW - 1) / NW;
+    double tmp[NFR];
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
+    for (int i = 0; i < NFR; ++i) {
       const int f = w + i * NW;
-      const int t = f / NT, b = f - t * NT;
-      const int col = (b | 1) < NT ? 32 * (b >> 1) + 2 * lr + (b & 1) : 16 * b + lr;  // paired tiles: interleaved columns
-      tmp[i] = f < KS * NT ? B[(int64_t)(4 * t + lk) * ldb + col] : 0.0;
+      const int t = f / FR, q = f - t * FR;
+      // full tiles: paired ones hold interleaved columns; the 4-column panels: column c + (lane & 3) in every block
+      const int col = q >= NF ? 16 * NF + 4 * (q - NF) + (lane & 3) : ((q | 1) < NF ? 32 * (q >> 1) + 2 * lr + (q & 1) : 16 * q + lr);
+      tmp[i] = f < KS * FR ? B[(int64_t)(4 * t + lk) * ldb + col] : 0.0;
     }
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
+    for (int i = 0; i < NFR; ++i) {
       const int f = w + i * NW;
-      if (f < KS * NT) sS[f * 64 + lane] = tmp[i];
+      if (f < KS * FR) sS[f * 64 + lane] = tmp[i];
     }
   }
   const bool rec = clk != nullptr && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(w) == 0;
@@ -569,6 +581,7 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sl2(const double* __restrict__ 
     return A + (int64_t)lk * lda + m;
   };
   auto frag = [&](const double* base, int t) {  // t is a compile-time constant at every call site
+    if (ABL & 1) return (d2v_t){(double)t, 1.0};
     if (t >= KS - 2) {
       int kr = 4 * t + lk;
       kr = kr < kcount ? kr : kcount - 1;
@@ -581,35 +594,53 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sl2(const double* __restrict__ 
 #pragma unroll
   for (int p = 0; p < PA; ++p) ra[p] = frag(cur, p < KS ? p : KS - 1);
   int64_t mytiles = 0;
-  for (int64_t tile = wave; tile < ntiles; tile += nwaves, ++mytiles) {
+  // One tile.  Written for the sake of the WAIT COUNTS: vmcnt counts loads and stores alike, in issue order, and the first
+  // k-steps of a tile need their V fragment - requested before the previous tile's ~26 result stores were issued.  The right
+  // wait is vmcnt(8 + those stores); what the compiler emits is vmcnt(8 + the stores it can PROVE were issued on every path
+  // into the loop header), and vmcnt(8) sits out the acknowledgement of most of the previous tile's stores (measured with the
+  // timing-only arms: the stores cost 0.13 ms of a 0.45 ms kernel that way, the loads 0.05 ms).  So: (a) the first tile is
+  // peeled (both edges into the header then carry the same history), (b) the one row-ragged tile of the whole matrix runs
+  // after the loop, (c) in a whole tile every store whose columns are valid for every n of this instantiation (n >= 4 KS - 3)
+  // is unconditional - no exec-mask branch around it, so it counts.
+  constexpr int NVALID = 4 * KS - 3;
+  auto do_tile = [&](int64_t tile, auto whole_tag) {
+    constexpr bool WHOLE = decltype(whole_tag)::value;
     const double* nxt = tile_base(tile + nwaves);
-    double4_t accE[NT], accO[NT];
+    double4_t accE[NF > 0 ? NF : 1], accO[NF > 0 ? NF : 1];
+    double acc4E[R4 > 0 ? R4 : 1], acc4O[R4 > 0 ? R4 : 1];
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
+    for (int b = 0; b < NF; ++b) {
       accE[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
       accO[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
     }
-    double bcur[NT];
 #pragma unroll
-    for (int b = 0; b < NT; ++b) bcur[b] = sS[b * 64 + lane];
+    for (int i = 0; i < R4; ++i) acc4E[i] = acc4O[i] = 0.0;
+    double bcur[FR];
+#pragma unroll
+    for (int q = 0; q < FR; ++q) bcur[q] = sS[q * 64 + lane];
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
       const d2v_t a = ra[t % PA];
       if (PA < KS) ra[t % PA] = t + PA < KS ? frag(cur, t + PA) : frag(nxt, t + PA - KS);
-      double bnxt[NT];
+      double bnxt[FR];
       if (t + 1 < KS) {
 #pragma unroll
-        for (int b = 0; b < NT; ++b) bnxt[b] = sS[((t + 1) * NT + b) * 64 + lane];
+        for (int q = 0; q < FR; ++q) bnxt[q] = (ABL & 2) ? bcur[q] : sS[((t + 1) * FR + q) * 64 + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < NT; ++b) {
+      for (int b = 0; b < NF; ++b) {
         accE[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bcur[b], accE[b], 0, 0, 0);
         accO[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bcur[b], accO[b], 0, 0, 0);
       }
+#pragma unroll
+      for (int i = 0; i < R4; ++i) {
+        acc4E[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, bcur[NF + i], acc4E[i], 0, 0, 0);
+        acc4O[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, bcur[NF + i], acc4O[i], 0, 0, 0);
+      }
       if (t + 1 < KS) {
 #pragma unroll
-        for (int b = 0; b < NT; ++b) bcur[b] = bnxt[b];
+        for (int q = 0; q < FR; ++q) bcur[q] = bnxt[q];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -626,17 +657,17 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sl2(const double* __restrict__ 
     cur = nxt;
     // results: accE[b][g] = Y[m0 + 2 (lk + 4 g)][col(b, lr)], accO: the row below it
     const int64_t m0 = tile * 32;
-    const bool whole = m0 + 32 <= mdim;  // wave-uniform: only the very last tile can be ragged in rows
+    if ((ABL & 4) && accE[0][0] != 1.2345e300) return;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int64_t rE = m0 + 2 * (lk + 4 * g);
       double* pE = C + rE * ldc;
       double* pO = pE + ldc;
-      const bool okE = whole || rE < mdim, okO = whole || rE + 1 < mdim;
+      const bool okE = WHOLE || rE < mdim, okO = WHOLE || rE + 1 < mdim;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int col = 32 * p + 2 * lr;
-        if (col + 1 < ncols) {
+        if (32 * p + 31 < NVALID || col + 1 < ncols) {
           if (okE) __builtin_nontemporal_store((d2u_t){accE[2 * p][g], accE[2 * p + 1][g]}, reinterpret_cast<d2u_t*>(pE + col));
           if (okO) __builtin_nontemporal_store((d2u_t){accO[2 * p][g], accO[2 * p + 1][g]}, reinterpret_cast<d2u_t*>(pO + col));
         } else if (col < ncols) {
@@ -644,20 +675,44 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sl2(const double* __restrict__ 
           if (okO) __builtin_nontemporal_store(accO[2 * p][g], pO + col);
         }
       }
-      if constexpr (NT & 1) {
-        const int col = 16 * (NT - 1) + lr;
-        if (col < ncols) {
-          if (okE) __builtin_nontemporal_store(accE[NT - 1][g], pE + col);
-          if (okO) __builtin_nontemporal_store(accO[NT - 1][g], pO + col);
+      if constexpr (NF & 1) {
+        const int col = 16 * (NF - 1) + lr;
+        if (16 * NF - 1 < NVALID || col < ncols) {
+          if (okE) __builtin_nontemporal_store(accE[NF - 1][g], pE + col);
+          if (okO) __builtin_nontemporal_store(accO[NF - 1][g], pO + col);
         }
       }
     }
+    if constexpr (R4 > 0) {  // the 4-column panels: D[blk][i][j] sits in lane 16 i + 4 blk + j: tile row 4 blk + i, column c + j
+      const int64_t rE = m0 + 2 * (4 * ((lane >> 2) & 3) + (lane >> 4));
+      double* pE = C + rE * ldc;
+      double* pO = pE + ldc;
+      const bool okE = WHOLE || rE < mdim, okO = WHOLE || rE + 1 < mdim;
+#pragma unroll
+      for (int i = 0; i < R4; ++i) {
+        const int col = 16 * NF + 4 * i + (lane & 3);
+        if (16 * NF + 4 * i + 3 < NVALID || col < ncols) {
+          if (okE) __builtin_nontemporal_store(acc4E[i], pE + col);
+          if (okO) __builtin_nontemporal_store(acc4O[i], pO + col);
+        }
+      }
+    }
+  };
+  const int64_t nfull = mdim / 32;  // whole tiles; at most one more (ragged in rows) follows
+  if (wave < nfull) {
+    do_tile(wave, std::true_type{});
+    ++mytiles;
+    for (int64_t tile = wave + nwaves; tile < nfull; tile += nwaves, ++mytiles) do_tile(tile, std::true_type{});
+  }
+  if (nfull < ntiles && nfull % nwaves == wave) {  // (its fragments are what the ring holds: it is this wave's next tile)
+    do_tile(nfull, std::false_type{});
+    ++mytiles;
   }
   if (rec) {
     clk[0] = clock64() - c0;
     clk[1] = wall_clock64() - t0;
     clk[2] = (unsigned long long)(2 * mytiles);  // in 16-row tiles
-    clk[3] = (unsigned long long)(NT * KS * NW);
+    clk[3] = (unsigned long long)((4 * NF + R4) * KS * 2);  // x 16 = the SIMD's matrix-pipe cycles per 16-row tile of each of its two waves
   }
   if (clk != nullptr && lane == 0) {
     const unsigned long long now = wall_clock64();
@@ -951,29 +1006,34 @@ static bool sl_dispatch(const double* V, int64_t ldv, int64_t rows, int n, const
   return false;
 }
 
-template <int NT, int KS>
+template <int NT, int KS, bool USE4 = true>
 static hipError_t launch_sl2(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
                              hipStream_t s, unsigned long long* clk) {
-  constexpr size_t lds = (size_t)KS * NT * 64 * sizeof(double);
+  constexpr int R4 = (4 * NT == KS || !USE4) ? 0 : KS - 4 * (NT - 1);
+  constexpr size_t lds = (size_t)KS * ((R4 ? NT - 1 : NT) + R4) * 64 * sizeof(double);
   static hipError_t attr = hipErrorNotReady;
   if (attr == hipErrorNotReady)
-    attr = lds > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_sl2<NT, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    attr = lds > 65536 ? hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_sl2<NT, KS, 0, USE4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                        : hipSuccess;
   if (attr != hipSuccess) return attr;
   const int64_t ntiles = (rows + 31) / 32;
   const int grid = (int)std::min<int64_t>(kNumCU, (ntiles + 7) / 8);
-  hipLaunchKernelGGL((k_gemm_tn_sl2<NT, KS>), dim3(grid), dim3(512), lds, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy, clk);
+  hipLaunchKernelGGL((k_gemm_tn_sl2<NT, KS, 0, USE4>), dim3(grid), dim3(512), lds, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy, clk);
   return hipSuccess;
 }
 
+// The ragged last column tile runs on the 4x4x4 MFMA (USE4) only for NT >= 7 (n >= 97), where the kernel is bound by the
+// matrix pipe: measured in one process (profiles/r03), n = 100: 0.394 vs 0.416 ms, n = 117: 0.566 vs 0.610 ms with it; but
+// n = 37 / 50 / 70, which are bound by HBM: 0.216 / 0.237 / 0.349 ms with it against 0.181 / 0.200 / 0.279 ms without - a
+// 4-column panel is stored in 32-byte pieces (16 rows x 4 columns per instruction), partial sectors on the write side.
 static bool sl2_dispatch(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
                          hipStream_t s, unsigned long long* clk, hipError_t* err) {
   const int NT = (n + 15) / 16;
   const int KS = (n + 3) / 4;
-#define LZ_SL(nt, ks)                                                            \
-  if (NT == nt && KS == ks) {                                                    \
-    *err = launch_sl2<nt, ks>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk);       \
-    return true;                                                                 \
+#define LZ_SL(nt, ks)                                                                     \
+  if (NT == nt && KS == ks) {                                                             \
+    *err = launch_sl2<nt, ks, (nt >= 7)>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk);     \
+    return true;                                                                          \
   }
 #define LZ_SL4(nt) LZ_SL(nt, 4 * nt - 3) LZ_SL(nt, 4 * nt - 2) LZ_SL(nt, 4 * nt - 1) LZ_SL(nt, 4 * nt)
   LZ_SL4(1) LZ_SL4(2) LZ_SL4(3) LZ_SL4(4) LZ_SL4(5) LZ_SL4(6) LZ_SL4(7) LZ_SL4(8)
@@ -1005,6 +1065,25 @@ static bool sreg_dispatch(const double* V, int64_t ldv, int64_t rows, int n, con
 static bool kbench_ritz_arm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
                             hipStream_t s, int variant, hipError_t* err) {
   *err = hipSuccess;
+  if (variant >= 30 && variant < 38 && n == 100) {  // timing-only arms of the S-in-LDS kernel: bit 0 no V loads, 1 no LDS reads, 2 no stores
+    constexpr size_t lds = (size_t)25 * 7 * 64 * sizeof(double);
+    auto go = [&](auto kern) {
+      *err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (*err == hipSuccess)
+        hipLaunchKernelGGL(kern, dim3(kNumCU), dim3(512), lds, s, V, ldv, rows, n, Spad, (int64_t)npad, n, Y, ldy, (unsigned long long*)nullptr);
+    };
+    switch (variant - 30) {
+      case 1: go(k_gemm_tn_sl2<7, 25, 1>); break;
+      case 2: go(k_gemm_tn_sl2<7, 25, 2>); break;
+      case 3: go(k_gemm_tn_sl2<7, 25, 3>); break;
+      case 4: go(k_gemm_tn_sl2<7, 25, 4>); break;
+      case 5: go(k_gemm_tn_sl2<7, 25, 5>); break;
+      case 6: go(k_gemm_tn_sl2<7, 25, 6>); break;
+      case 7: go(k_gemm_tn_sl2<7, 25, 7>); break;
+      default: go(k_gemm_tn_sl2<7, 25, 0>); break;
+    }
+    return true;
+  }
   const int CT = (n + 15) / 16;
   const int64_t ntiles = (rows + 31) / 32;
   if (variant < 2 || variant == 5 || CT > 16 || ntiles < 2 * kNumCU * (kTPB / 64)) return false;
