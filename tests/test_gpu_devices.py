@@ -197,3 +197,27 @@ def test_bench_self_spawn_two_ranks_on_one_gpu():
     assert line["comm_calls_per_step"] == 3 * 100 + 2  # (k + 1) exchanges + (k + 1) alpha all-reduces + k coefficient all-reduces
     assert line["partial_reorth"] is not None and line["one_reduce_arm"] is not None  # both extra arms ran
     assert "stalled" not in line and line["value"] > 0 and line["roofline"]["kernel"] in ("qtw", "update", "spmv")
+
+
+def test_a_dying_worker_ends_the_pool_and_is_reported():
+    """A rank that dies mid-life (here: killed) must surface as an exception in the caller - its peers would otherwise sit in a
+    collective forever - with every other worker terminated; a fresh `execute_Lanczos` on the object starts a new pool."""
+    Lanczos.verbose = False
+    H = synthetic.laplacian_2d_5pt(96, 80).to_scipy()
+    s = Lanczos(H)
+    s.devices = [0, 0]
+    s.comm_backend = "host"
+    s.execute_Lanczos(20)
+    H_eff = s.H_eff.copy()
+    pool = s._handle.pool
+    pool.procs[1].kill()
+    pool.procs[1].wait()
+    import lanczos_amd
+
+    with pytest.raises(lanczos_amd.LanczosHipError, match="rank 1"):
+        s.execute_Lanczos(20)
+    assert pool.closed and all(p.poll() is not None for p in pool.procs)
+    s.close()
+    s.execute_Lanczos(20)  # a new pool
+    assert s._handle.pool is not pool and np.array_equal(s.H_eff, H_eff)
+    s.close()

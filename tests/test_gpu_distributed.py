@@ -70,6 +70,18 @@ WORKER = textwrap.dedent('''
         qual = s.ritz_quality() if name in ("lap2d", "graph", "dense", "lap3d") else None  # collective; restores basis row 0
         if qual is not None:
             assert np.array_equal(s.V_local, V)
+        chunked = None
+        if name in ("lap2d", "graph"):
+            # the CHUNKED Ritz mode on a row-block partition (what a rank does when a second rows x n array does not fit beside its
+            # basis): Y re-formed in 512-row chunks, Gram matrix accumulated per chunk and all-reduced, quality sums from column batches
+            G0 = s.h.ritz_gram()
+            s.h.set_tuning(16, 512)
+            s.get_H_eigs()
+            Yc, Gc, qc = s.H_eigvecs_local, s.h.ritz_gram(), s.ritz_quality()
+            chunked = dict(rows=s.h.ritz_info()["chunk_rows"], dY=float(np.abs(Yc - Y).max()), dG=float(np.abs(Gc - G0).max()),
+                           dq=float(np.abs(qc - qual).max()), basis_ok=bool(np.array_equal(s.V_local, V)))
+            s.h.set_tuning(16, 0)
+            s.get_H_eigs()
         # single-rank oracle on the full matrix
         full = build(0, M)
         full = full.to_scipy() if hasattr(full, "to_scipy") else __import__("scipy.sparse").sparse.csr_matrix(full)
@@ -90,7 +102,7 @@ WORKER = textwrap.dedent('''
                          scale=float(max(np.abs(ao).max(), np.abs(bo).max())),
                          dV=float(np.abs(V[:, :8] - Vo[:8, lo:hi].T).max() / np.abs(Vo[:8]).max()), dY=float(np.abs(Y - V @ S).max()),
                          orth=float(np.abs(boot.allreduce_sum(V.T @ V) - np.eye(n)).max()),
-                         comm_launches=comm_launches, sweeps=sweeps, n=n, device_built_equal=device_built_equal, dq=dq)
+                         comm_launches=comm_launches, sweeps=sweeps, n=n, device_built_equal=device_built_equal, dq=dq, chunked=chunked)
     res = boot.allgather_obj(out)
     if boot.rank == 0:
         import json
@@ -122,6 +134,9 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
         assert per_rank["c4_slab_k200"]["device_built_equal"] is True
         for name in ("lap2d", "graph", "dense", "lap3d"):  # lz_ritz_quality on the row-block partition (halo, all-gather, dense)
             assert per_rank[name]["dq"] is not None and per_rank[name]["dq"] < 1e-12, (name, per_rank[name])
+        for name in ("lap2d", "graph"):  # the chunked Ritz mode on the partition (halo and all-gather exchange of the column batches)
+            c = per_rank[name]["chunked"]
+            assert c["rows"] == 512 and c["dY"] < 1e-13 and c["dG"] < 1e-13 and c["dq"] < 1e-12 and c["basis_ok"], (name, c)
         # (graph_twophase: same y bits as "graph", but alpha's partial sums are grouped by the kernel's own row blocks, so the
         # coefficients agree to rounding, not bit for bit: held to the same tolerances below)
         assert per_rank["c4_slab_k200"]["prefix"] >= 100 and per_rank["c5_k500"]["prefix"] >= 300, per_rank
