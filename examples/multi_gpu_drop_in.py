@@ -5,10 +5,12 @@
 With more than one GPU id the calling process never touches a GPU: it spawns one worker per id (lanczos_amd/_pool.py), each
 assembles its own slab of H = -T + V on its device (the matrix never exists on the host) and the row-block-partitioned solver
 runs over RCCL."""
+import os
 import sys
 
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
 from lanczos_amd import Hamiltonian, Lanczos, synthetic
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 48
