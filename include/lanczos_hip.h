@@ -220,6 +220,17 @@ int lz_set_allgather(lz_handle h, int64_t chunk);
  * beta_out[n-1] (n >= 2) receive the recurrence coefficients (replicated on all
  * ranks); beta follows the reference's indexing (beta[j-1] set at step j). */
 int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double* beta_out);
+/* ---- checkpoint / resume (SURVEY.md section 5 hook; nothing to mirror: the reference keeps no solver state on disk) ----
+ * After lz_run(h, n1, ...) the state (V[0..n1), r, alpha[0..n1), beta[0..n1-1)) is everything the recurrence needs to go on at
+ * step n1: lz_get_basis / lz_get_residual + the coefficient arrays are a checkpoint.  lz_get_residual: r = H v_{n1-1} -
+ * alpha_{n1-1} v_{n1-1} - beta_{n1-2} v_{n1-2} (Lanczos.py:119 after the last step), this rank's rows.
+ * lz_run_resume continues such a run to n > j0 steps in total: V_rows is (j0, rows_local) row-major with leading dimension
+ * ldv_in, alpha_in has j0 and beta_in j0 - 1 entries.  Steps j0 .. n-1 run on the plain six-launch loop (every loop
+ * structure produces the same bits), so alpha_out[n], beta_out[n-1] and the basis equal those of an uninterrupted
+ * lz_run(h, n, ...) BIT FOR BIT (same options).  Not with LZ_FLAG_REORTH_PARTIAL / LZ_FLAG_ONE_REDUCE (LZ_ERR_STATE). */
+int lz_get_residual(lz_handle h, double* r_local);
+int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_in, const double* r_local, const double* alpha_in,
+                  const double* beta_in, double* alpha_out, double* beta_out);
 /* Krylov basis, row-major (n, rows_local): basis vector j is row j
  * (replaces cp.asnumpy(V.T), Lanczos.py:136; the mirror exposes the transposed view). */
 int lz_get_basis(lz_handle h, double* V_out, int64_t ld);

@@ -85,6 +85,8 @@ SIGNATURES = {
     "lz_set_halo": (C.c_int, [_P, C.c_int, _I32, _I64, _I32, _I64]),
     "lz_set_allgather": (C.c_int, [_P, C.c_int64]),
     "lz_run": (C.c_int, [_P, C.c_int, _D, _D, _D]),
+    "lz_get_residual": (C.c_int, [_P, _D]),
+    "lz_run_resume": (C.c_int, [_P, C.c_int, C.c_int, _D, C.c_int64, _D, _D, _D, _D, _D]),
     "lz_get_basis": (C.c_int, [_P, _D, C.c_int64]),
     "lz_get_basis_block": (C.c_int, [_P, C.c_int64, C.c_int64, _D, C.c_int64]),
     "lz_ritz_vectors": (C.c_int, [_P, _D, _D]),
@@ -444,6 +446,28 @@ class Handle:
             self.check(st)
         self.n = n
         return alpha, beta[: n - 1]
+
+    def get_residual(self):
+        """r entering step n of the last run (this rank's rows): with the basis and alpha / beta, a checkpoint"""
+        r = np.empty(self.rows)
+        self.check(self.lib.lz_get_residual(self._h, dptr(r)))
+        return r
+
+    def run_resume(self, n, V_rows, r, alpha, beta):
+        """continue a run of j0 = len(V_rows) completed steps to n steps in total; returns the full alpha (n), beta (n - 1)"""
+        V_rows, r, alpha, beta = f64(V_rows), f64(r), f64(alpha), f64(beta)
+        j0 = V_rows.shape[0]
+        if V_rows.shape != (j0, self.rows) or r.shape != (self.rows,) or alpha.shape != (j0,) or beta.shape != (max(j0 - 1, 0),):
+            raise ValueError("checkpoint arrays have the wrong shapes")
+        a_out, b_out = np.zeros(n), np.zeros(max(n - 1, 1))
+        if beta.size == 0:
+            beta = np.zeros(1)
+        st = self.lib.lz_run_resume(self._h, int(n), int(j0), dptr(V_rows), self.rows, dptr(r), dptr(alpha), dptr(beta), dptr(a_out), dptr(b_out))
+        self.breakdown = st == LZ_WARN_BREAKDOWN
+        if not self.breakdown:
+            self.check(st)
+        self.n = n
+        return a_out, b_out[: n - 1]
 
     def get_basis(self):
         V = np.empty((self.n, self.rows))

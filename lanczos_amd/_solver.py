@@ -288,6 +288,64 @@ class LanczosBase:
         self._say("+++ Lanczos executed successfully.")
         self.Lanczos_has_been_executed = True
 
+    # ------------------------------------------------------------------ checkpoint / resume (extension; SURVEY.md section 5 hook)
+    def checkpoint(self):
+        """The state a finished run of n steps leaves behind - enough to continue it later with ``resume_Lanczos``:
+        ``{"alpha" (n), "beta" (n - 1), "V" (n, M) row-major, "r" (M), "M", "fused_norm"}``.  One GPU only."""
+        if not self.Lanczos_has_been_executed:
+            raise ValueError(_NOT_EXECUTED)
+        if self._multi():
+            raise NotImplementedError("checkpoint / resume runs on one GPU (devices must be None or a single entry)")
+        h = self._handle
+        return {"alpha": self._alpha.copy(), "beta": self._beta.copy(), "V": h.get_basis(), "r": h.get_residual(), "M": self.M,
+                "fused_norm": bool(self.fused_norm)}
+
+    def save_checkpoint(self, path):
+        np.savez(path, **self.checkpoint())
+
+    def resume_Lanczos(self, n, checkpoint):
+        """Continue the run stored in ``checkpoint`` (a dict from ``checkpoint()`` or the path of a ``save_checkpoint`` file) to
+        ``n`` steps in total.  The result - ``H_eff``, ``V``, Ritz pairs - is bit-identical to ``execute_Lanczos(n)`` run in one go
+        with the same start vector (tests/test_gpu_lanczos.py)."""
+        ck = dict(np.load(checkpoint, allow_pickle=False)) if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__") else checkpoint
+        j0 = len(ck["alpha"])
+        if int(ck["M"]) != self.M:
+            raise ValueError("the checkpoint belongs to a matrix of another size")
+        if n > self.M:
+            raise ValueError("n cannot be larger than M!")
+        if n <= j0:
+            raise ValueError("resume_Lanczos: n must exceed the %d steps already in the checkpoint" % j0)
+        if self._multi():
+            raise NotImplementedError("checkpoint / resume runs on one GPU (devices must be None or a single entry)")
+        if self.reorth != "full":
+            raise NotImplementedError("resume needs reorth='full' (the partial mode's omega-recurrence is not part of the checkpoint)")
+        self._say("+++ Executing Lanczos algorithm")
+        self.n = n
+        self.fused_norm = bool(ck["fused_norm"])
+        h = self._get_handle()
+        h.set_options(self.options | (_capi.FLAG_FUSED_NORM if self.fused_norm else 0))
+        self._upload_matrix(h)
+        alpha, beta = h.run_resume(n, ck["V"], ck["r"], ck["alpha"], ck["beta"])
+        if h.breakdown:
+            import warnings
+
+            warnings.warn("Lanczos breakdown: a residual norm beta reached zero (invariant subspace)", RuntimeWarning, stacklevel=2)
+        self._timings = h.timings()
+        self.sweeps = h.last_sweeps()
+        H_eff = np.zeros((n, n))
+        idx = np.arange(n)
+        H_eff[idx, idx] = alpha
+        H_eff[idx[:-1], idx[1:]] = beta
+        H_eff[idx[1:], idx[:-1]] = beta
+        self._alpha, self._beta, self._H_eff = alpha, beta, H_eff
+        self._V = None
+        self._H_eigvecs_host = None
+        if not (hasattr(self.H, "dims") and hasattr(self.H, "points")):
+            self.H = scipy.sparse.csr_matrix(self.H.to_scipy() if hasattr(self.H, "to_scipy") else self.H, dtype=np.float64)
+        self.H_eigs_have_been_found = False
+        self._say("+++ Lanczos executed successfully.")
+        self.Lanczos_has_been_executed = True
+
     def _ritz(self, checks):
         if not self.Lanczos_has_been_executed:
             raise ValueError(_NOT_EXECUTED)

@@ -180,7 +180,8 @@ struct lz_context {
   hipEvent_t run_a = nullptr, run_b = nullptr;
   bool run_timed = false;
   int last_sweeps = 0;
-  int last_engine = 0;  // 1: the last lz_run went through the small-problem engine (one cooperative kernel)
+  int last_engine = 0;  // which loop ran last (enum Loop)
+  int r_state = 0;      // what d_r holds after the last run: 0 nothing usable, 1 the residual entering step n, 2 y = A v_{n-1} (three-term pending)
   double* h_pinned = nullptr;  // 8 pinned doubles for the per-step scalar read-back of the partial-reorth mode
   bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
   lz_timings acc;
@@ -836,11 +837,18 @@ Loop choose_loop(lz_handle h, int n) {
 
 // ---- the plain loop: six launches per step (pass 1, second-stage sums, pass 2, SpMV, alpha sum, three-term), with the
 // opt-in partial re-orthogonalisation (Simon's omega-recurrence on the host) --------------------------------------------
-int run_loop_six(lz_handle h, int n, int* sweeps_out) {
-  // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
-  LZ_TRY(step_spmv(h, 0));
+int run_loop_six(lz_handle h, int n, int* sweeps_out, int j0 = 0) {
   const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL);
-  LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
+  if (j0 == 0) {
+    // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
+    LZ_TRY(step_spmv(h, 0));
+    LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
+  } else if (!fused) {
+    // resumed run (lz_run_resume): steps 0 .. j0-1 are in the basis, r is the residual entering step j0; the scale-then-dot order
+    // wants ||r||^2 in d_nrm2: r = r - 0 * V[0] leaves r unchanged bit for bit and refreshes it
+    LZ_HIP(h, hipMemsetAsync(h->d_c + n, 0, sizeof(double), h->stream));
+    LZ_TRY(step_three_term(h, 0, -1, h->d_c + n, nullptr, true));
+  }
   const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
   const bool partial = (h->flags & LZ_FLAG_REORTH_PARTIAL) != 0;
   // Partial re-orthogonalisation (opt-in): Simon's omega-recurrence on the host, fed with alpha_j and beta_{j+1}
@@ -862,7 +870,7 @@ int run_loop_six(lz_handle h, int n, int* sweeps_out) {
   bool force_next = false;
   double normA = 0.0;
   int sweeps = 0;
-  for (int j = 0; j < n; ++j) {
+  for (int j = j0; j < n; ++j) {
     h->prof_iter = (j % pstride) == pstride / 2;  // centred sample: same mean j as the full run
     const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
     bool sweep = true;
@@ -914,6 +922,35 @@ int run_loop_six(lz_handle h, int n, int* sweeps_out) {
     }
   }
   *sweeps_out = sweeps;
+  return LZ_OK;
+}
+
+// Breakdown report.  The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov
+// space gives it a residual of rounding noise (or an exact zero and then inf/NaN), and it carries on.  So does this
+// run - the coefficients are delivered exactly as computed - but the status says so: a beta at or below 64 eps times
+// the scale of T (max |alpha|, |beta|), or any non-finite coefficient.  beta[n-2] is also where step j = 0 parks its
+// norm before step n-1 overwrites it, so every entry of beta_out has been a divisor.
+int breakdown_status(lz_handle h, int n, const double* alpha_out, const double* beta_out) {
+  double tscale = 0.0;
+  for (int j = 0; j < n; ++j) {
+    if (std::isfinite(alpha_out[j])) tscale = std::max(tscale, std::fabs(alpha_out[j]));
+    if (j < n - 1 && std::isfinite(beta_out[j])) tscale = std::max(tscale, std::fabs(beta_out[j]));
+  }
+  const double tiny = 64.0 * 2.220446049250313e-16 * tscale;
+  for (int j = 0; j < n; ++j) {
+    const bool bad_a = !std::isfinite(alpha_out[j]);
+    const bool bad_b = j < n - 1 && !(std::isfinite(beta_out[j]) && beta_out[j] > tiny);
+    if (bad_a || bad_b) {
+      char msg[200];
+      if (bad_b && std::isfinite(beta_out[j]))
+        snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - beta[%d] = %.3e <= 64 eps * %.3e: the Krylov space is exhausted, later vectors are rounding noise",
+                 j, beta_out[j], tscale);
+      else
+        snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - %s[%d] is not finite (a residual norm reached zero)", bad_b ? "beta" : "alpha", j);
+      h->err = msg;
+      return LZ_WARN_BREAKDOWN;
+    }
+  }
   return LZ_OK;
 }
 
@@ -1703,6 +1740,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     default: LZ_TRY(run_loop_six(h, n, &sweeps)); break;
   }
   h->last_sweeps = sweeps;
+  h->r_state = (h->last_engine == LOOP_SIX) ? 1 : (h->last_engine == LOOP_FUSED_SMALL || h->last_engine == LOOP_THREE_TERM_FUSED) ? 2 : 0;
   h->prof_iter = true;
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
   const double t3 = now();
@@ -1733,32 +1771,62 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     h->acc.total_ms += ms;
     h->run_timed = false;
   }
-  // Breakdown report.  The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov
-  // space gives it a residual of rounding noise (or an exact zero and then inf/NaN), and it carries on.  So does this
-  // run - the coefficients are delivered exactly as computed - but the status says so: a beta at or below 64 eps times
-  // the scale of T (max |alpha|, |beta|), or any non-finite coefficient.  beta[n-2] is also where step j = 0 parks its
-  // norm before step n-1 overwrites it, so every entry of beta_out has been a divisor.
-  double tscale = 0.0;
-  for (int j = 0; j < n; ++j) {
-    if (std::isfinite(alpha_out[j])) tscale = std::max(tscale, std::fabs(alpha_out[j]));
-    if (j < n - 1 && std::isfinite(beta_out[j])) tscale = std::max(tscale, std::fabs(beta_out[j]));
+  return breakdown_status(h, n, alpha_out, beta_out);
+}
+
+/* ---- checkpoint / resume ("Optional: dump (alpha, beta, j, V[:j])") ---------------------------------- */
+int lz_get_residual(lz_handle h, double* r_local) {
+  if (!h || !r_local) return LZ_ERR_ARG;
+  LZ_TRY(require_basis(h, 0));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  const int n = h->n;
+  if (h->r_state == 2) {
+    // the three- / five-launch loops leave y = A v_{n-1} behind: their three-term recurrence rides in the NEXT step's pass 1.
+    // Form r = (y - alpha_{n-1} v_{n-1}) - beta_{n-2} v_{n-2} now, with the same kernel and expression (Lanczos.py:119).
+    Scope sc(h, LZ_K_THREE, 32.0 * (double)h->rows, 6.0 * (double)h->rows);
+    launch_three_term(h->d_r, h->d_V + (int64_t)(n - 1) * h->ldv, n >= 2 ? h->d_V + (int64_t)(n - 2) * h->ldv : nullptr, h->d_alpha + (n - 1),
+                      h->d_beta + (n >= 2 ? n - 2 : 0), h->rows_pad, h->d_part, h->stream);
+    LZ_TRY(check_launch(h, "three_term(residual)"));
+    h->r_state = 1;
   }
-  const double tiny = 64.0 * 2.220446049250313e-16 * tscale;
-  for (int j = 0; j < n; ++j) {
-    const bool bad_a = !std::isfinite(alpha_out[j]);
-    const bool bad_b = j < n - 1 && !(std::isfinite(beta_out[j]) && beta_out[j] > tiny);
-    if (bad_a || bad_b) {
-      char msg[200];
-      if (bad_b && std::isfinite(beta_out[j]))
-        snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - beta[%d] = %.3e <= 64 eps * %.3e: the Krylov space is exhausted, later vectors are rounding noise",
-                 j, beta_out[j], tscale);
-      else
-        snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - %s[%d] is not finite (a residual norm reached zero)", bad_b ? "beta" : "alpha", j);
-      h->err = msg;
-      return LZ_WARN_BREAKDOWN;
-    }
-  }
+  if (h->r_state != 1)
+    return fail(h, LZ_ERR_STATE, "lz_get_residual: the last run left no residual (run lz_run first; not after the one-reduce loop or lz_run_two_sided)");
+  LZ_HIP(h, hipMemcpyAsync(r_local, h->d_r, (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
   return LZ_OK;
+}
+
+int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_in, const double* r_local, const double* alpha_in,
+                  const double* beta_in, double* alpha_out, double* beta_out) {
+  if (!h) return LZ_ERR_ARG;
+  if (!V_rows || !r_local || !alpha_in || !beta_in || !alpha_out || !beta_out) return fail(h, LZ_ERR_ARG, "lz_run_resume: NULL buffer");
+  if (j0 < 1 || n <= j0) return fail(h, LZ_ERR_ARG, "lz_run_resume: need 1 <= j0 < n (j0 completed steps, n in total)");
+  if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run_resume: n cannot be larger than M");
+  if (ldv_in < h->rows) return fail(h, LZ_ERR_ARG, "lz_run_resume: ldv_in < rows_local");
+  if (h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE))
+    return fail(h, LZ_ERR_STATE, "lz_run_resume: not with partial re-orthogonalisation (its omega-recurrence lives on the host) or the one-reduce loop");
+  LZ_TRY(basis_alloc(h, n, 1));
+  h->halo_inflight_j = -1;
+  LZ_HIP(h, hipMemcpy2DAsync(h->d_V, (size_t)h->ldv * sizeof(double), V_rows, (size_t)ldv_in * sizeof(double), (size_t)h->rows * sizeof(double),
+                             (size_t)j0, hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(h->d_r, r_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(h->d_alpha, alpha_in, (size_t)j0 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (j0 > 1) LZ_HIP(h, hipMemcpyAsync(h->d_beta, beta_in, (size_t)(j0 - 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+  int sweeps = n - j0;
+  h->last_engine = LOOP_SIX;  // every loop structure gives the same bits (tests/test_gpu_small.py): the plain one takes a start step
+  LZ_TRY(run_loop_six(h, n, &sweeps, j0));
+  h->last_sweeps = sweeps;
+  h->r_state = 1;
+  h->prof_iter = true;
+  LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
+  h->acc.total_ms += ms;
+  return breakdown_status(h, n, alpha_out, beta_out);
 }
 
 // ---- two-sided (bi-orthogonal) Lanczos ------------------------------------------------------------------------------

@@ -582,3 +582,43 @@ def test_one_reduce_cancellation_guard(hip):
             assert np.array_equal(a0, a1) and np.array_equal(b0, b1)  # the repeat IS the default loop
         else:
             assert np.abs(a1 - a0).max() < 1e-11 and np.abs(b1 - b0).max() < 1e-11
+
+
+@pytest.mark.parametrize("build,n1,n2", [(lambda: synthetic.laplacian_2d_5pt(64, 48).to_scipy(), 10, 31),             # three-launch loop
+                                         (lambda: synthetic.laplacian_3d_7pt(40, 30, 20).to_scipy(), 17, 40),         # five-launch loop
+                                         (lambda: synthetic.random_graph_laplacian(50000, 175000, seed=3).to_scipy(), 2, 12),
+                                         (lambda: synthetic.dense_symmetric(700, seed=2), 25, 26)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_checkpoint_and_resume_is_bit_identical(tmp_path, build, n1, n2, fused):
+    """SURVEY.md section 5 hook: (alpha, beta, j, V[:j]) + the residual is a checkpoint; `resume_Lanczos` continues it.  A run of
+    n1 steps, saved, loaded into a NEW object and continued to n2 steps gives H_eff, V and the Ritz values of an uninterrupted
+    n2-step run bit for bit - whichever loop structure (three / five / six launches per step) the uninterrupted run used."""
+    H = build()
+    Lanczos.verbose = False
+    whole = Lanczos(H)
+    whole.fused_norm = fused
+    whole.execute_Lanczos(n2)
+    first = Lanczos(H)
+    first.fused_norm = fused
+    first.execute_Lanczos(n1)
+    assert np.array_equal(np.diag(first.H_eff)[: n1 - 1], np.diag(whole.H_eff)[: n1 - 1])  # (the last alpha of a run is final too)
+    path = str(tmp_path / "ck.npz")
+    first.save_checkpoint(path)
+    ck = first.checkpoint()
+    assert ck["V"].shape == (n1, H.shape[0]) and ck["r"].shape == (H.shape[0],) and len(ck["beta"]) == n1 - 1
+    first.close()
+    second = Lanczos(H)
+    second.resume_Lanczos(n2, path)
+    assert second._handle.last_engine() == "kernels"
+    assert np.array_equal(second.H_eff, whole.H_eff)
+    assert np.array_equal(second.V, whole.V)
+    assert np.array_equal(second.H_eigvals, whole.H_eigvals)
+    third = Lanczos(H)  # from the in-memory dict, and the resumed run can itself be checkpointed
+    third.resume_Lanczos(n2, ck)
+    assert np.array_equal(third.H_eff, whole.H_eff)
+    r2 = third.checkpoint()["r"]
+    assert np.array_equal(r2, whole.checkpoint()["r"])
+    with pytest.raises(ValueError, match="must exceed"):
+        third.resume_Lanczos(n1, ck)
+    for s in (whole, second, third):
+        s.close()
