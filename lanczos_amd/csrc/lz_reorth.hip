@@ -247,6 +247,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
   if ((ABL & 1) && sink == 1.2345e300) part[0] = sink;
 }
 
+#ifdef LZ_KBENCH  // retired A/B arm (LZ_FLAG_QTW_MFMA: 20 % slower than the 4x4x4 kernel): kernel-bench build only
 // MFMA variant.  Lane l of a wave: row r = l & 15 of the current 16-row tile,
 // k-group g = l >> 4.  Step s covers 8 consecutive elements of the slice
 // (64 B per row): the lane loads the double2 at element 8*s + 2*g of its row;
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
     }
   }
 }
+
+#endif  // LZ_KBENCH
 
 // MFMA variant 2: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction).  Lane layout measured on
 // gfx950 (tools/probes/mfma_f64_4x4x4_layout.hip): A[blk][i][k] lives in lane 16k + 4blk + i, B[blk][k][j] in lane
@@ -608,6 +611,7 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
     return err;
   }
   if constexpr (SCALE == 3 || SCALE == 4) return hipErrorInvalidValue;  // these modes exist for the default (4x4x4 MFMA) family only
+#ifdef LZ_KBENCH
   if constexpr (SCALE != 2 && SCALE != 3 && SCALE != 4) {
     if (plan.family == 1) {
       switch (plan.variant) {
@@ -619,6 +623,9 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
       return hipSuccess;
     }
   }
+#else
+  if (plan.family == 1) return hipErrorInvalidValue;  // (lz_set_options refuses LZ_FLAG_QTW_MFMA in the product library)
+#endif
   switch (plan.variant) {
     case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
     case 7: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 0>), grid, block, lds, s, LZ_QTW_ARGS); break;  // plain (cached) loads

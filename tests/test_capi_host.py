@@ -202,6 +202,16 @@ def test_product_library_has_no_ablation_kernels():
     assert not re.search(rb"k_qtw_mfma4ILi\d+ELi\d+ELi\d+ELi[1-9]\d*EE", blob)
     assert not re.search(rb"k_qtw_valuILi\d+ELi\d+ELi\d+ELi\d+ELi[1-9]\d*EE", blob)
     assert not re.search(rb"k_spmv_streamILi\d+ELi[1-9]\d*EE", blob)
+    # round 3: the S-in-LDS Ritz kernel's timing-only arms, and the RETIRED A/B arms (measured slower; kernel-bench build only)
+    assert re.search(rb"k_gemm_tn_sl2ILi\d+ELi\d+ELi0ELb[01]EE", blob), "S-in-LDS Ritz kernel not found - naming changed?"
+    assert not re.search(rb"k_gemm_tn_sl2ILi\d+ELi\d+ELi[1-9]", blob)
+    assert not re.search(rb"k_gemm_tn_sregILi\d+ELi\d+ELi[1-9]", blob)
+    for retired in (rb"k_small_run", rb"k_small_step", rb"k_gemm_tn_persist", rb"k_gemm_tn_ldsI", rb"k_qtw_mfmaILi"):
+        assert retired not in blob, retired
+    if os.path.isfile(_capi.KBENCH_LIB_PATH):  # ... which the kernel-bench build still carries
+        kblob = open(_capi.KBENCH_LIB_PATH, "rb").read()
+        for retired in (rb"k_small_run", rb"k_gemm_tn_persist", rb"k_gemm_tn_ldsI", rb"k_qtw_mfmaILi"):
+            assert retired in kblob, retired
     lib = lanczos_amd.load_library()
     assert lib.lz_set_tuning(None, 1, 21) == -1  # (no handle on a CPU box; with one: tests/test_gpu_kernels.py)
 
