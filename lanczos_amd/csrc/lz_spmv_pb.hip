@@ -192,23 +192,81 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
   const int cb = blockIdx.x;
   const int64_t c0 = (int64_t)cb * W;
   const int wn = (int)(ncols - c0 < W ? ncols - c0 : W);
-  // W and c0 are multiples of 32: whole double2 lanes except possibly the very last pair of the vector
+  // W and c0 are multiples of 32: whole double2 lanes except possibly the very last pair of the vector.
+  // The column block of v -> LDS with ALL of a thread's loads in flight before its first LDS store (W <= 19 968 doubles: at most
+  // ten 16-byte loads per thread); as a load -> wait -> store loop this was ten dependent round trips per workgroup (round 3).
   {
+    constexpr int NX = (kPbMaxW / 2 + kPbThreads - 1) / kPbThreads;
     const double2* x2 = reinterpret_cast<const double2*>(x + c0);
     double2* s2 = reinterpret_cast<double2*>(xs);
     const int n2 = wn >> 1;
-    for (int i = threadIdx.x; i < n2; i += kPbThreads) s2[i] = x2[i];
+    double2 tmp[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = threadIdx.x + i * kPbThreads;
+      tmp[i] = q < n2 ? x2[q] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int q = threadIdx.x + i * kPbThreads;
+      if (q < n2) s2[q] = tmp[i];
+    }
     if ((wn & 1) && threadIdx.x == 0) xs[wn - 1] = x[c0 + wn - 1];
   }
   __syncthreads();
   const int64_t p0 = (int64_t)cbptr[cb] >> 1, p1 = (int64_t)cbptr[cb + 1] >> 1;  // stream positions are multiples of 8
   const uint32_t* pc2 = reinterpret_cast<const uint32_t*>(pcol);
-  for (int64_t pb = p0 + threadIdx.x; pb < p1; pb += (int64_t)U * kPbThreads) {
+  constexpr int64_t B = (int64_t)U * kPbThreads;  // pairs per batch
+  // One batch: lane p takes the pairs p, p + 1024, ...: a value pair, a column pair, the destination of its group of 8.
+  // FULL batches are unconditional and software-pipelined - the loads of batch b + 1 are issued BEFORE the scattered stores of
+  // batch b - for the sake of the wait counts: vmcnt counts loads and stores alike, in issue order, so a load issued after a
+  // store cannot be waited for without waiting for that store's acknowledgement from HBM first (a non-temporal, scattered
+  // 64-byte sector: microseconds).  In the old loop every batch sat that out (s_waitcnt vmcnt(0) once per batch).
+  auto load = [&](int64_t base, double2 (&a)[U], uint32_t (&c)[U], uint32_t (&d)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = base + (int64_t)u * kPbThreads;
+      a[u] = pb_ld_vals(pvals, p);
+      c[u] = __builtin_nontemporal_load(pc2 + p);
+      d[u] = __builtin_nontemporal_load(gdst + (p >> (kPbPadLog - 1)));
+    }
+  };
+  auto store = [&](int64_t base, const double2 (&a)[U], const uint32_t (&c)[U], const uint32_t (&d)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = base + (int64_t)u * kPbThreads;
+      // streamed once, read back by phase 2 from HBM: non-temporal
+      st_stream<1>(reinterpret_cast<double2*>(T2 + d[u] + (((uint32_t)p & (uint32_t)(kPbPad / 2 - 1)) << 1)),
+                   make_double2(a[u].x * xs[c[u] & 0xffffu], a[u].y * xs[c[u] >> 16]));
+    }
+  };
+  const int64_t nfull = (p1 - p0) / B;
+  int64_t base = p0 + threadIdx.x;
+  if (nfull > 0) {
+    double2 a[U], an[U];
+    uint32_t c[U], d[U], cn[U], dn[U];
+    load(base, a, c, d);
+    for (int64_t b = 1; b < nfull; ++b) {
+      load(base + B, an, cn, dn);
+      store(base, a, c, d);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[u] = an[u];
+        c[u] = cn[u];
+        d[u] = dn[u];
+      }
+      base += B;
+    }
+    store(base, a, c, d);
+    base += B;
+  }
+  // the ragged rest (less than one batch)
+  {
     double2 a[U];
     uint32_t c[U], d[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t p = pb + (int64_t)u * kPbThreads;
+      const int64_t p = base + (int64_t)u * kPbThreads;
       const bool ok = p < p1;
       a[u] = ok ? pb_ld_vals(pvals, p) : make_double2(0.0, 0.0);
       c[u] = ok ? __builtin_nontemporal_load(pc2 + p) : 0u;
@@ -216,8 +274,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t p = pb + (int64_t)u * kPbThreads;
-      // streamed once, read back by phase 2 from HBM: non-temporal
+      const int64_t p = base + (int64_t)u * kPbThreads;
       if (p < p1)
         st_stream<1>(reinterpret_cast<double2*>(T2 + d[u] + (((uint32_t)p & (uint32_t)(kPbPad / 2 - 1)) << 1)),
                      make_double2(a[u].x * xs[c[u] & 0xffffu], a[u].y * xs[c[u] >> 16]));
