@@ -133,6 +133,12 @@ class LanczosBase:
         if self.verbose:
             print(msg)
 
+    def _device(self):
+        """the live handle behind the lazily fetched results (V, H_eigvecs, windows of them)"""
+        if self._handle is None:
+            raise _capi.LanczosHipError(-4, "the device state of this run was released (close()); run execute_Lanczos again")
+        return self._handle
+
     # ------------------------------------------------------------------ properties
     @property
     def H_eff(self):
@@ -147,7 +153,7 @@ class LanczosBase:
         if not self.Lanczos_has_been_executed:
             raise ValueError(_NOT_EXECUTED)
         if self._V is None:
-            self._V = self._handle.get_basis().T
+            self._V = self._device().get_basis().T
         return self._V
 
     @property
@@ -183,7 +189,8 @@ class LanczosBase:
 
     def find_exact_eigs(self, nr_vecs=20):
         self._say("+++ Calculating exact eigs using scipy.sparse.linalg.eigsh.")
-        self._H_eigvals_actual, self._H_eigvecs_actual = scipy.sparse.linalg.eigsh(self.H, k=nr_vecs, which="SM")
+        H = self.H.to_scipy() if hasattr(self.H, "to_scipy") else self.H  # (a StencilOperator / synthetic.CSR is materialised for SciPy)
+        self._H_eigvals_actual, self._H_eigvecs_actual = scipy.sparse.linalg.eigsh(H, k=nr_vecs, which="SM")
         self._say("+++ Finished calculating exact eigs.")
 
     # ------------------------------------------------------------------ the hot path
@@ -355,7 +362,7 @@ class LanczosBase:
         # Lanczos.py:157-158 only need its n x n Gram matrix, which the device forms too.  When a second M x n array does
         # not fit beside the basis (BASELINE C4 on one GPU) the library keeps S and re-forms Y in row chunks for the Gram
         # matrix and for every later fetch (lz_ritz_info): nothing here depends on free device memory.
-        self._handle.ritz_vectors(H_eff_eigvecs, fetch=False)
+        self._device().ritz_vectors(H_eff_eigvecs, fetch=False)
         self._H_eff_eigvecs = H_eff_eigvecs
         self._H_eigvecs_host = None
         if checks:
@@ -377,21 +384,21 @@ class LanczosBase:
     def _H_eigvecs(self):
         """(M, n) Ritz vectors, C-order; copied off the device on first use."""
         if self._H_eigvecs_host is None:
-            self._H_eigvecs_host = self._handle.ritz_fetch()
+            self._H_eigvecs_host = self._device().ritz_fetch()
         return self._H_eigvecs_host
 
     def V_rows(self, lo, hi):
         """Rows ``[lo, hi)`` of ``V`` (an (hi - lo, n) block) without moving the whole basis off the device (extension)."""
         if not self.Lanczos_has_been_executed:
             raise ValueError(_NOT_EXECUTED)
-        return self._handle.get_basis_block(lo, hi).T
+        return self._device().get_basis_block(lo, hi).T
 
     def H_eigvecs_rows(self, lo, hi):
         """Rows ``[lo, hi)`` of ``H_eigvecs`` without materialising the whole (M, n) array on the host (extension: at
         BASELINE C4 size ``H_eigvecs`` alone is 160 GB)."""
         if not self.H_eigs_have_been_found:
             self.get_H_eigs()
-        return self._handle.ritz_fetch_rows(lo, hi)
+        return self._device().ritz_fetch_rows(lo, hi)
 
     def get_H_eigs(self):
         self._ritz(self._check_eigs)
