@@ -115,7 +115,7 @@ int lz_set_options(lz_handle h, int flags);
  *    7  profile only every value-th iteration of lz_run
  *    8  update-kernel variant (1 cached loads, 2 one position per lane, 3/4/5 slice owner with 8/4/1 positions per lane)
  *    9  Ritz back-transform kernel: 0 auto (33..128 columns: S resident in LDS, 32-row tiles; 129..200: S-stationary, S in
- *       registers; else one workgroup per 128 rows), 1 the latter always, 6 the 16-row-tile form of the S-in-LDS kernel
+ *       registers; else one workgroup per 128 rows), 1 the latter always
  *   10  irregular SpMV: entries per row block   12  1 = no row-stride skew
  *   13  1 = NaN-poison a fresh basis allocation before the required parts are cleared (test knob)
  *   14  irregular SpMV plan (0 auto: the column-blocked two-phase kernels for matrices without column locality, 1 never, 2 always)
@@ -125,7 +125,7 @@ int lz_set_options(lz_handle h, int flags);
  * The product library returns LZ_ERR_ARG for everything that lives only in the kernel-bench build (make KBENCH=1 ->
  * liblanczos_kbench.so, loaded by tools/ and by the tests of those arms): the timing-only ablation arms (knob 1 >= 20,
  * knob 3) and the A/B arms retired in round 3 because they measured slower - the one-kernel and one-launch-per-step engines
- * (15 = 2, 3, 5), the persistent / LDS-staged Ritz GEMMs (9 = 2, 3, 4), the ticket / deferred-fold two-sided links
+ * (15 = 2, 3, 5), the persistent / LDS-staged / 16-row-tile Ritz GEMMs (9 = 2, 3, 4, 6), the ticket / deferred-fold two-sided links
  * (11 = 2, 3), and LZ_FLAG_QTW_MFMA (lz_set_options). */
 int lz_set_tuning(lz_handle h, int index, int value);
 /* "hip=<path of the libamdhip64 this library is bound to>;rccl=<path of the librccl it dlopened, or empty>".

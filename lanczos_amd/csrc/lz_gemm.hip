@@ -361,6 +361,7 @@ __global__ __launch_bounds__(NA == 2 ? 256 : 512) void k_gemm_tn_lds(const doubl
 
 #endif  // LZ_KBENCH
 
+#ifdef LZ_KBENCH  // the 16-row-tile form (superseded by k_gemm_tn_sl2 below, 0.49 vs 0.43 ms at n = 100): kernel-bench build only, variant 6
 // Ritz back-transform for n <= 128: S RESIDENT IN LDS, Y-stationary waves, no barrier after the prologue.
 // Why a third kernel.  The S-stationary kernel pays ~1400 cycles per 16-row tile for its barrier, partial-tile hand-over and
 // ring refill whatever n is (measured in round 3: 11 874 cycles per tile against an MFMA floor of 10 400 at n = 200, but 4 286
@@ -508,6 +509,8 @@ __global__ __launch_bounds__(256 * WPS) void k_gemm_tn_sl(const double* __restri
     if (blockIdx.x < 256) atomicMax(clk + 8 + blockIdx.x, now);  // per-workgroup exit tick (diagnostic: LZ_DEBUG_TIMING)
   }
 }
+
+#endif  // LZ_KBENCH
 
 // The same kernel with 32-ROW tiles (the default for n <= 128): half the vector-memory and LDS instructions per MFMA.
 // Measured on the 16-row version (in-kernel clocks, round 3): the oldest wave of a SIMD runs at 0.93-0.96 of the MFMA issue
@@ -973,6 +976,7 @@ static hipError_t launch_sreg(const double* V, int64_t ldv, int64_t rows, int n,
   return hipSuccess;
 }
 
+#ifdef LZ_KBENCH
 // S-in-LDS launcher (n <= 128)
 template <int NT, int KS, int WPS>
 static hipError_t launch_sl(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
@@ -1005,6 +1009,8 @@ static bool sl_dispatch(const double* V, int64_t ldv, int64_t rows, int n, const
 #undef LZ_SL
   return false;
 }
+
+#endif  // LZ_KBENCH
 
 template <int NT, int KS, bool USE4 = true>
 static hipError_t launch_sl2(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y, int64_t ldy,
@@ -1165,7 +1171,8 @@ static bool kbench_ritz_arm(const double* V, int64_t ldv, int64_t rows, int n, c
 hipError_t launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, const double* Spad, int npad, double* Y,
                             int64_t ldy, hipStream_t s, int variant, unsigned long long* clk) {
   const int64_t ntiles = (rows + 31) / 32;
-  // 0 (auto): n <= 128 and at least 4096 rows: S resident in LDS (k_gemm_tn_sl2, 32-row tiles; 6 = k_gemm_tn_sl, 16-row tiles);
+  // 0 (auto): 33 <= n <= 128 and at least 4096 rows: S resident in LDS (k_gemm_tn_sl2, 32-row tiles; kernel-bench build: 6 = the
+  // superseded 16-row-tile form);
   // 129 <= n <= 200: the S-stationary kernel where it applies (enough row tiles for a persistent grid, 16-byte aligned
   // rows); else one workgroup per 128 rows.  1 forces the latter.
   const bool sreg_ok = n > 128 && n <= 200 && (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 && npad >= 16 * ((n + 15) / 16) &&
@@ -1177,9 +1184,10 @@ hipError_t launch_ritz_gemm(const double* V, int64_t ldv, int64_t rows, int n, c
   if (variant != 1 && sl_ok) {
     hipError_t e = hipSuccess;
     const bool pairs_ok = (ldv & 1) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0;  // 16-byte loads of V
-    if (variant != 6 && pairs_ok ? sl2_dispatch(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e)
-                                 : sl_dispatch<2>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e))
-      return e;
+#ifdef LZ_KBENCH
+    if (variant == 6 && sl_dispatch<2>(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e)) return e;
+#endif
+    if (pairs_ok && sl2_dispatch(V, ldv, rows, n, Spad, npad, Y, ldy, s, clk, &e)) return e;
   }
   if (variant != 1 && sreg_ok) {
     hipError_t e = hipSuccess;

@@ -206,7 +206,7 @@ def test_product_library_has_no_ablation_kernels():
     assert re.search(rb"k_gemm_tn_sl2ILi\d+ELi\d+ELi0ELb[01]EE", blob), "S-in-LDS Ritz kernel not found - naming changed?"
     assert not re.search(rb"k_gemm_tn_sl2ILi\d+ELi\d+ELi[1-9]", blob)
     assert not re.search(rb"k_gemm_tn_sregILi\d+ELi\d+ELi[1-9]", blob)
-    for retired in (rb"k_small_run", rb"k_small_step", rb"k_gemm_tn_persist", rb"k_gemm_tn_ldsI", rb"k_qtw_mfmaILi"):
+    for retired in (rb"k_small_run", rb"k_small_step", rb"k_gemm_tn_persist", rb"k_gemm_tn_ldsI", rb"k_qtw_mfmaILi", rb"k_gemm_tn_slILi"):
         assert retired not in blob, retired
     if os.path.isfile(_capi.KBENCH_LIB_PATH):  # ... which the kernel-bench build still carries
         kblob = open(_capi.KBENCH_LIB_PATH, "rb").read()

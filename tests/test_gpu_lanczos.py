@@ -419,10 +419,10 @@ def test_ablation_knobs_are_rejected_by_the_product_library(hip, kb):
     # one-launch-per-step engines (15 = 2, 3, 5), the persistent / LDS-staged / forced S-stationary Ritz GEMM arms (9 >= 2),
     # the ticket / deferred-fold two-sided links (11 >= 2)
     for idx, val in [(1, 21), (1, 27), (1, 31), (1, 37), (3, 1), (3, 15), (24, 0), (-1, 0), (0, -5),
-                     (15, 2), (15, 3), (15, 5), (9, 2), (9, 3), (9, 4), (9, 5), (9, 21), (11, 2), (11, 3)]:
+                     (15, 2), (15, 3), (15, 5), (9, 2), (9, 3), (9, 4), (9, 5), (9, 6), (9, 21), (11, 2), (11, 3)]:
         assert h.lib.lz_set_tuning(h._h, idx, val) == -1, (idx, val)  # LZ_ERR_ARG
     assert b"lz_set_tuning" in h.lib.lz_last_error(h._h)
-    for idx, val in [(1, 0), (1, 10), (1, 13), (8, 2), (7, 8), (13, 1), (13, 0), (15, 0), (15, 1), (9, 0), (9, 1), (11, 0), (11, 1), (16, 4096), (16, 0)]:
+    for idx, val in [(1, 0), (1, 10), (1, 13), (8, 2), (7, 8), (13, 1), (13, 0), (15, 0), (15, 1), (9, 0), (9, 1), (11, 0), (11, 1), (16, 4096), (16, 0)]:  # (9, 6) is retired too
         assert h.lib.lz_set_tuning(h._h, idx, val) == 0, (idx, val)
     assert h.lib.lz_set_options(h._h, hip.FLAG_QTW_MFMA) == -1 and b"retired" in h.lib.lz_last_error(h._h)  # the 16x16x4 Q^T w arm
     assert h.lib.lz_set_options(h._h, hip.FLAG_QTW_VALU | hip.FLAG_FUSED_NORM) == 0  # (the VALU kernel is the fallback for > 5000 basis rows)
@@ -448,11 +448,12 @@ def _ritz_case(H_handle, dims, n):
     return V, S
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4])
-@pytest.mark.parametrize("dims,n", [((300, 250), 50), ((512, 256), 200), ((331, 211), 197)])
+@pytest.mark.parametrize("variant", [2, 3, 4, 6])
+@pytest.mark.parametrize("dims,n", [((300, 250), 50), ((512, 256), 200), ((331, 211), 197), ((300, 250), 100), ((331, 211), 37)])
 def test_retired_ritz_gemm_arms_in_the_kernel_bench_build(kb, variant, dims, n):
     """2: the 32-row tile walked by persistent waves; 3: two waves per SIMD with 16-row tiles, S staged through LDS; 4: one wave
-    per SIMD, 32-row tiles, S through LDS - measured slower than the defaults, kept correct."""
+    per SIMD, 32-row tiles, S through LDS; 6 (n <= 128): the 16-row-tile form of the S-in-LDS kernel, superseded by the 32-row
+    form - all measured slower than the defaults, kept correct."""
     h = kb.Handle(0)
     h.set_tuning(9, variant)
     V, S = _ritz_case(h, dims, n)
@@ -460,7 +461,7 @@ def test_retired_ritz_gemm_arms_in_the_kernel_bench_build(kb, variant, dims, n):
     h.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 6])
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("dims,n", [((300, 250), 50), ((331, 211), 37), ((512, 256), 200), ((331, 211), 197), ((331, 211), 193),
                                     ((300, 250), 49), ((300, 250), 64), ((300, 250), 65), ((300, 250), 100), ((331, 211), 111),
                                     ((300, 250), 150), ((331, 211), 192), ((300, 250), 201), ((300, 250), 126), ((257, 256), 178),
@@ -472,11 +473,8 @@ def test_ritz_backtransform_kernels(hip, variant, dims, n):
     """Y = V S (Lanczos.py:153-156) by the FP64-MFMA kernels - 0: automatic choice: S resident in LDS, Y-stationary waves
     without barriers for 32 < n <= 128; the S-stationary kernel (S held in registers, 16-row tiles of V through LDS) for
     129 <= n <= 200 - every (column tiles, k-steps) instantiation of either is hit by some case here - else (n > 200) the
-    one-workgroup-per-128-rows kernel; 1: the latter always (one wave per SIMD with a 32-row x n tile); 6: the 16-row-tile
-    form of the S-in-LDS kernel (what runs when V is not 16-byte aligned) - against NumPy on the fetched basis, ragged row
-    and column counts included."""
-    if variant == 6 and not 32 < n <= 128:
-        pytest.skip("variant 6 differs from 0 only for 32 < n <= 128")
+    one-workgroup-per-128-rows kernel; 1: the latter always (one wave per SIMD with a 32-row x n tile) - against NumPy on the
+    fetched basis, ragged row and column counts included."""
     A = synthetic.laplacian_2d_5pt(*dims)
     M = A.shape[0]
     v0 = synthetic.reference_start_vector(M)
@@ -494,7 +492,7 @@ def test_ritz_backtransform_kernels(hip, variant, dims, n):
     assert np.abs(G - np.eye(n)).max() < 1e-12
     info = h.ritz_info()
     assert info["chunk_rows"] == 0
-    if variant in (0, 6) and 32 < n <= 200:  # the S-in-LDS (n <= 128) or the S-stationary kernel ran and left its clock record
+    if variant == 0 and 32 < n <= 200:  # the S-in-LDS (n <= 128) or the S-stationary kernel ran and left its clock record
         assert info["tiles"] > 0 and 500 < info["clock_mhz"] < 3000 and info["cycles_per_tile"] >= info["mfma_floor_cycles_per_tile"] > 0, info
     else:
         assert info["tiles"] == 0
