@@ -313,7 +313,7 @@ class PoolHandle:
         """(n, M): every rank writes its columns of every basis row straight into the shared mapping"""
         with self._seg("V", (self.n, self.rows), np.float64) as s:
             self.pool.request({"cmd": "fetch_basis", "V": s.spec})
-            return np.array(s.arr)
+            return s.arr  # the mapping itself (no second copy of a 16 GB basis): it outlives the unlinked file until the array is dropped
 
     def get_basis_block(self, r0, r1):
         r0, r1 = int(r0), int(r1)
@@ -335,7 +335,7 @@ class PoolHandle:
         r0, r1 = int(r0), int(r1)
         with self._seg("Y", (r1 - r0, self.n), np.float64) as s:
             self.pool.request({"cmd": "fetch_ritz", "Y": s.spec, "rows": (r0, r1)})
-            return np.array(s.arr)
+            return s.arr  # (see get_basis)
 
     def ritz_gram(self):
         return self.pool.request({"cmd": "gram"})[0]["G"]
