@@ -1,5 +1,7 @@
 /* Plain-C client of liblanczos_hip.so (no Python, no C++): builds a 2-D periodic 5-point Laplacian, runs k Lanczos
- * steps through the C ABI and prints the extreme Ritz-value bounds from the Gershgorin interval of T.
+ * steps through the C ABI and prints the extreme Ritz-value bounds from the Gershgorin interval of T; then the round-3 entry
+ * points: the back-transform with S = I (Y must equal the basis), a row window of Y (resident and forced-chunked), and a
+ * checkpoint (basis + residual + coefficients) resumed to 2 k steps, which must reproduce an uninterrupted 2 k-step run bit for bit.
  *
  *   gcc -std=c99 -Iinclude examples/c_abi_example.c -Llanczos_amd -llanczos_hip -Wl,-rpath,$PWD/lanczos_amd -lm -o c_abi_example
  */
@@ -68,7 +70,40 @@ int main(int argc, char** argv) {
   CHECK(lz_last_sweeps(h, &sweeps));
   printf("M=%lld k=%d alpha[0]=%.15g beta[0]=%.15g Gershgorin(T)=[%.6f, %.6f] sweeps=%d\n", (long long)M, k, alpha[0], beta[0], lo, hi,
          sweeps);
+  /* ---- Y = V S with S = I: the Ritz vectors are the basis vectors; fetch a window of rows, resident and chunked ---- */
+  double* S = calloc((size_t)k * k, sizeof *S);
+  double* V = malloc((size_t)k * M * sizeof *V);
+  double* Yw = malloc((size_t)40 * k * sizeof *Yw);
+  for (int j = 0; j < k; ++j) S[(size_t)j * k + j] = 1.0;
+  CHECK(lz_get_basis(h, V, M));
+  int bad = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    CHECK(lz_set_tuning(h, 16, pass ? 512 : 0)); /* pass 1: force the chunked mode (what a 160 GB basis gets on one GPU) */
+    CHECK(lz_ritz_vectors(h, S, NULL));
+    int64_t chunk = -1;
+    CHECK(lz_ritz_info(h, &chunk, NULL));
+    CHECK(lz_get_ritz_rows(h, M / 2 - 7, 40, Yw));
+    for (int r = 0; r < 40; ++r)
+      for (int j = 0; j < k; ++j) bad += Yw[(size_t)r * k + j] != V[(size_t)j * M + (M / 2 - 7 + r)];
+    printf("ritz rows (%s, chunk_rows=%lld): %d mismatches\n", pass ? "chunked" : "resident", (long long)chunk, bad);
+    if ((pass == 1) != (chunk > 0)) bad += 1;
+  }
+  CHECK(lz_set_tuning(h, 16, 0));
+  /* ---- checkpoint after k steps, resume to 2 k, compare with an uninterrupted 2 k-step run ---- */
+  const int k2 = 2 * k;
+  double* r = malloc(M * sizeof *r);
+  double* a2 = malloc(k2 * sizeof *a2);
+  double* b2 = malloc(k2 * sizeof *b2);
+  double* a3 = malloc(k2 * sizeof *a3);
+  double* b3 = malloc(k2 * sizeof *b3);
+  CHECK(lz_get_residual(h, r));
+  CHECK(lz_run_resume(h, k2, k, V, M, r, alpha, beta, a2, b2));
+  CHECK(lz_run(h, k2, v0, a3, b3));
+  for (int j = 0; j < k2; ++j) bad += a2[j] != a3[j];
+  for (int j = 0; j + 1 < k2; ++j) bad += b2[j] != b3[j];
+  printf("resume %d -> %d steps vs one run of %d: %d mismatches\n", k, k2, k2, bad);
   lz_destroy(h);
   free(rowptr), free(colidx), free(vals), free(v0), free(alpha), free(beta);
-  return (isfinite(lo) && isfinite(hi) && sweeps == k) ? 0 : 1;
+  free(S), free(V), free(Yw), free(r), free(a2), free(b2), free(a3), free(b3);
+  return (isfinite(lo) && isfinite(hi) && sweeps == k && bad == 0) ? 0 : 1;
 }

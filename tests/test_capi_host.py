@@ -189,6 +189,8 @@ def test_plain_c_client_runs(tmp_path):
     p = subprocess.run([exe, "64", "48", "24"], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "sweeps=24" in p.stdout
+    assert "ritz rows (resident, chunk_rows=0): 0 mismatches" in p.stdout and "ritz rows (chunked, chunk_rows=512): 0 mismatches" in p.stdout
+    assert "resume 24 -> 48 steps vs one run of 48: 0 mismatches" in p.stdout
 
 
 def test_product_library_has_no_ablation_kernels():
