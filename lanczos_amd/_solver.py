@@ -405,19 +405,11 @@ class LanczosBase:
 
     # ------------------------------------------------------------------ diagnostics (host, NumPy)
     def _eigvec_quality(self):
-        """cos^2 between H x / |H x| and x for every Ritz vector (Lanczos.py:169-175); computed on the
-        device-resident Ritz vectors when the matrix is CSR, else with NumPy on the host copy."""
+        """cos^2 between H x / |H x| and x for every Ritz vector (Lanczos.py:169-175), computed on the device-resident Ritz
+        vectors (lz_ritz_quality)."""
         if not self.H_eigs_have_been_found:
             self.get_H_eigs()
-        try:
-            return self._handle.ritz_quality()
-        except _capi.LanczosHipError as e:
-            if e.status != -4:  # LZ_ERR_STATE: no device kernel for this matrix kind (dense, one rank) -> NumPy on the host copy
-                raise
-        H, X = self.H, self.H_eigvecs
-        HX = H @ X if scipy.sparse.issparse(H) else np.asarray(H) @ X
-        HX = HX / np.linalg.norm(HX, axis=0)
-        return np.einsum("ij,ij->j", HX, X) ** 2
+        return self._device().ritz_quality()  # device kernels for CSR and dense, one rank or a partition: no host fallback
 
     def print_good_eigs(self, tol=0.01, print_nr=20, print_bad=True):
         """Print the first ``print_nr`` Ritz values with the eigenvector quality

@@ -2279,7 +2279,7 @@ int lz_ritz_gram(lz_handle h, double* gram_out) {
 int lz_ritz_quality(lz_handle h, double* out) {
   if (!h || !out) return LZ_ERR_ARG;
   if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: call lz_ritz_vectors first");
-  if (h->kind != 1 && !(h->world > 1 || h->tune[6])) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: CSR matrices only");
+  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: no matrix set");
   LZ_HIP(h, hipSetDevice(h->dev));
   const int n = h->y_n;
   // Chunked mode: whole Ritz vectors are formed a batch of columns at a time (Yb = V^T-layout x S[:, c0:c0+nb], all rows)
@@ -2302,8 +2302,9 @@ int lz_ritz_quality(lz_handle h, double* out) {
   std::vector<double> sums(2 * (size_t)n);
   int rc = LZ_OK;
   hipError_t e = hipSuccess;
-  if (h->world > 1 || h->tune[6]) {
-    // Row-block partition: z = A y_i needs the neighbours' entries of y_i, so every Ritz vector takes the path a Lanczos
+  if (h->world > 1 || h->tune[6] || h->kind == 2) {
+    // Row-block partition (and dense matrices on any number of ranks: the fused kernel below walks CSR rows): z = A y_i needs
+    // the neighbours' entries of y_i, so every Ritz vector takes the path a Lanczos
     // vector takes - copied into basis row 0 (saved and restored), exchanged (halo or all-gather), multiplied by the
     // SpMV kernel, whose epilogue already delivers y_i . z; ||z||^2 from the three-term kernel with zero coefficients.
     // One all-reduce of the 2 n sums at the end.

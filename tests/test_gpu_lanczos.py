@@ -620,3 +620,20 @@ def test_checkpoint_and_resume_is_bit_identical(tmp_path, build, n1, n2, fused):
         third.resume_Lanczos(n1, ck)
     for s in (whole, second, third):
         s.close()
+
+
+def test_ritz_quality_of_a_dense_matrix_runs_on_the_device(capsys):
+    """print_good_eigs (Lanczos.py:166-185) on the dense-ndarray call path of 1Dbox.py: the quality sums come from the device
+    (every Ritz vector multiplied by the resident dense operator) - there is no NumPy fallback in the product."""
+    A = synthetic.dense_symmetric(700, seed=4)
+    Lanczos.verbose = False
+    s = Lanczos(A)
+    s.execute_Lanczos(40)
+    q = s._eigvec_quality()
+    Y = s.H_eigvecs
+    AY = A @ Y
+    ref = np.einsum("ij,ij->j", AY / np.linalg.norm(AY, axis=0), Y) ** 2
+    np.testing.assert_allclose(q, ref, rtol=1e-11, atol=1e-13)
+    assert np.array_equal(s._handle.get_basis(), s.V.T)  # the basis row the kernel borrows is back
+    s.print_good_eigs(print_nr=3)
+    assert "Eigvec InnerProd" in capsys.readouterr().out
