@@ -182,6 +182,21 @@ def test_stencil_operator_on_one_and_on_three_workers():
     assert np.abs(th3 - s0.H_eigvals)[:4].max() <= 1e-10 * scale
     for s in (s0, s1, sH):
         s.close()
+    # the potential evaluated INSIDE the assembly kernel (no N^3 host array at all): one device vs two workers
+    ham2 = Hamiltonian(N, 25, synthetic.DeuteronPotential(), 197.327**2 / (2 * 469.4592) / (25.0 / N) ** 2)
+    ham2.device_potential = True
+    op2 = ham2.operator("27")
+    assert op2.potential is None and op2.potential_params is not None
+    a = Lanczos(op2)
+    a.execute_Lanczos(n, seed=78)
+    b = Lanczos(op2)
+    b.devices = [0, 0]
+    b.comm_backend = "host"
+    b.execute_Lanczos(n, seed=78)
+    assert np.abs(a.H_eff - b.H_eff).max() <= 1e-10 * np.abs(a.H_eff).max()
+    assert np.abs(a.H_eff - s0.H_eff).max() <= 1e-9 * scale  # (device exp/pow differ from NumPy's in the last bits: not the bit-exact path)
+    a.close()
+    b.close()
 
 
 def test_bench_self_spawn_two_ranks_on_one_gpu():
