@@ -48,7 +48,13 @@ class _Shm:
     def __init__(self, key, name, shape, dtype):
         self.path = os.path.join(_SHM_DIR, f"lz_{key}_{name}_{uuid.uuid4().hex[:8]}")
         self.shape, self.dtype = tuple(int(x) for x in shape), np.dtype(dtype)
-        self.arr = np.memmap(self.path, dtype=self.dtype, mode="w+", shape=self.shape if int(np.prod(self.shape)) else (1,))
+        nbytes = max(int(np.prod(self.shape)), 1) * self.dtype.itemsize
+        fd = os.open(self.path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)  # this user only: the matrix / the basis are in there
+        try:
+            os.ftruncate(fd, nbytes)
+        finally:
+            os.close(fd)
+        self.arr = np.memmap(self.path, dtype=self.dtype, mode="r+", shape=self.shape if int(np.prod(self.shape)) else (1,))
         if not int(np.prod(self.shape)):
             self.arr = self.arr[:0].reshape(self.shape)
 
