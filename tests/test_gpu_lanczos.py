@@ -493,7 +493,9 @@ def test_ritz_backtransform_kernels(hip, variant, dims, n):
     info = h.ritz_info()
     assert info["chunk_rows"] == 0
     if variant == 0 and 32 < n <= 200:  # the S-in-LDS (n <= 128) or the S-stationary kernel ran and left its clock record
-        assert info["tiles"] > 0 and 500 < info["clock_mhz"] < 3000 and info["cycles_per_tile"] >= info["mfma_floor_cycles_per_tile"] > 0, info
+        # (cycles per tile = workgroup 0's span / the tiles of its first wave: with only a handful of tiles per wave, as here,
+        # the other waves of the workgroup may own one tile less, so the figure can dip a few per cent under the floor)
+        assert info["tiles"] > 0 and 500 < info["clock_mhz"] < 3000 and info["cycles_per_tile"] >= 0.85 * info["mfma_floor_cycles_per_tile"] > 0, info
     else:
         assert info["tiles"] == 0
     # the same vectors re-formed in row chunks (what BASELINE C4 needs on one GPU: no room for a second M x n array)
