@@ -487,7 +487,14 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   if (W > kPbMaxW) W = kPbMaxW;
   const int nCB = (int)((A.ncols + W - 1) / W);
   // The diagonal split needs a row's own column to be its local index: the whole square matrix on this rank.
-  const bool diag = A.host_colidx != nullptr && A.rows == A.ncols;
+  bool diag = A.host_colidx != nullptr && A.rows == A.ncols;
+  if (diag) {  // a row that stores its diagonal TWICE (unsummed duplicates are legal CSR) has one slot for two products: no split then
+    for (int64_t r = 0; r < A.rows && diag; ++r) {
+      int nd = 0;
+      for (int64_t k = rowptr_host[r]; k < rowptr_host[r + 1]; ++k) nd += A.host_colidx[k] == r;
+      if (nd > 1) diag = false;
+    }
+  }
   bool f32 = A.host_vals != nullptr;
   if (f32)
     for (int64_t k = 0; k < A.nnz; ++k) {

@@ -264,3 +264,39 @@ def test_two_phase_layouts_of_different_size_coexist(hip):
     h2.close()
     assert np.array_equal(h1.spmv_host(x1), y1)
     h1.close()
+
+
+def test_two_phase_spmv_with_duplicate_diagonal_entries(hip):
+    """Unsummed duplicates are legal CSR.  A row that stores its diagonal twice cannot use the diagonal split of the two-phase
+    layout (one LDS slot per row): the layout must fall back to sending every entry through the product stream - same bits as
+    SciPy's csr_matvec, which adds the stored entries one by one."""
+    import scipy.sparse
+
+    A = synthetic.random_graph_laplacian(20000, 70000, seed=9).to_scipy().tocsr()
+    # append a second diagonal entry (value 0.25) to 50 rows, keeping the columns sorted (the duplicate follows the original)
+    rows = np.arange(0, 20000, 400)
+    indptr, indices, data = A.indptr.copy(), A.indices.copy(), A.data.copy()
+    out_idx, out_val, out_ptr = [], [], [0]
+    for r in range(A.shape[0]):
+        cols, vals = indices[indptr[r]:indptr[r + 1]], data[indptr[r]:indptr[r + 1]]
+        if r in rows and (cols == r).any():
+            k = int(np.flatnonzero(cols == r)[0]) + 1
+            cols, vals = np.insert(cols, k, r), np.insert(vals, k, 0.25)
+        out_idx.append(cols)
+        out_val.append(vals)
+        out_ptr.append(out_ptr[-1] + len(cols))
+    B = scipy.sparse.csr_matrix((np.concatenate(out_val), np.concatenate(out_idx), np.array(out_ptr)), shape=A.shape)
+    assert B.nnz == A.nnz + 50 and not B.has_canonical_format
+    h = hip.Handle(0)
+    h.set_tuning(14, 2)
+    h.set_csr(B.shape[0], 0, B.indptr, B.indices, B.data)
+    assert h.spmv_plan() == "two-phase"
+    x = np.random.default_rng(3).standard_normal(B.shape[0])
+    y = np.zeros(B.shape[0])
+    for r in range(B.shape[0]):  # csr_matvec's order: one stored entry after the other
+        acc = 0.0
+        for k in range(B.indptr[r], B.indptr[r + 1]):
+            acc += B.data[k] * x[B.indices[k]]
+        y[r] = acc
+    assert np.array_equal(h.spmv_host(x), y)
+    h.close()
