@@ -315,6 +315,10 @@ int lz_bi_alloc(lz_handle h, int n);
 int lz_bi_set_row(lz_handle h, int which, int j, const double* row);
 int lz_bi_get_row(lz_handle h, int which, int j, double* row);
 int lz_step_bireorth(lz_handle h, int j);
+/* The other branch of the same static method, bireorthogonalize(..., mem_safe=True) (IrrLanczos.py:398-407; no caller in the
+ * reference): V1[j] -= sum_i (V1[j].V2[i] / V2[i].V2[i]) V2[i], then V2[j] against the rows of V1 likewise - one sweep over
+ * ALL n rows with the reference's uu[j:] = 1, uv[j] = 0; bases 0 (V1) and 1 (V2) only, q_basis / p_basis untouched.  j >= 0. */
+int lz_step_bireorth_mem_safe(lz_handle h, int j);
 
 #ifdef __cplusplus
 }

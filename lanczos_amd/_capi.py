@@ -113,6 +113,7 @@ SIGNATURES = {
     "lz_bi_set_row": (C.c_int, [_P, C.c_int, C.c_int, _D]),
     "lz_bi_get_row": (C.c_int, [_P, C.c_int, C.c_int, _D]),
     "lz_step_bireorth": (C.c_int, [_P, C.c_int]),
+    "lz_step_bireorth_mem_safe": (C.c_int, [_P, C.c_int]),
 }
 
 
@@ -619,6 +620,9 @@ class Handle:
 
     def step_bireorth(self, j):
         self.check(self.lib.lz_step_bireorth(self._h, int(j)))
+
+    def step_bireorth_mem_safe(self, j):
+        self.check(self.lib.lz_step_bireorth_mem_safe(self._h, int(j)))
 
     def spmv_host(self, x, ncols=None):
         x = f64(x)

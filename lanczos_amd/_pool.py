@@ -297,6 +297,9 @@ class PoolHandle:
         with self._seg("v0", v0.shape, np.float64) as s:
             s.arr[...] = v0
             rep = self.pool.request({"cmd": "run", "n": int(n), "v0": s.spec, "options": self._flags})
+        return self._coefficients(rep, n)
+
+    def _coefficients(self, rep, n):
         for r in rep[1:]:  # alpha, beta are all-reduced sums: every rank must hold the same bits
             if not (np.array_equal(r["alpha"], rep[0]["alpha"], equal_nan=True) and np.array_equal(r["beta"], rep[0]["beta"], equal_nan=True)):
                 raise _capi.LanczosHipError(-3, "the ranks disagree on the recurrence coefficients")
@@ -305,6 +308,26 @@ class PoolHandle:
         self.breakdown = any(r["breakdown"] for r in rep)
         self.n = int(n)
         return rep[0]["alpha"], rep[0]["beta"]
+
+    def get_residual(self):
+        """(M,): r entering step n of the last run, every rank writing its rows"""
+        with self._seg("r", (self.rows,), np.float64) as s:
+            self.pool.request({"cmd": "residual", "r": s.spec})
+            return np.array(s.arr)
+
+    def run_resume(self, n, V_rows, r, alpha, beta):
+        """continue a run of j0 = len(V_rows) completed steps to n in total: every rank takes its rows of the checkpoint out of
+        the shared mapping (the partition need not be the one the checkpoint was written with)"""
+        V_rows, r = np.asarray(V_rows, dtype=np.float64), np.asarray(r, dtype=np.float64)
+        alpha, beta = np.ascontiguousarray(alpha, dtype=np.float64), np.ascontiguousarray(beta, dtype=np.float64)
+        j0 = V_rows.shape[0]
+        if V_rows.shape != (j0, self.rows) or r.shape != (self.rows,) or alpha.shape != (j0,) or beta.shape != (max(j0 - 1, 0),):
+            raise ValueError("checkpoint arrays have the wrong shapes")
+        with self._seg("V", V_rows.shape, np.float64) as sv, self._seg("r", r.shape, np.float64) as sr:
+            sv.arr[...] = V_rows
+            sr.arr[...] = r
+            rep = self.pool.request({"cmd": "resume", "n": int(n), "V": sv.spec, "r": sr.spec, "alpha": alpha, "beta": beta, "options": self._flags})
+        return self._coefficients(rep, n)
 
     def timings(self):
         return self._last.get("timings")

@@ -298,13 +298,12 @@ class LanczosBase:
     # ------------------------------------------------------------------ checkpoint / resume (extension; SURVEY.md section 5 hook)
     def checkpoint(self):
         """The state a finished run of n steps leaves behind - enough to continue it later with ``resume_Lanczos``:
-        ``{"alpha" (n), "beta" (n - 1), "V" (n, M) row-major, "r" (M), "M", "fused_norm"}``.  One GPU only."""
+        ``{"alpha" (n), "beta" (n - 1), "V" (n, M) row-major, "r" (M), "M", "fused_norm"}``.  With ``devices`` the ranks write
+        their rows into one host array, so a checkpoint does not depend on the partition that made it."""
         if not self.Lanczos_has_been_executed:
             raise ValueError(_NOT_EXECUTED)
-        if self._multi():
-            raise NotImplementedError("checkpoint / resume runs on one GPU (devices must be None or a single entry)")
         h = self._handle
-        return {"alpha": self._alpha.copy(), "beta": self._beta.copy(), "V": h.get_basis(), "r": h.get_residual(), "M": self.M,
+        return {"alpha": self._alpha.copy(), "beta": self._beta.copy(), "V": np.array(h.get_basis()), "r": h.get_residual(), "M": self.M,
                 "fused_norm": bool(self.fused_norm)}
 
     def save_checkpoint(self, path):
@@ -322,8 +321,6 @@ class LanczosBase:
             raise ValueError("n cannot be larger than M!")
         if n <= j0:
             raise ValueError("resume_Lanczos: n must exceed the %d steps already in the checkpoint" % j0)
-        if self._multi():
-            raise NotImplementedError("checkpoint / resume runs on one GPU (devices must be None or a single entry)")
         if self.reorth != "full":
             raise NotImplementedError("resume needs reorth='full' (the partial mode's omega-recurrence is not part of the checkpoint)")
         self._say("+++ Executing Lanczos algorithm")

@@ -76,6 +76,22 @@ class Rank:
         return {"alpha": alpha, "beta": beta, "breakdown": bool(s.h.breakdown), "sweeps": s.h.last_sweeps(), "engine": s.h.last_engine(),
                 "timings": s.h.timings()}
 
+    def cmd_residual(self, m):
+        out = _attach(m["r"], "r+")  # (M,): this rank's rows of the residual entering step n
+        out[self.lo:self.hi] = self.solver.h.get_residual()
+        out.flush()
+        return {}
+
+    def cmd_resume(self, m):
+        s = self.solver
+        s.h.set_options(int(m["options"]))
+        s.options = int(m["options"])
+        V = _attach(m["V"])  # (j0, M)
+        r = _attach(m["r"])
+        alpha, beta = s.resume_Lanczos(int(m["n"]), np.ascontiguousarray(V[:, self.lo:self.hi]), np.asarray(r[self.lo:self.hi]), m["alpha"], m["beta"])
+        return {"alpha": alpha, "beta": beta, "breakdown": bool(s.h.breakdown), "sweeps": s.h.last_sweeps(), "engine": s.h.last_engine(),
+                "timings": s.h.timings()}
+
     def cmd_ritz(self, m):
         S = np.array(_attach(m["S"]))
         self.solver.h.ritz_vectors(S, fetch=False)

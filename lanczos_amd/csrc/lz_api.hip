@@ -1992,6 +1992,19 @@ int lz_step_bireorth(lz_handle h, int j) {
   return LZ_OK;
 }
 
+int lz_step_bireorth_mem_safe(lz_handle h, int j) {
+  if (!h) return LZ_ERR_ARG;
+  LZ_TRY(bi_check_row(h, 0, j));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  // IrrLanczos.py:399-403 then :405-409: V1[j] against the rows of V2, then V2[j] against the rows of V1 (its row j already
+  // updated).  The n coefficients of a half live in d_gamma (n + 1 doubles, idle in the step API).
+  launch_bi_mem_safe(bi_row(h, 0, j), bi_base(h, 1), h->ldv, h->n, j, h->rows_pad, h->d_gamma, h->stream);
+  launch_bi_mem_safe(bi_row(h, 1, j), bi_base(h, 0), h->ldv, h->n, j, h->rows_pad, h->d_gamma, h->stream);
+  LZ_TRY(check_launch(h, "bireorthogonalize (mem_safe)"));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
 int lz_run_two_sided(lz_handle h, int n, const double* q0, const double* p0, double* alpha_out, double* beta_out, double* gamma_out) {
   if (!h) return LZ_ERR_ARG;
   if (!q0 || !p0 || !alpha_out || !beta_out || !gamma_out) return fail(h, LZ_ERR_ARG, "lz_run_two_sided: NULL buffer");

@@ -333,4 +333,72 @@ void launch_bi_two_term(int sub, int dots, double* r, double* sv, const double* 
 #undef LZ_TT
 }
 
+// ---- IrrLanczos.bireorthogonalize(mem_safe=True) (IrrLanczos.py:398-407): one classical Gram-Schmidt sweep of row j of one
+// base against ALL n rows of the other base, each coefficient divided by that row's own squared norm -------------------------
+// coef[i] = (x . B[i]) / (B[i] . B[i]) for i < j, 0 for i == j, x . B[i] for i > j (the reference's uu[j:] = 1, uv[j] = 0;
+// a zero row i < j gives 0/0 = nan exactly as NumPy does).  One block per row; padded tail entries of the rows are zero.
+__global__ __launch_bounds__(kTPB) void k_ms_coef(const double* __restrict__ x, const double* __restrict__ B, int64_t ldv, int64_t n2, int j,
+                                                  double* __restrict__ coef) {
+  __shared__ double sm[2 * (kTPB / 64)];
+  const int i = blockIdx.x;
+  const double2* b2 = reinterpret_cast<const double2*>(B + (int64_t)i * ldv);
+  const double2* x2 = reinterpret_cast<const double2*>(x);
+  double uv = 0.0, uu = 0.0;
+  for (int64_t t = threadIdx.x; t < n2; t += kTPB) {
+    const double2 b = b2[t], a = x2[t];
+    uv = fma(a.x, b.x, uv);
+    uv = fma(a.y, b.y, uv);
+    uu = fma(b.x, b.x, uu);
+    uu = fma(b.y, b.y, uu);
+  }
+  uv = wave_sum(uv);
+  uu = wave_sum(uu);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[2 * w] = uv;
+    sm[2 * w + 1] = uu;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < kTPB / 64; ++q) {
+      a += sm[2 * q];
+      b += sm[2 * q + 1];
+    }
+    coef[i] = i == j ? 0.0 : (i > j ? a : a / b);
+  }
+}
+
+// x[k] -= sum_i coef[i] * B[i][k], the sum formed row by row from row 0 with every product rounded on its own - the order and
+// rounding of np.sum(coef[:, None] * B, axis=0) (a reduction over the slow axis adds whole rows in turn; no pairwise tree there).
+__global__ __launch_bounds__(kTPB) void k_ms_apply(double* __restrict__ x, const double* __restrict__ B, int64_t ldv, int64_t n2, int n,
+                                                   const double* __restrict__ coef) {
+  extern __shared__ double sc[];
+  for (int i = threadIdx.x; i < n; i += kTPB) sc[i] = coef[i];
+  __syncthreads();
+  double2* x2 = reinterpret_cast<double2*>(x);
+  for (int64_t t = (int64_t)blockIdx.x * kTPB + threadIdx.x; t < n2; t += (int64_t)gridDim.x * kTPB) {
+    const double2* b2 = reinterpret_cast<const double2*>(B) + t;
+    const int64_t ld2 = ldv >> 1;
+    double2 b = b2[0];
+    double ax = __dmul_rn(sc[0], b.x), ay = __dmul_rn(sc[0], b.y);
+    for (int i = 1; i < n; ++i) {
+      b = b2[(int64_t)i * ld2];
+      ax = __dadd_rn(ax, __dmul_rn(sc[i], b.x));
+      ay = __dadd_rn(ay, __dmul_rn(sc[i], b.y));
+    }
+    double2 v = x2[t];
+    v.x = __dsub_rn(v.x, ax);
+    v.y = __dsub_rn(v.y, ay);
+    x2[t] = v;
+  }
+}
+
+// one half of the mem_safe branch: row j of `X` against the n rows of `B` (both (n, ldv) bases, ldv even, rows zero-padded to len)
+void launch_bi_mem_safe(double* xrow, const double* B, int64_t ldv, int n, int j, int64_t len, double* coef, hipStream_t s) {
+  const int64_t n2 = len >> 1;
+  hipLaunchKernelGGL(k_ms_coef, dim3(n), dim3(kTPB), 0, s, xrow, B, ldv, n2, j, coef);
+  hipLaunchKernelGGL(k_ms_apply, dim3(bi_grid(n2)), dim3(kTPB), (size_t)n * sizeof(double), s, xrow, B, ldv, n2, n, coef);
+}
+
 }  // namespace lz

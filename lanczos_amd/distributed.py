@@ -474,6 +474,28 @@ class DistributedLanczos:
         self.executed = True
         return self.alpha, self.beta
 
+    def checkpoint_local(self):
+        """this rank's share of the state a finished run leaves behind (see Lanczos.checkpoint): ``V`` (n, rows_local), ``r``
+        (rows_local) + the coefficients every rank holds"""
+        return {"alpha": self.alpha.copy(), "beta": self.beta.copy(), "V": self.h.get_basis(), "r": self.h.get_residual(), "M": self.M}
+
+    def resume_Lanczos(self, n, V_rows_local, r_local, alpha, beta):
+        """continue a run of ``len(alpha)`` completed steps to ``n`` in total from this rank's rows of the checkpoint; collective
+        (every rank calls it with its own rows and the same coefficients); bit-identical to one run of ``n`` steps"""
+        if n > self.M:
+            raise ValueError("n cannot be larger than M!")
+        self.n = n
+        self.alpha, self.beta = self.h.run_resume(n, V_rows_local, r_local, alpha, beta)
+        self.breakdown = bool(self.h.breakdown)
+        idx = np.arange(n)
+        H_eff = np.zeros((n, n))
+        H_eff[idx, idx] = self.alpha
+        H_eff[idx[:-1], idx[1:]] = self.beta
+        H_eff[idx[1:], idx[:-1]] = self.beta
+        self.H_eff = H_eff
+        self.executed = True
+        return self.alpha, self.beta
+
     @property
     def V_local(self):
         """(rows_local, n) block of the basis."""

@@ -121,11 +121,30 @@ class IrrLanczos(LanczosBase):
     def bireorthogonalize(V1, V2, q_basis, p_basis, j, use_cuda=True, mem_safe=False):
         """In place on row ``j`` of the four (n, M) arrays, the reference's default branch (IrrLanczos.py:408-441):
         project ``V1[j]`` on ``p_basis[:j]`` and ``V2[j]`` on ``q_basis[:j]`` (sequential Gram-Schmidt), rescale the
-        pair to ``V1[j] . V2[j] = +-1``, then extend the two orthonormal bases by row ``j``.  Runs on the device."""
+        pair to ``V1[j] . V2[j] = +-1``, then extend the two orthonormal bases by row ``j``.  ``mem_safe=True`` is the
+        reference's other branch (:398-407, no caller there): one sweep of ``V1[j]`` against all rows of ``V2`` and of
+        ``V2[j]`` against all rows of ``V1``, each coefficient over that row's own squared norm; ``q_basis`` /
+        ``p_basis`` are not read.  Both run on the device."""
         _use_cuda_or_notice(LanczosBase, use_cuda)
         if mem_safe:
-            raise NotImplementedError("mem_safe=True (IrrLanczos.py:397-407) is a different, unused arithmetic; "
-                                      "only the default branch is implemented")
+            V1, V2 = np.asarray(V1), np.asarray(V2)
+            n, M = V1.shape
+            if not 0 <= j < n:
+                raise ValueError("bireorthogonalize needs 0 <= j < n")
+            h = _capi.Handle(LanczosBase.device_id)
+            try:
+                eye_ptr = np.arange(M + 1, dtype=np.int32)
+                h.set_csr(M, 0, eye_ptr, eye_ptr[:-1], np.ones(M))  # length carrier only; no matvec is run
+                h.bi_alloc(n)
+                for which, a in enumerate((V1, V2)):
+                    for i in range(n):  # the sweep reads every row, also those past j (IrrLanczos.py:399-400)
+                        h.bi_set_row(which, i, a[i])
+                h.step_bireorth_mem_safe(j)
+                V1[j] = h.bi_get_row(0, j)
+                V2[j] = h.bi_get_row(1, j)
+            finally:
+                h.close()
+            return
         if j < 1:
             raise ValueError("bireorthogonalize needs j >= 1")
         arrs = [np.asarray(a) for a in (V1, V2, q_basis, p_basis)]

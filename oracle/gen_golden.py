@@ -145,6 +145,30 @@ def two_sided_main():
     two_sided_case("two_sided_lap2d_8x8_n2", synthetic.laplacian_2d_5pt(8, 8).to_scipy(), 2, gen="laplacian_2d_5pt(8, 8)")
 
 
+def mem_safe_main():
+    """The static IrrLanczos.bireorthogonalize(..., mem_safe=True) (IrrLanczos.py:398-407) on the reference's CPU branch: three
+    input pairs - zero rows past j (how the driver's arrays look), every row filled, and j = 0."""
+    rng = np.random.default_rng(2024)
+    data = dict(numpy_version=np.__version__)
+    worst = 0.0
+    for tag, (n, M, j, fill) in {"a": (8, 300, 5, False), "b": (6, 1000, 3, True), "c": (5, 130, 0, True)}.items():
+        V1 = rng.uniform(-1, 1, (n, M))
+        V2 = rng.uniform(-1, 1, (n, M))
+        if not fill:
+            V1[j + 1:] = 0
+            V2[j + 1:] = 0
+        R1, R2 = V1.copy(), V2.copy()
+        quiet(ref_irregular.IrrLanczos.bireorthogonalize, R1, R2, None, None, j, use_cuda=False, mem_safe=True)
+        O1, O2 = V1.copy(), V2.copy()
+        two_sided_ref.bireorthogonalize_mem_safe(O1, O2, j)
+        worst = max(worst, np.abs(O1 - R1).max(), np.abs(O2 - R2).max())
+        assert np.array_equal(np.delete(R1, j, 0), np.delete(V1, j, 0)) and np.array_equal(np.delete(R2, j, 0), np.delete(V2, j, 0))
+        data.update({f"{tag}_V1": V1, f"{tag}_V2": V2, f"{tag}_j": j, f"{tag}_out1": R1[j].copy(), f"{tag}_out2": R2[j].copy()})
+    data["ref_vs_oracle_maxabs"] = worst
+    np.savez_compressed(os.path.join(OUT, "bireorth_mem_safe.npz"), **data)
+    print(f"bireorth_mem_safe            ref-vs-oracle max|diff|={worst:.3e}")
+
+
 def deuteron_potential(x, y, z):
     # same functional form/constants the reference's driver uses (3Ddeuteron.py:51-61); data, not code of the path
     r = np.sqrt(x**2 + y**2 + z**2)
@@ -156,6 +180,8 @@ def main():
     os.chdir(os.environ.get("TMPDIR", "/tmp"))  # the reference's Hamiltonian creates ./T_matrices
     if "--two-sided-only" in sys.argv:
         return two_sided_main()
+    if "--mem-safe-only" in sys.argv:
+        return mem_safe_main()
 
     # (i) C1: dense 512 x 512 random symmetric, n = 20, explicit v0
     A = synthetic.dense_symmetric(512, seed=0)
@@ -233,6 +259,7 @@ def main():
     case("lap2d_8x8_n2", synthetic.laplacian_2d_5pt(8, 8).to_scipy(), 2, store_matrix=False, gen="laplacian_2d_5pt(8, 8)")
     # the Irregular copy's two-sided variant (IrrLanczos.py:77-187)
     two_sided_main()
+    mem_safe_main()
 
 
 if __name__ == "__main__":

@@ -13,6 +13,8 @@ What it restates (paths relative to /root/reference):
 * ``execute_two_sided``   <- Python/Irregular/IrrLanczos.py:77-187 (CPU branch)
 * ``bireorthogonalize``   <- Python/Irregular/IrrLanczos.py:390-443 (default
                              ``mem_safe=False`` branch, the only one the driver loop uses)
+* ``bireorthogonalize_mem_safe`` <- Python/Irregular/IrrLanczos.py:398-407 (pinned by
+                             tests/golden/bireorth_mem_safe.npz, made by the reference's static method)
 * ``build_h_eff``         <- Python/Irregular/IrrLanczos.py:165-174
 
 Semantics kept as they are in the reference, quirks included:
@@ -36,7 +38,7 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse
 
-__all__ = ["start_pair", "bireorthogonalize", "execute_two_sided", "build_h_eff"]
+__all__ = ["start_pair", "bireorthogonalize", "bireorthogonalize_mem_safe", "execute_two_sided", "build_h_eff"]
 
 
 def start_pair(M, seed=99):
@@ -65,6 +67,17 @@ def bireorthogonalize(Q, P, Qb, Pb, j):
         Pb[j] = Pb[j] - np.dot(Pb[j], Pb[i]) / np.dot(Pb[i], Pb[i]) * Pb[i]
     Qb[j] = Qb[j] / np.linalg.norm(Qb[j])
     Pb[j] = Pb[j] / np.linalg.norm(Pb[j])
+
+
+def bireorthogonalize_mem_safe(V1, V2, j):
+    """IrrLanczos.py:398-407 (``mem_safe=True``; the reference never calls it), in place on row ``j`` of the two (n, M)
+    arrays: one sweep over ALL n rows, rows at and past ``j`` with unit divisor, row ``j`` itself skipped."""
+    for X, B in ((V1, V2), (V2, V1)):
+        uv = np.sum(X[j] * B, axis=1)
+        uu = np.sum(B * B, axis=1)
+        uu[j:] = 1
+        uv[j] = 0
+        X[j] = X[j] - np.sum((uv / uu)[:, None] * B, axis=0)
 
 
 def build_h_eff(alpha, beta, gamma):

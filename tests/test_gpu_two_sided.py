@@ -5,10 +5,12 @@ The recurrence is numerically unstable in the reference itself (a 1e-16 relative
 to 1e-7 within 20-40 steps, see `sensitivity`), so coefficients are compared on the prefix the reference arithmetic
 determines to 1e-12, with the north-star bar of 1e-10 relative there; single bi-orthogonalisation steps are compared
 tightly."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import load_golden, two_sided_names
+from conftest import GOLDEN_DIR, load_golden, two_sided_names
 from lanczos_amd import IrrLanczos, synthetic
 from oracle import two_sided_ref as ts
 
@@ -82,6 +84,29 @@ def test_bireorthogonalize_step_matches_oracle():
     assert abs(abs(q @ p) - 1) < 1e-13
     assert np.abs(got[3][:j] @ q).max() < 1e-12 * np.linalg.norm(q) and np.abs(got[2][:j] @ p).max() < 1e-12 * np.linalg.norm(p)
     assert abs(np.linalg.norm(got[2][j]) - 1) < 1e-14 and np.abs(got[2][:j] @ got[2][j]).max() < 1e-13
+
+
+def test_bireorthogonalize_mem_safe_matches_the_reference():
+    """the static method's other branch (IrrLanczos.py:398-407) against outputs of the reference's own static method
+    (tests/golden/bireorth_mem_safe.npz): rows past j filled or zero, j = 0, and a longer random case against the oracle"""
+    d = np.load(os.path.join(GOLDEN_DIR, "bireorth_mem_safe.npz"))
+    for tag in "abc":
+        V1, V2, j = d[tag + "_V1"].copy(), d[tag + "_V2"].copy(), int(d[tag + "_j"])
+        IrrLanczos.bireorthogonalize(V1, V2, None, None, j, mem_safe=True)
+        for got, want, src in ((V1, d[tag + "_out1"], d[tag + "_V1"]), (V2, d[tag + "_out2"], d[tag + "_V2"])):
+            assert np.abs(got[j] - want).max() <= 1e-13 * np.abs(want).max()
+            assert np.array_equal(np.delete(got, j, 0), np.delete(src, j, 0))  # only row j is touched
+    rng = np.random.default_rng(8)
+    n, M, j = 40, 70001, 17
+    V1, V2 = rng.standard_normal((n, M)), rng.standard_normal((n, M))
+    V1[j + 1:] = 0
+    V2[j + 1:] = 0
+    R1, R2 = V1.copy(), V2.copy()
+    ts.bireorthogonalize_mem_safe(R1, R2, j)
+    IrrLanczos.bireorthogonalize(V1, V2, None, None, j, mem_safe=True)
+    assert np.abs(V1[j] - R1[j]).max() <= 1e-13 * np.abs(R1[j]).max() and np.abs(V2[j] - R2[j]).max() <= 1e-13 * np.abs(R2[j]).max()
+    with pytest.raises(ValueError, match="0 <= j < n"):
+        IrrLanczos.bireorthogonalize(V1, V2, None, None, n, mem_safe=True)
 
 
 def test_nonsymmetric_uses_the_transpose():

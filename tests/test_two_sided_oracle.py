@@ -41,3 +41,18 @@ def test_h_eff_layout_quirk():
     T = ts.build_h_eff(np.arange(1.0, 6.0), np.arange(10.0, 14.0), np.arange(20.0, 24.0))
     assert T[0, 1] == 20.0 and T[1, 2] == 20.0 and T[2, 3] == 21.0 and T[3, 4] == 22.0  # row i >= 1 carries gamma[i-1]
     assert T[1, 0] == 10.0 and T[4, 3] == 13.0 and T[4, 4] == 5.0
+
+
+def test_mem_safe_branch_matches_the_reference_static_method():
+    """IrrLanczos.py:398-407 as run by the reference itself (oracle/gen_golden.py --mem-safe-only): bit for bit."""
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    d = np.load(os.path.join(GOLDEN_DIR, "bireorth_mem_safe.npz"))
+    assert float(d["ref_vs_oracle_maxabs"]) == 0.0
+    for tag in "abc":
+        V1, V2, j = d[tag + "_V1"].copy(), d[tag + "_V2"].copy(), int(d[tag + "_j"])
+        ts.bireorthogonalize_mem_safe(V1, V2, j)
+        assert np.array_equal(V1[j], d[tag + "_out1"]) and np.array_equal(V2[j], d[tag + "_out2"])
+        assert np.array_equal(np.delete(V1, j, 0), np.delete(d[tag + "_V1"], j, 0))
