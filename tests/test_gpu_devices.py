@@ -199,6 +199,52 @@ def test_stencil_operator_on_one_and_on_three_workers():
     b.close()
 
 
+def test_checkpoint_and_resume_through_the_workers(tmp_path):
+    """SURVEY.md section 5 hook through ``devices``: a checkpoint written by two workers is one host array per field (no trace of
+    the partition), so three workers - or one GPU without workers - continue it; the result equals the uninterrupted run of the
+    same world bit for bit, and the one-GPU continuation of the two-worker checkpoint equals ... the two-worker prefix it was
+    given plus its own arithmetic (coefficients to the 1e-10 bar of the partition-vs-single comparison)."""
+    H = synthetic.laplacian_2d_5pt(90, 70).to_scipy()
+    n1, n2 = 12, 30
+    Lanczos.verbose = False
+
+    def solver(devs):
+        s = Lanczos(H)
+        s.devices = devs
+        s.comm_backend = "host"
+        return s
+
+    whole = solver([0, 0])
+    whole.execute_Lanczos(n2)
+    first = solver([0, 0])
+    first.execute_Lanczos(n1)
+    path = str(tmp_path / "ck.npz")
+    first.save_checkpoint(path)
+    ck = first.checkpoint()
+    assert ck["V"].shape == (n1, H.shape[0]) and ck["r"].shape == (H.shape[0],)
+    assert np.array_equal(ck["V"], whole.V.T[:n1])
+    first.close()
+    second = solver([0, 0])
+    second.resume_Lanczos(n2, path)
+    assert np.array_equal(second.H_eff, whole.H_eff) and np.array_equal(second.V, whole.V)
+    assert np.array_equal(second.H_eigvals, whole.H_eigvals)
+    assert np.array_equal(second.checkpoint()["r"], whole.checkpoint()["r"])
+    second.close()
+    whole.close()
+    # another partition, and no partition at all, continue the same file
+    ref = Lanczos(H)
+    ref.execute_Lanczos(n2)
+    scale = np.abs(np.diag(ref.H_eff)).max()
+    for devs in ([0, 0, 0], None):
+        t = solver(devs)
+        t.resume_Lanczos(n2, path)
+        assert np.array_equal(np.diag(t.H_eff)[: n1 - 1], ck["alpha"][: n1 - 1])
+        assert np.abs(t.H_eff - ref.H_eff).max() <= 1e-10 * scale
+        assert np.abs(t.V - ref.V).max() <= 1e-10 * np.abs(ref.V).max()
+        t.close()
+    ref.close()
+
+
 def test_bench_self_spawn_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2` without a launcher: the parent (which never touches the GPU) spawns both ranks, rank 0
     prints ONE JSON line - the plumbing the driver's first multi-GPU run will go through."""
