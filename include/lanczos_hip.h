@@ -232,7 +232,11 @@ int lz_get_residual(lz_handle h, double* r_local);
 int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_in, const double* r_local, const double* alpha_in,
                   const double* beta_in, double* alpha_out, double* beta_out);
 /* Krylov basis, row-major (n, rows_local): basis vector j is row j
- * (replaces cp.asnumpy(V.T), Lanczos.py:136; the mirror exposes the transposed view). */
+ * (replaces cp.asnumpy(V.T), Lanczos.py:136; the mirror exposes the transposed view).
+ * Result publication: device -> host copies of 192 MB and more (this call, lz_get_basis_block, lz_ritz_vectors with Y_out,
+ * lz_get_ritz_vectors / lz_get_ritz_rows) go through a ring of pinned staging buffers (6 x 32 MB per handle, created at the
+ * first such copy) emptied by host copy threads: 40-45 GB/s into fresh pageable NumPy memory instead of the 15-21 GB/s of a
+ * plain hipMemcpy (tools/publish_probe.py).  Environment LZ_XFER_THREADS = number of copy threads (default 6; 0 = plain copy). */
 int lz_get_basis(lz_handle h, double* V_out, int64_t ld);
 /* the entries [row0, row0 + nrows) of every basis vector: (n, nrows) row-major with leading dimension ld >= nrows (a window
  * of V when the whole (n, rows_local) array is too large to move: BASELINE config C4, 160 GB) */

@@ -182,6 +182,7 @@ struct lz_context {
   int last_sweeps = 0;
   int last_engine = 0;  // which loop ran last (enum Loop)
   int r_state = 0;      // what d_r holds after the last run: 0 nothing usable, 1 the residual entering step n, 2 y = A v_{n-1} (three-term pending)
+  Xfer* xfer = nullptr;        // staging ring of the large device -> host copies (lz_xfer.hip), created at the first one
   double* h_pinned = nullptr;  // 8 pinned doubles for the per-step scalar read-back of the partial-reorth mode
   bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
   lz_timings acc;
@@ -1156,6 +1157,7 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_sendbuf);
   hipFree(h->d_xfull);
   if (h->h_pinned) hipHostFree(h->h_pinned);
+  xfer_free(h->xfer);
   if (h->cstream) {
     hipStreamSynchronize(h->cstream);
     hipStreamDestroy(h->cstream);
@@ -2075,9 +2077,8 @@ int lz_get_basis(lz_handle h, double* V_out, int64_t ld) {
   LZ_TRY(require_basis(h, 0));
   if (ld < h->rows) return fail(h, LZ_ERR_ARG, "lz_get_basis: ld < rows_local");
   LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipMemcpy2DAsync(V_out, (size_t)ld * sizeof(double), h->d_V, (size_t)h->ldv * sizeof(double),
-                             (size_t)h->rows * sizeof(double), (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, V_out, (size_t)ld * sizeof(double), h->d_V, (size_t)h->ldv * sizeof(double),
+                     (size_t)h->rows * sizeof(double), (size_t)h->n));
   return LZ_OK;
 }
 
@@ -2086,9 +2087,8 @@ int lz_get_basis_block(lz_handle h, int64_t row0, int64_t nrows, double* V_out, 
   LZ_TRY(require_basis(h, 0));
   if (row0 < 0 || nrows < 1 || row0 + nrows > h->rows || ld < nrows) return fail(h, LZ_ERR_ARG, "lz_get_basis_block: bad row range or ld < nrows");
   LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipMemcpy2DAsync(V_out, (size_t)ld * sizeof(double), h->d_V + row0, (size_t)h->ldv * sizeof(double),
-                             (size_t)nrows * sizeof(double), (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, V_out, (size_t)ld * sizeof(double), h->d_V + row0, (size_t)h->ldv * sizeof(double),
+                     (size_t)nrows * sizeof(double), (size_t)h->n));
   return LZ_OK;
 }
 
@@ -2161,8 +2161,12 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
     h->y_chunked = false;
     h->y_chunk = h->rows;
     LZ_TRY(ritz_rows_into(h, 0, h->rows, h->d_Y));
-    if (Y_out) LZ_HIP(h, hipMemcpyAsync(Y_out, h->d_Y, (size_t)h->rows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    if (Y_out) {
+      const size_t bytes = (size_t)h->rows * n * sizeof(double);
+      LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, Y_out, bytes, h->d_Y, bytes, bytes, 1));
+    } else {
+      LZ_HIP(h, hipStreamSynchronize(h->stream));
+    }
     return LZ_OK;
   }
   // chunked: a bounded buffer (at most 4 GiB, at most a quarter of what is free), whole 16-row tiles
@@ -2194,9 +2198,8 @@ int lz_get_ritz_rows(lz_handle h, int64_t row0, int64_t nrows, double* Y_out) {
   LZ_HIP(h, hipSetDevice(h->dev));
   const int n = h->y_n;
   if (!h->y_chunked) {
-    if (nrows > 0)
-      LZ_HIP(h, hipMemcpyAsync(Y_out, h->d_Y + (size_t)row0 * n, (size_t)nrows * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t bytes = (size_t)nrows * n * sizeof(double);
+    LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, Y_out, bytes, h->d_Y + (size_t)row0 * n, bytes, bytes, nrows > 0 ? 1 : 0));
     return LZ_OK;
   }
   if (!h->d_V || h->n != n || h->rows != h->y_rows) return fail(h, LZ_ERR_STATE, "lz_get_ritz_rows: the basis of the run is gone");
@@ -2204,9 +2207,8 @@ int lz_get_ritz_rows(lz_handle h, int64_t row0, int64_t nrows, double* Y_out) {
     const int64_t nr = std::min<int64_t>(h->y_chunk, h->y_rows - r);
     LZ_TRY(ritz_rows_into(h, r, nr, h->d_Y));
     const int64_t a = std::max(r, row0), b = std::min(r + nr, row0 + nrows);
-    LZ_HIP(h, hipMemcpyAsync(Y_out + (size_t)(a - row0) * n, h->d_Y + (size_t)(a - r) * n, (size_t)(b - a) * n * sizeof(double),
-                             hipMemcpyDeviceToHost, h->stream));
-    LZ_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t bytes = (size_t)(b - a) * n * sizeof(double);
+    LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, Y_out + (size_t)(a - row0) * n, bytes, h->d_Y + (size_t)(a - r) * n, bytes, bytes, 1));
   }
   return LZ_OK;
 }

@@ -123,6 +123,13 @@ void launch_bi(int first, int pend, int dots, double* x, double* y, const double
 void launch_bi_two_term(int sub, int dots, double* r, double* sv, const double* u, const double* v, const double* c0, const double* c1,
                         const double* da, const double* db, int64_t len, double* part, double* fo, double* o0, double* o1,
                         unsigned* ticket, hipStream_t s);  // ticket != nullptr: the last block folds the partials (one launch)
+// ---- result publication (lz_xfer.hip): large device -> host copies through a ring of pinned staging buffers + host copy threads
+struct Xfer;
+void xfer_free(Xfer*& x);
+hipError_t xfer_d2h(int dev, hipStream_t stream, Xfer*& state, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
+                    size_t height);  // returns with the destination complete (stream synchronised)
+int xfer_threads();
+
 void launch_bi_mem_safe(double* xrow, const double* B, int64_t ldv, int n, int j, int64_t len, double* coef, hipStream_t s);
 int bi_partials_needed();  // per partial buffer; the handle keeps two (deferred folds ping-pong between them)
 

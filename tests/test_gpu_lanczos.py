@@ -639,3 +639,39 @@ def test_ritz_quality_of_a_dense_matrix_runs_on_the_device(capsys):
     assert np.array_equal(s._handle.get_basis(), s.V.T)  # the basis row the kernel borrows is back
     s.print_good_eigs(print_nr=3)
     assert "Eigvec InnerProd" in capsys.readouterr().out
+
+
+def test_large_results_come_back_through_the_staged_copy_unchanged():
+    """Result publication (Lanczos.py:132-141,153-156): copies of >= 192 MB leave the device through a ring of pinned staging
+    buffers and host copy threads (lz_xfer.hip).  The same data fetched in small pieces (row by row / window by window: the
+    runtime's plain path) must be the same bytes - whole basis with a padded destination stride, an odd window of it, the
+    Ritz vectors whole and as a row range."""
+    from lanczos_amd import _capi
+
+    M, n = 1_300_003, 24  # 250 MB per array; rows not a multiple of anything
+    d = np.linspace(1.0, 2.0, M)
+    ptr = np.arange(M + 1, dtype=np.int32)
+    h = _capi.Handle(0)
+    h.set_options(_capi.FLAG_FUSED_NORM)
+    h.set_csr(M, 0, ptr, ptr[:-1], d)
+    v0 = np.random.default_rng(3).standard_normal(M)
+    a, b = h.run(n, v0 / np.linalg.norm(v0))
+    V = h.get_basis()
+    for j in (0, 7, n - 1):
+        assert np.array_equal(V[j], h.basis_get_row(j))
+    ld = M + 5
+    Vp = np.full((n, ld), -7.0)
+    h.check(h.lib.lz_get_basis(h._h, _capi.dptr(Vp), ld))
+    assert np.array_equal(Vp[:, :M], V) and (Vp[:, M:] == -7.0).all()  # the padding of the caller's array is not touched
+    blk = h.get_basis_block(11, M - 3)  # 24 rows x 10.4 MB: the 2-D staging path
+    assert np.array_equal(blk, V[:, 11:M - 3])
+    S = np.linalg.eigh(np.diag(a) + np.diag(b, 1) + np.diag(b, -1))[1]
+    Y = h.ritz_vectors(S)
+    assert np.abs(Y - V.T @ S).max() < 1e-13
+    assert np.array_equal(h.ritz_fetch(), Y)
+    lo, hi = 100_001, M - 77
+    big = h.ritz_fetch_rows(lo, hi)
+    assert np.array_equal(big, Y[lo:hi])
+    for r0 in (lo, 600_000, hi - 1000):  # small windows: plain path
+        assert np.array_equal(h.ritz_fetch_rows(r0, r0 + 1000), Y[r0:r0 + 1000])
+    h.close()
