@@ -11,6 +11,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -65,13 +66,17 @@ hipError_t xfer_d2h(int dev, hipStream_t stream, Xfer*& state, void* dst, size_t
                     size_t height) {
   const int T = xfer_threads();
   if (width == 0 || height == 0) return hipStreamSynchronize(stream);
-  if (T == 0 || width * height < ((size_t)192 << 20)) {
-    hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, stream);
-    if (e != hipSuccess) return e;
-    return hipStreamSynchronize(stream);
-  }
+  auto plain = [&]() -> hipError_t {
+    const hipError_t pe = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, stream);
+    return pe != hipSuccess ? pe : hipStreamSynchronize(stream);
+  };
+  if (T == 0 || width * height < ((size_t)192 << 20)) return plain();
   hipError_t e = xfer_init(state);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess) {  // no pinned memory to be had (locked-memory limit): the runtime's own path still works
+    xfer_free(state);
+    (void)hipGetLastError();
+    return plain();
+  }
   struct Job {
     int b;
     char* d;
@@ -111,7 +116,11 @@ hipError_t xfer_d2h(int dev, hipStream_t stream, Xfer*& state, void* dst, size_t
     }
   };
   std::vector<std::thread> pool;
-  for (int t = 0; t < T; ++t) pool.emplace_back(worker);
+  try {
+    for (int t = 0; t < T; ++t) pool.emplace_back(worker);
+  } catch (const std::system_error&) {  // thread limit reached: carry on with the threads that did start, or plainly
+    if (pool.empty()) return plain();
+  }
   int next = 0;
   auto submit = [&](char* d, size_t dp, const char* s, size_t sp, size_t w, size_t h) -> hipError_t {
     const int b = next;
