@@ -81,6 +81,50 @@ def build_local(kind, dims, lo, hi):
     raise ValueError(kind)
 
 
+def class_surface(lanczos_amd, local, k):
+    """Wall time of the reference's call sequence through lanczos_amd.Lanczos (see the call site)."""
+    H = local.to_scipy()
+    M = H.shape[0]
+    cls = lanczos_amd.Lanczos
+    keep = cls.verbose
+    cls.verbose = False
+    try:
+        s = cls(H)
+        rec = {"workload_rows": M, "k": k}
+        for name in ("first_call", "second_call"):
+            t = time.perf_counter()
+            s.execute_Lanczos(k)
+            wall = time.perf_counter() - t
+            dev = s.timings["total_ms"] / 1e3
+            rec[name] = {"wall_s": round(wall, 4), "lz_run_device_s": round(dev, 4), "overhead_s": round(wall - dev, 4),
+                         **{kk: round(vv, 4) for kk, vv in s.host_timings.items()}}
+        t = time.perf_counter()
+        theta = s.H_eigvals
+        rec["H_eigvals_s"] = round(time.perf_counter() - t, 4)  # eigh(H_eff) + Y = V S + the two get_H_eigs checks on the device Gram matrix
+        big = 16.0 * M * k > 48e9  # V and H_eigvecs together on the host
+        if not big:
+            t = time.perf_counter()
+            V = s.V
+            rec["V_fetch_s"] = round(time.perf_counter() - t, 4)
+            rec["V_fetch_gbs"] = round(V.nbytes / max(time.perf_counter() - t, 1e-9) / 1e9, 1)
+            del V
+            s._V = None
+            t = time.perf_counter()
+            Y = s.H_eigvecs
+            rec["H_eigvecs_fetch_s"] = round(time.perf_counter() - t, 4)
+            rec["H_eigvecs_fetch_gbs"] = round(Y.nbytes / max(time.perf_counter() - t, 1e-9) / 1e9, 1)
+            del Y
+        else:
+            rec["V_fetch_s"] = rec["H_eigvecs_fetch_s"] = None
+        rec["ritz_min_max"] = [float(theta.min()), float(theta.max())]
+        rec["note"] = ("lanczos_amd.Lanczos(H) on a fresh object, default start vector (np.random.seed(99); uniform(-1, 1, M) on the host, "
+                       "as the reference's CPU branch does); outside `value`")
+        s.close()
+        return rec
+    finally:
+        cls.verbose = keep
+
+
 def cpu_baseline(kind, dims, k, budget_s=40.0):
     """Time the oracle's FAITHFUL restatement of the reference loop (all n rows swept, two
     n x M temporaries) on this host for a bounded number of iterations."""
@@ -214,6 +258,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-arm", action="store_true", help="N > 1: skip the extra halo-overlap measurement")
     ap.add_argument("--arm-timeout", type=float, default=240.0, help="seconds after which stalled extra arms are abandoned (main line still printed)")
+    ap.add_argument("--no-class-surface", action="store_true", help="skip the drop-in class-surface wall-time record (N = 1 only)")
     ap.add_argument("--no-partial", action="store_true", help="skip the extra (untimed-in-value) partial re-orthogonalisation measurement")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel hipEvents (roofline fields become null)")
     ap.add_argument("--profile-stride", type=int, default=8, help="bracket only every n-th iteration with hipEvents (each event costs ~3 us)")
@@ -287,7 +332,7 @@ def main():
     # Per-kernel events cost ~3 us each (1.8 % of the headline run when every launch is bracketed): sample every
     # stride-th iteration (centred, so the sampled launches have the same mean basis size as all launches).
     stride = max(1, args.profile_stride)
-    solver.h.set_tuning(7, stride)
+    solver.h.set_tuning(_capi.TUNE_PROFILE_STRIDE, stride)
 
     # Setup (not a step): let the runtime finish its one-time work (code-object load of every kernel variant, clock
     # ramp) on a short solve; a ~60 ms one-off stall was observed ~0.1 s after the first launches of a process.
@@ -451,6 +496,8 @@ def main():
             theta_part = np.linalg.eigvalsh(solver.H_eff)
             partial = {
                 "iterations_per_s": round(2 * k / tp, 1), "ms_per_solve": round(1e3 * tp / 2, 3), "sweeps": solver.h.last_sweeps(), "of": k,
+                "engine": solver.h.last_engine(), "host_syncs_inside_lz_run": solver.h.last_host_syncs(),
+                "device_ms_per_solve": round(tmp["total_ms"] / 2, 3),
                 "max_rel_ritz_diff_vs_full": float(np.abs(theta_part - theta_full).max() / np.abs(theta_full).max()),
                 "spmv_share_of_device_time": round(tmp["spmv"]["ms"] * tmp["spmv"]["launches"] / max(tmp["spmv"]["timed_launches"], 1) / max(tmp["total_ms"], 1e-9), 3),
                 "whole_iteration_gbps": round(sum(tmp[c]["bytes"] for c in ("spmv", "qtw", "update", "three_term")) / max(tmp["total_ms"], 1e-9) / 1e6, 1),
@@ -503,6 +550,15 @@ def main():
                               "comm_calls_per_iteration": round(tm1["comm"]["launches"] / 2.0 / k, 2),
                               "max_abs_coeff_diff_vs_default": float(max(np.abs(a_1 - alpha_main).max(), np.abs(b_1 - beta_main).max()))}
             solver.h.set_options(solver.options)
+        # (4) N = 1: what the DROP-IN caller waits for.  `value` times lz_run; a user of the reference calls
+        # Lanczos(H).execute_Lanczos(k) and reads .H_eigvals / .V / .H_eigvecs (Lanczos.py:75-163).  Wall seconds of each through
+        # the class surface, on a fresh object: first call (start vector + content hash + pack + validate + H2D + layout + solve),
+        # second call on the unchanged H (hash only + solve), then the lazily fetched results.
+        if world == 1 and not args.no_class_surface and hasattr(local, "to_scipy"):
+            arm_state["arm"] = "class_surface"
+            line_cs = class_surface(lanczos_amd, local, k)
+            if rank == 0:
+                line["class_surface"] = line_cs
     except Exception as e:  # an extra arm failed (e.g. a collective returned an error on this rank): the measured main line is
         # still delivered, marked, and the job ends non-zero at once - the other ranks are inside collectives this rank has left
         print(f"bench.py: rank {rank} failed in extra arm '{arm_state['arm']}': {e}", file=sys.stderr, flush=True)

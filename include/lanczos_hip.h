@@ -122,6 +122,11 @@ int lz_set_options(lz_handle h, int flags);
  *   15  loop structure (0 auto: three launches per step for small problems, five up to 4e6 rows per rank, else six; 1 six always)
  *   16  rows per chunk of the CHUNKED Ritz mode (0 auto: chunked only when Y does not fit beside the basis; > 0 forces it: tests)
  *   11  two-sided Gram-Schmidt links (0 / 1: streaming kernel + fold kernel per link)
+ *   17  fixed-K (stencil) SpMV layout: 0 auto (ELL-ordered second copy for 5, 7 and 27 entries per row: a lane owns whole rows),
+ *       1 never (CSR-order kernel with products staged through LDS; CSR-stream for 27), 2 ELL one row per lane and trip,
+ *       3 ELL two adjacent rows per lane (16-byte loads)
+ *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
+ *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta)
  * The product library returns LZ_ERR_ARG for everything that lives only in the kernel-bench build (make KBENCH=1 ->
  * liblanczos_kbench.so, loaded by tools/ and by the tests of those arms): the timing-only ablation arms (knob 1 >= 20,
  * knob 3) and the A/B arms retired in round 3 because they measured slower - the one-kernel and one-launch-per-step engines
@@ -282,6 +287,12 @@ int lz_last_sweeps(lz_handle h, int* sweeps);
  * one-launch-per-step engines of the kernel-bench build (retired from the product library in round 3: bit-identical, not
  * faster - DESIGN.md section 4). */
 int lz_last_engine(lz_handle h, int* engine);
+/* Host <-> device synchronisations lz_run made between its first and its last launch (the final wait for alpha / beta is not
+ * counted).  0 for every loop on one rank and over RCCL - including, since round 4, the partial re-orthogonalisation mode
+ * (engine 7: Simon's omega-recurrence and the sweep decision live on the device; lz_set_tuning(h, 18, 1) selects the former
+ * host-decided loop, engine 0, which reads two scalars back per step).  The host-staged collective backend (tests) counts two
+ * per collective. */
+int lz_last_host_syncs(lz_handle h, int64_t* syncs);
 
 /* ---- single steps (unit parity tests drive the kernels one by one) ------ */
 /* allocate a zeroed basis of n rows + r (what lz_run does first, Lanczos.py:104-107) */

@@ -29,6 +29,27 @@ FLAG_REORTH_PARTIAL = 64
 FLAG_OVERLAP_HALO = 128
 FLAG_ONE_REDUCE = 256
 
+# lz_set_tuning knob indices (the legend lives in include/lanczos_hip.h)
+TUNE_QTW_SLICE = 0          # Q^T w slice length per block
+TUNE_QTW_VARIANT = 1        # Q^T w kernel variant (unroll / rows per tile; >= 20: timing-only ablations, kernel-bench build)
+TUNE_STREAM_ROWS = 2        # CSR-stream rows per block
+TUNE_SPMV_ABLATION = 3      # timing-only SpMV ablation arm (kernel-bench build)
+TUNE_STREAM_ENTRIES = 4     # CSR-stream entries per block
+TUNE_FIXED_ROWS = 5         # fixed-K rows per block (CSR-order kernel)
+TUNE_FORCE_COLLECTIVES = 6  # issue the collectives even when world == 1
+TUNE_PROFILE_STRIDE = 7     # bracket only every value-th iteration of lz_run with events
+TUNE_UPDATE_VARIANT = 8     # pass-2 kernel variant
+TUNE_RITZ_KERNEL = 9        # Ritz back-transform kernel (0 auto, 1 the one-workgroup-per-128-rows kernel always)
+TUNE_PB_ENTRIES = 10        # two-phase SpMV: entries per row block
+TUNE_BI_LINKS = 11          # two-sided Gram-Schmidt links
+TUNE_NO_SKEW = 12           # 1 = no row-stride skew
+TUNE_POISON_BASIS = 13      # 1 = NaN-poison a fresh basis allocation (test knob)
+TUNE_SPMV_PLAN = 14         # irregular SpMV plan (0 auto, 1 never two-phase, 2 always)
+TUNE_LOOP = 15              # loop structure (0 auto, 1 six launches per step always)
+TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 forces it)
+TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto = ELL, 1 CSR order, 2 ELL one row per lane, 3 ELL two rows per lane)
+TUNE_PARTIAL_LOOP = 18      # partial re-orthogonalisation loop (0 device-resident, 1 host-decided, 2 device-resident without the fused scale)
+
 KERNEL_CLASSES = ("spmv", "qtw", "update", "three_term", "final", "comm", "ritz")
 K_COUNT = len(KERNEL_CLASSES)
 
@@ -98,6 +119,7 @@ SIGNATURES = {
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
     "lz_last_sweeps": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_last_engine": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "lz_last_host_syncs": (C.c_int, [_P, _I64]),
     "lz_basis_alloc": (C.c_int, [_P, C.c_int]),
     "lz_basis_set_row": (C.c_int, [_P, C.c_int, _D]),
     "lz_basis_get_row": (C.c_int, [_P, C.c_int, _D]),
@@ -529,10 +551,18 @@ class Handle:
         and the three-term recurrence folded into their consumer kernels); "three-term-fused": five launches per step (the
         three-term recurrence folded into pass 1; the default between the small problems and 4e6 rows per rank);
         "one-reduce": LZ_FLAG_ONE_REDUCE; "one-reduce-repeated": such a run whose cancellation guard fired and that was
-        repeated on the default loop; "step" / "small": the retired one-launch-per-step / one-kernel engines (kernel-bench build)."""
+        repeated on the default loop; "partial-device": LZ_FLAG_REORTH_PARTIAL with the omega-recurrence and the sweep decision on
+        the device (no host synchronisation inside the run); "step" / "small": the retired one-launch-per-step / one-kernel
+        engines (kernel-bench build)."""
         k = C.c_int()
         self.check(self.lib.lz_last_engine(self._h, C.byref(k)))
-        return ("kernels", "small", "fused", "three-term-fused", "step", "one-reduce-repeated", "one-reduce")[k.value]
+        return ("kernels", "small", "fused", "three-term-fused", "step", "one-reduce-repeated", "one-reduce", "partial-device")[k.value]
+
+    def last_host_syncs(self):
+        """host <-> device synchronisations inside the last lz_run (between its first and its last launch)"""
+        k = C.c_int64()
+        self.check(self.lib.lz_last_host_syncs(self._h, C.byref(k)))
+        return k.value
 
     def timings(self):
         t = LzTimings()

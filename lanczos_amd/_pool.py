@@ -130,11 +130,16 @@ class WorkerPool:
                         self.kill()
                         raise _capi.LanczosHipError(-3, f"worker rank {r} (GPU {self.devices[r]}): {replies[r]['error']}\n{replies[r].get('traceback', '')}")
             if deadline is not None and time.time() > deadline and any(x is None for x in replies):
-                self.kill()
-                raise _capi.LanczosHipError(-3, f"worker ranks {[r for r, x in enumerate(replies) if x is None]} did not answer within {timeout:.0f} s")
+                silent = [r for r, x in enumerate(replies) if x is None]
+                self.kill(hard=silent)  # a stalled rank (stuck collective, stopped process) does not react to SIGTERM: SIGKILL, by pid
+                raise _capi.LanczosHipError(-3, f"worker rank(s) {silent} (GPU {[self.devices[r] for r in silent]}) did not answer within "
+                                                f"{timeout:.0f} s; the pool was terminated (Lanczos.worker_timeout overrides the deadline)")
         return replies
 
-    def request(self, msg, timeout=None):
+    def request(self, msg, timeout=60.0):
+        """``timeout``: seconds every rank has to answer (``PoolHandle`` derives it from the work of the command; ``None`` waits
+        for ever and only notices DEAD ranks).  On expiry every child this pool started is ended by pid - the silent ones with
+        SIGKILL - and ``LanczosHipError`` names the silent ranks."""
         if self.closed:
             raise _capi.LanczosHipError(-4, "the worker pool is closed")
         data = (json.dumps(_enc(msg)) + "\n").encode("utf-8")
@@ -167,12 +172,15 @@ class WorkerPool:
                 p.wait()
             p.stdout.close()
 
-    def kill(self):
-        """end every rank now (exact pids of the children this pool started)"""
+    def kill(self, hard=()):
+        """end every rank now (exact pids of the children this pool started); ranks in ``hard`` get SIGKILL at once"""
         self.closed = True
-        for p in self.procs:
+        for r, p in enumerate(self.procs):
             if p.poll() is None:
-                p.terminate()
+                if r in hard:
+                    p.kill()
+                else:
+                    p.terminate()
         t_end = time.time() + 10.0
         for p in self.procs:
             try:
@@ -207,9 +215,15 @@ class StencilOperator:
             raise ValueError("potential must have one entry per grid point")
 
     def key(self):
+        """What decides whether the device copy is current.  The potential enters by CONTENT (8 M bytes through the threaded
+        hash of the matrix cache: cheap next to a run), not by address: ``np.ascontiguousarray`` aliases the caller's array, so
+        a parameter scan that changes it in place - or a freed array whose address is reused - must not be mistaken for the
+        matrix already on the device."""
+        from ._solver import _fingerprint
+
         return ("stencil", self.dims, self.points, self.T_factor, self.weights4, self.negate_T,
-                None if self.potential is None else self.potential.ctypes.data,
-                None if self.potential_params is None else tuple(self.potential_params))
+                None if self.potential is None else _fingerprint(self.potential),
+                None if self.potential_params is None else tuple(float(x) for x in self.potential_params))
 
     def to_scipy(self, device_id=0):
         import scipy.sparse
@@ -227,7 +241,19 @@ class StencilOperator:
 class PoolHandle:
     """What ``_solver.LanczosBase`` needs from a ``_capi.Handle``, served by a ``WorkerPool``."""
 
+    # Deadlines (round 4; SURVEY section 5 "failure detection").  A dead rank was always noticed (poll()); a STALLED one - a
+    # collective that never completes, a stopped process - was not: the caller hung.  Every command now carries a deadline
+    # derived from its work with pessimistic rates (a tenth or less of what the hardware does), never below `floor_s`;
+    # `timeout_override` (Lanczos.worker_timeout) replaces it.  On expiry the pool is terminated and the /dev/shm segments
+    # of the command are unlinked by their context managers.
+    floor_s = 60.0
+    rate_host_copy = 0.5e9     # bytes/s through /dev/shm + a worker's validation + upload
+    rate_device_stream = 2e11  # bytes/s of algorithmic traffic per rank (HBM does 6e12)
+    rate_flops = 2e12          # FP64 flop/s per rank in the Ritz GEMMs (the kernels do 5e13)
+    per_step_s = 0.05          # per Lanczos step: collectives, host-staged backend included
+
     def __init__(self, devices, backend="rccl"):
+        self.timeout_override = None
         self.pool = WorkerPool(devices, backend)
         self.world = self.pool.world
         self.breakdown = False
@@ -243,14 +269,29 @@ class PoolHandle:
     def _seg(self, name, shape, dtype):
         return _Shm(self.pool.key, name, shape, dtype)
 
+    def deadline(self, host_bytes=0.0, device_bytes=0.0, flops=0.0, steps=0):
+        """seconds a command of that much work may take before its ranks count as stalled"""
+        if self.timeout_override is not None:
+            return float(self.timeout_override)
+        w = max(self.world, 1)
+        return self.floor_s + host_bytes / self.rate_host_copy + device_bytes / w / self.rate_device_stream + flops / w / self.rate_flops + steps * self.per_step_s
+
+    def _matrix_bytes(self):
+        return float(getattr(self, "_mat_bytes", 0.0))
+
+    def _run_deadline(self, n):
+        M = float(self.rows or 0)
+        return self.deadline(host_bytes=8.0 * M, device_bytes=n * (self._matrix_bytes() + 64.0 * M) + 8.0 * n * n * M, steps=n)
+
     # ---- matrix ---------------------------------------------------------------------------------------------------------------
     def set_options(self, flags):
         self._flags = int(flags)
 
-    def _matrix(self, msg):
+    def _matrix(self, msg, host_bytes=0.0):
         msg = dict(msg, cmd="matrix", options=self._flags, fused_norm=bool(self._flags & _capi.FLAG_FUSED_NORM),
                    one_reduce=bool(self._flags & _capi.FLAG_ONE_REDUCE))
-        self._info = self.pool.request(msg)
+        self._info = self.pool.request(msg, timeout=self.deadline(host_bytes=3.0 * host_bytes, device_bytes=10.0 * host_bytes))
+        self._mat_bytes = float(host_bytes) if host_bytes else 12.0 * 27 * float(msg["M"])
         self.matrix_uploads += 1
         self.rows = int(msg["M"])
         bounds = partition.row_bounds(self.rows, self.world)
@@ -262,13 +303,14 @@ class PoolHandle:
             a.arr[...] = rowptr
             b.arr[...] = colidx
             c.arr[...] = vals
-            self._matrix({"kind": "csr", "M": int(M_global), "rowptr": a.spec, "colidx": b.spec, "vals": c.spec, "mode": mode})
+            self._matrix({"kind": "csr", "M": int(M_global), "rowptr": a.spec, "colidx": b.spec, "vals": c.spec, "mode": mode},
+                         host_bytes=float(rowptr.nbytes + colidx.nbytes + vals.nbytes))
 
     def set_dense(self, A):
         A = np.asarray(A, dtype=np.float64)
         with self._seg("dense", A.shape, np.float64) as a:
             a.arr[...] = A
-            self._matrix({"kind": "dense", "M": A.shape[0], "A": a.spec})
+            self._matrix({"kind": "dense", "M": A.shape[0], "A": a.spec}, host_bytes=float(A.nbytes))
 
     def set_stencil(self, op):
         msg = {"kind": "stencil", "M": op.shape[0], "dims": list(op.dims), "points": op.points, "T_factor": op.T_factor, "weights4": list(op.weights4),
@@ -276,7 +318,7 @@ class PoolHandle:
         if op.potential is not None:
             with self._seg("pot", op.potential.shape, np.float64) as p:
                 p.arr[...] = op.potential
-                self._matrix(dict(msg, potential=p.spec))
+                self._matrix(dict(msg, potential=p.spec), host_bytes=float(op.potential.nbytes))
         else:
             self._matrix(msg)
 
@@ -296,7 +338,7 @@ class PoolHandle:
             raise ValueError("v0 has the wrong length")
         with self._seg("v0", v0.shape, np.float64) as s:
             s.arr[...] = v0
-            rep = self.pool.request({"cmd": "run", "n": int(n), "v0": s.spec, "options": self._flags})
+            rep = self.pool.request({"cmd": "run", "n": int(n), "v0": s.spec, "options": self._flags}, timeout=self._run_deadline(int(n)))
         return self._coefficients(rep, n)
 
     def _coefficients(self, rep, n):
@@ -312,7 +354,7 @@ class PoolHandle:
     def get_residual(self):
         """(M,): r entering step n of the last run, every rank writing its rows"""
         with self._seg("r", (self.rows,), np.float64) as s:
-            self.pool.request({"cmd": "residual", "r": s.spec})
+            self.pool.request({"cmd": "residual", "r": s.spec}, timeout=self.deadline(host_bytes=8.0 * self.rows))
             return np.array(s.arr)
 
     def run_resume(self, n, V_rows, r, alpha, beta):
@@ -326,7 +368,8 @@ class PoolHandle:
         with self._seg("V", V_rows.shape, np.float64) as sv, self._seg("r", r.shape, np.float64) as sr:
             sv.arr[...] = V_rows
             sr.arr[...] = r
-            rep = self.pool.request({"cmd": "resume", "n": int(n), "V": sv.spec, "r": sr.spec, "alpha": alpha, "beta": beta, "options": self._flags})
+            rep = self.pool.request({"cmd": "resume", "n": int(n), "V": sv.spec, "r": sr.spec, "alpha": alpha, "beta": beta, "options": self._flags},
+                                    timeout=self._run_deadline(int(n)) + float(V_rows.nbytes) / self.rate_host_copy)
         return self._coefficients(rep, n)
 
     def timings(self):
@@ -341,20 +384,20 @@ class PoolHandle:
     def get_basis(self):
         """(n, M): every rank writes its columns of every basis row straight into the shared mapping"""
         with self._seg("V", (self.n, self.rows), np.float64) as s:
-            self.pool.request({"cmd": "fetch_basis", "V": s.spec})
+            self.pool.request({"cmd": "fetch_basis", "V": s.spec}, timeout=self.deadline(host_bytes=8.0 * self.n * self.rows))
             return s.arr  # the mapping itself (no second copy of a 16 GB basis): it outlives the unlinked file until the array is dropped
 
     def get_basis_block(self, r0, r1):
         r0, r1 = int(r0), int(r1)
         with self._seg("Vb", (self.n, r1 - r0), np.float64) as s:
-            self.pool.request({"cmd": "fetch_basis_block", "V": s.spec, "rows": (r0, r1)})
+            self.pool.request({"cmd": "fetch_basis_block", "V": s.spec, "rows": (r0, r1)}, timeout=self.deadline(host_bytes=8.0 * self.n * (r1 - r0)))
             return np.array(s.arr)
 
     def ritz_vectors(self, S, fetch=True):
         S = np.ascontiguousarray(S, dtype=np.float64)
         with self._seg("S", S.shape, np.float64) as s:
             s.arr[...] = S
-            self.pool.request({"cmd": "ritz", "S": s.spec})
+            self.pool.request({"cmd": "ritz", "S": s.spec}, timeout=self.deadline(flops=2.0 * self.rows * self.n * self.n, device_bytes=16.0 * self.rows * self.n))
         return self.ritz_fetch() if fetch else None
 
     def ritz_fetch(self):
@@ -363,11 +406,13 @@ class PoolHandle:
     def ritz_fetch_rows(self, r0, r1):
         r0, r1 = int(r0), int(r1)
         with self._seg("Y", (r1 - r0, self.n), np.float64) as s:
-            self.pool.request({"cmd": "fetch_ritz", "Y": s.spec, "rows": (r0, r1)})
+            self.pool.request({"cmd": "fetch_ritz", "Y": s.spec, "rows": (r0, r1)},
+                              timeout=self.deadline(host_bytes=8.0 * self.n * (r1 - r0), flops=2.0 * (r1 - r0) * self.n * self.n))
             return s.arr  # (see get_basis)
 
     def ritz_gram(self):
-        return self.pool.request({"cmd": "gram"})[0]["G"]
+        return self.pool.request({"cmd": "gram"}, timeout=self.deadline(flops=4.0 * self.rows * self.n * self.n, device_bytes=16.0 * self.rows * self.n))[0]["G"]
 
     def ritz_quality(self):
-        return self.pool.request({"cmd": "quality"})[0]["q"]
+        return self.pool.request({"cmd": "quality"}, timeout=self.deadline(flops=2.0 * self.rows * self.n * self.n,
+                                                                           device_bytes=self.n * (self._matrix_bytes() + 32.0 * self.rows), steps=self.n))[0]["q"]

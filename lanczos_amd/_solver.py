@@ -47,22 +47,61 @@ def _use_cuda_or_notice(obj, use_cuda):
     print(_CPU_NOTICE)
 
 
-def _fingerprint(*arrays):
-    """Cheap content hash of the matrix arrays (a few GB/s): decides whether the device copy of H is still current."""
+_HASH_CHUNK = 32 << 20
+_hash_pool = None
+
+
+def _fingerprint_start(*arrays):
+    """Content hash of the matrix arrays: decides whether the device copy of H is still current.  Every byte is hashed (an
+    in-place change of any entry is seen), in 32 MB chunks on a few threads (xxhash releases the GIL): ~0.02 s for the
+    headline's 640 MB of CSR instead of the 0.1 s of one thread.  Returns a function that waits for the digest - the caller
+    draws the start vector meanwhile (NumPy's legacy RNG releases the GIL too)."""
+    views = []
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        views.append(memoryview(a).cast("B") if a.size else memoryview(b""))
     try:
         import xxhash
 
-        h = xxhash.xxh3_64()
-        for a in arrays:
-            h.update(memoryview(np.ascontiguousarray(a)).cast("B"))
-        return h.hexdigest()
+        def one(mv):
+            return xxhash.xxh3_64_intdigest(mv)
     except ImportError:  # pragma: no cover - xxhash is optional
         import zlib
 
-        c = 0
-        for a in arrays:
-            c = zlib.crc32(memoryview(np.ascontiguousarray(a)).cast("B"), c)
-        return c
+        def one(mv):
+            return zlib.crc32(mv)
+    chunks = [mv[o:o + _HASH_CHUNK] for mv in views for o in range(0, max(len(mv), 1), _HASH_CHUNK)]
+    sizes = tuple(len(mv) for mv in views)
+    if len(chunks) <= 2:
+        digests = tuple(one(c) for c in chunks)
+        return lambda: (sizes, digests)
+    global _hash_pool
+    if _hash_pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        _hash_pool = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix="lz-hash")
+    futures = [_hash_pool.submit(one, c) for c in chunks]
+    return lambda: (sizes, tuple(f.result() for f in futures))
+
+
+def _fingerprint(*arrays):
+    return _fingerprint_start(*arrays)()
+
+
+def _native_arrays(H):
+    """the arrays that ARE the matrix as the caller holds it (no conversion, no copy): what the cache key is hashed from"""
+    if scipy.sparse.issparse(H):
+        if H.format in ("csr", "csc", "bsr"):
+            return (H.format, H.indptr, H.indices, H.data)
+        if H.format == "coo":
+            return ("coo", H.row, H.col, H.data)
+        return None
+    if hasattr(H, "rowptr") and hasattr(H, "colidx"):
+        return ("csr", H.rowptr, H.colidx, H.vals)
+    if isinstance(H, np.ndarray):
+        return ("dense", H)
+    return None
 
 
 def _pack_matrix(H):
@@ -100,6 +139,8 @@ class LanczosBase:
                      # basis are row-block partitioned over one FRESH worker process per listed GPU (RCCL all-reduces of
                      # alpha / ||r||^2 / Q^T w, halo or all-gather exchange of the SpMV input); same calls, same results
     comm_backend = "rccl"  # "host": collectives staged through host memory (several workers on ONE GPU: tests)
+    worker_timeout = None  # with ``devices``: seconds every worker has to answer a command; None = derived from the work of the
+                           # command with pessimistic rates, never below 60 s (a stalled rank ends the pool with LanczosHipError)
     strict_use_cuda = False  # True: use_cuda=False raises NotImplementedError instead of running the HIP path with a notice
     cache_matrix = True  # keep H on the device across execute_Lanczos calls while its content hash is unchanged
     _check_eigs = ("normalized", "orthogonal")  # which asserts get_H_eigs runs (Lanczos.py:157-158)
@@ -212,9 +253,23 @@ class LanczosBase:
                 self._handle = _capi.Handle(want[0])
             self._handle_devices = (want, self.comm_backend)
             self._matrix_key = self._matrix_key_alt = None
+        if hasattr(self._handle, "timeout_override"):
+            self._handle.timeout_override = self.worker_timeout
         return self._handle
 
-    def _upload_matrix(self, h):
+    def _matrix_key_start(self):
+        """Start hashing H as the caller holds it (threads); returns a function that delivers the cache key (or None)."""
+        H = self.H
+        if not self.cache_matrix or (hasattr(H, "dims") and hasattr(H, "points")):
+            return lambda: None
+        native = _native_arrays(H)
+        if native is None:
+            return lambda: None
+        wait = _fingerprint_start(*native[1:])
+        shape = tuple(np.shape(H))
+        return lambda: (native[0], shape, wait())
+
+    def _upload_matrix(self, h, pending_key=None):
         """H -> device(s), skipped when the device copy is still current (same format, shape and content hash): a second
         ``execute_Lanczos`` on one object then costs no repack, no H2D and no SpMV-plan rebuild (C3: ~1 GB + 2.6 GB of layout)."""
         H = self.H
@@ -228,10 +283,19 @@ class LanczosBase:
                                             potential_params=H.potential_params, negate_T=H.negate_T)
                 self._matrix_key, self._matrix_key_alt = key, None
             return
-        packed = _pack_matrix(H)
-        key = (packed[0], tuple(np.shape(H)), _fingerprint(*packed[1:])) if self.cache_matrix else None
+        # The cache key is hashed from the arrays the caller holds (CSR, CSC, COO, dense ...), BEFORE any conversion: a second
+        # call on an unchanged H costs one threaded hash, no tocsr(), no repack (round 3 packed first and hashed the result)
+        if pending_key is not None:
+            key = pending_key()
+        else:
+            key = self._matrix_key_start()()
         if key is not None and key in (self._matrix_key, self._matrix_key_alt):
             return
+        packed = _pack_matrix(H)
+        if key is None and self.cache_matrix:
+            key = (packed[0], tuple(np.shape(H)), _fingerprint(*packed[1:]))
+            if key in (self._matrix_key, self._matrix_key_alt):
+                return
         if packed[0] == "csr":
             h.set_csr(self.M, 0, packed[1], packed[2], packed[3])
         else:
@@ -247,12 +311,17 @@ class LanczosBase:
         M = self.M
 
         # start vector: the reference's CPU-branch stream (global legacy RNG), Lanczos.py:93-100
+        import time
+
+        t_0 = time.perf_counter()
+        pending_key = self._matrix_key_start()  # hashes H on helper threads while this thread draws v0
         np.random.seed(seed)
         if v0 is None:
             v0 = np.random.uniform(-1, 1, size=(M))
         else:
             v0 = np.array(v0)
-        v0 = v0 / np.linalg.norm(v0)
+        v0 /= np.linalg.norm(v0)  # (in place, like the reference: v0 is this call's own copy)
+        t_1 = time.perf_counter()
         if n < 2:
             # the reference allocates beta = zeros(n-1) and writes beta[-1] at j = 0 (Lanczos.py:107,112)
             raise IndexError("index -1 is out of bounds for axis 0 with size 0")
@@ -262,8 +331,13 @@ class LanczosBase:
         h = self._get_handle()
         h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0)
                       | (_capi.FLAG_FUSED_NORM if self.fused_norm else 0))
-        self._upload_matrix(h)
+        self._upload_matrix(h, pending_key)
+        t_2 = time.perf_counter()
         alpha, beta = h.run(n, v0)
+        t_3 = time.perf_counter()
+        # where the caller's wall time went, host side (seconds): drawing / normalising v0, deciding whether the device copy of
+        # H is current (+ pack, validate and upload when it is not), lz_run (upload of v0, the solve, alpha / beta back)
+        self.host_timings = {"start_vector_s": t_1 - t_0, "matrix_s": t_2 - t_1, "run_s": t_3 - t_2}
         if h.breakdown:  # lz_run returned LZ_WARN_BREAKDOWN
             # The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov space gives inf/NaN there too.
             import warnings
@@ -286,11 +360,17 @@ class LanczosBase:
         # the reference's GPU branch leaves a SciPy CSR in self.H (Lanczos.py:137); a stencil descriptor stays what it is
         # (materialising it is exactly what it exists to avoid)
         if not (hasattr(self.H, "dims") and hasattr(self.H, "points")):
-            was_dense = not (scipy.sparse.issparse(self.H) or hasattr(self.H, "rowptr"))
-            self.H = scipy.sparse.csr_matrix(self.H.to_scipy() if hasattr(self.H, "to_scipy") else self.H, dtype=np.float64)
-            if was_dense and self.cache_matrix and self._matrix_key is not None and self._matrix_key_alt is None:
-                # the dense matrix stays resident (dense GEMV); the CSR copy now in self.H is the same operator
-                self._matrix_key_alt = ("csr", tuple(self.H.shape), _fingerprint(*_pack_matrix(self.H)[1:]))
+            newH = scipy.sparse.csr_matrix(self.H.to_scipy() if hasattr(self.H, "to_scipy") else self.H, dtype=np.float64)
+            if self.cache_matrix and self._matrix_key is not None and self._matrix_key_alt is None:
+                # what the caller handed over stays resident (a dense matrix keeps its dense GEMV); the CSR copy now in self.H
+                # is the same operator: remember its key too, unless it is the very same arrays (a CSR input: no second hash)
+                old = _native_arrays(self.H)
+                same = old is not None and old[0] == "csr" and all(
+                    getattr(a, "ctypes", None) is not None and a.ctypes.data == b.ctypes.data and a.nbytes == b.nbytes
+                    for a, b in zip(old[1:], (newH.indptr, newH.indices, newH.data)))
+                if not same:
+                    self._matrix_key_alt = ("csr", tuple(newH.shape), _fingerprint(newH.indptr, newH.indices, newH.data))
+            self.H = newH
         self.H_eigs_have_been_found = False
         self._say("+++ Lanczos executed successfully.")
         self.Lanczos_has_been_executed = True

@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <system_error>
+#include <thread>
 
 #include "lz_internal.h"
 
@@ -183,7 +185,11 @@ struct lz_context {
   int last_engine = 0;  // which loop ran last (enum Loop)
   int r_state = 0;      // what d_r holds after the last run: 0 nothing usable, 1 the residual entering step n, 2 y = A v_{n-1} (three-term pending)
   Xfer* xfer = nullptr;        // staging ring of the large device -> host copies (lz_xfer.hip), created at the first one
-  double* h_pinned = nullptr;  // 8 pinned doubles for the per-step scalar read-back of the partial-reorth mode
+  double* h_pinned = nullptr;  // 8 pinned doubles for the per-step scalar read-back of the host-decided partial-reorth loop (tune[18] == 1)
+  double* d_om = nullptr;      // device-resident partial re-orthogonalisation: omega-recurrence state (omega_state_doubles)
+  int* d_omi = nullptr;        //   ... gate of the coming step, sweep count, per-step sweep log (omega_state_ints)
+  int om_n = 0;
+  int64_t host_syncs = 0;      // host <-> device synchronisations between the first and the last launch of the last lz_run
   bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
   lz_timings acc;
 };
@@ -250,6 +256,39 @@ int dev_alloc(lz_handle h, T*& p, size_t count) {
   p = static_cast<T*>(q);
   return LZ_OK;
 }
+
+// host -> device on the handle's stream.  The runtime's own path: a resident pageable source is pinned in place and read at
+// the link's rate (57 GB/s measured); a staged pipeline like lz_xfer.hip's was built and measured slower (see lz_xfer.hip).
+int upload(lz_handle h, void* dst, const void* src, size_t bytes) {
+  LZ_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  return LZ_OK;
+}
+int upload2d(lz_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+  LZ_HIP(h, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, h->stream));
+  return LZ_OK;
+}
+
+// run fn(t, lo, hi) over [0, count) on a few host threads (the validation sweeps over all nnz of lz_set_csr)
+template <class F>
+void parallel_ranges(int64_t count, int64_t min_per_thread, F fn) {
+  const unsigned hc = std::thread::hardware_concurrency();
+  int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, hc ? hc / 2 : 1), count / std::max<int64_t>(min_per_thread, 1)));
+  if (xfer_threads() == 0) T = 1;  // LZ_XFER_THREADS=0: no helper threads anywhere
+  std::vector<std::thread> pool;
+  const int64_t per = (count + T - 1) / T;
+  int started = 0;
+  try {
+    for (int t = 1; t < T; ++t) {
+      pool.emplace_back(fn, t, std::min(count, t * per), std::min(count, (t + 1) * per));
+      ++started;
+    }
+  } catch (const std::system_error&) {
+  }
+  fn(0, (int64_t)0, std::min(count, per));
+  for (int t = started + 1; t < T; ++t) fn(t, std::min(count, t * per), std::min(count, (t + 1) * per));  // threads that could not be had
+  for (auto& th : pool) th.join();
+}
+constexpr int kMaxHostThreads = 16;
 
 // ---- roctx ranges (opt-in: LZ_ROCTX=1) --------------------------------------
 // Host-side phase markers for `rocprofv3 --marker-trace`: one range per kernel class around its launches.  The marker
@@ -349,6 +388,7 @@ int comm_allreduce(lz_handle h, double* dbuf, int64_t count) {
     h->hbuf_a.resize((size_t)count);
     LZ_HIP(h, hipMemcpyAsync(h->hbuf_a.data(), dbuf, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     LZ_HIP(h, hipStreamSynchronize(h->stream));
+    h->host_syncs += 2;
     if (h->h_ar(h->h_user, h->hbuf_a.data(), count) != 0) return fail(h, LZ_ERR_COMM, "host all-reduce callback failed");
     LZ_HIP(h, hipMemcpyAsync(dbuf, h->hbuf_a.data(), count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     LZ_HIP(h, hipStreamSynchronize(h->stream));
@@ -386,6 +426,7 @@ int comm_exchange_x(lz_handle h, int j, const double** x_out) {
       h->hbuf_b.resize((size_t)std::max<int64_t>(h->total_recv, 1));
       LZ_HIP(h, hipMemcpyAsync(h->hbuf_a.data(), h->d_sendbuf, h->total_send * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       LZ_HIP(h, hipStreamSynchronize(h->stream));
+      h->host_syncs += 2;
       if (h->h_ex(h->h_user, (int)h->peers.size(), h->peers.data(), h->hbuf_a.data(), h->scount.data(), h->hbuf_b.data(),
                   h->rcount.data()) != 0)
         return fail(h, LZ_ERR_COMM, "host halo-exchange callback failed");
@@ -403,6 +444,7 @@ int comm_exchange_x(lz_handle h, int j, const double** x_out) {
       h->hbuf_b.resize((size_t)(h->ag_chunk * h->world));
       LZ_HIP(h, hipMemcpyAsync(h->hbuf_a.data(), vj, h->ag_chunk * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       LZ_HIP(h, hipStreamSynchronize(h->stream));
+      h->host_syncs += 2;
       if (h->h_ag(h->h_user, h->hbuf_a.data(), h->hbuf_b.data(), h->ag_chunk) != 0)
         return fail(h, LZ_ERR_COMM, "host all-gather callback failed");
       LZ_HIP(h, hipMemcpyAsync(h->d_xfull, h->hbuf_b.data(), h->ag_chunk * h->world * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -812,7 +854,8 @@ enum Loop {
   LOOP_THREE_TERM_FUSED = 3,  // up to 4e6 rows per rank: five launches per step (run_loop_three_term_fused)
   LOOP_SMALL_STEP = 4,        // kernel-bench build only: one launch per step
   LOOP_ONE_REDUCE_REPEATED = 5,  // a one-reduce run whose cancellation guard fired: repeated on the default loop
-  LOOP_ONE_REDUCE = 6         // LZ_FLAG_ONE_REDUCE: one all-reduce per iteration
+  LOOP_ONE_REDUCE = 6,        // LZ_FLAG_ONE_REDUCE: one all-reduce per iteration
+  LOOP_PARTIAL_DEVICE = 7     // LZ_FLAG_REORTH_PARTIAL, default: the omega-recurrence and the sweep decision live on the device
 };
 
 Loop choose_loop(lz_handle h, int n) {
@@ -820,6 +863,9 @@ Loop choose_loop(lz_handle h, int n) {
   const bool default_kernels = h->qplan.family == 2 && !(f & (LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->tune[1] == 0 && h->tune[8] == 0;
   const bool full_fused = (f & LZ_FLAG_FUSED_NORM) && !(f & LZ_FLAG_REORTH_PARTIAL);
   if ((f & LZ_FLAG_ONE_REDUCE) && !(f & LZ_FLAG_REORTH_PARTIAL) && h->qplan.family == 2) return LOOP_ONE_REDUCE;
+  // partial re-orthogonalisation: device-resident decisions with the default kernels (tune[18] == 1: the host-decided loop,
+  // two scalars read back per step - kept for the bit-identity test and as an A/B arm)
+  if ((f & LZ_FLAG_REORTH_PARTIAL) && default_kernels && h->tune[18] != 1 && !(f & LZ_FLAG_OVERLAP_HALO)) return LOOP_PARTIAL_DEVICE;
   const bool one_rank = h->world == 1 && h->comm_kind == 0;
 #ifdef LZ_KBENCH
   const bool want_steps = h->tune[15] == 5 && n <= kSmallStepMaxN;
@@ -860,12 +906,14 @@ int run_loop_six(lz_handle h, int n, int* sweeps_out, int j0 = 0) {
     if (!h->h_pinned) LZ_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), 8 * sizeof(double), hipHostMallocDefault));
     w_prev.assign((size_t)n + 1, 0.0);
     w_cur.assign((size_t)n + 1, 0.0);
+    w_cur[0] = 1.0;  // omega_{0,0} = v_0 . v_0 (until round 4 this row was all zero, which made a spurious sweep due at j = 2)
     w_new.assign((size_t)n + 1, 0.0);
     ha.assign((size_t)n + 1, 0.0);
     hb.assign((size_t)n + 1, 0.0);
     double nrm2 = 0.0;
     LZ_HIP(h, hipMemcpyAsync(&nrm2, h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     LZ_HIP(h, hipStreamSynchronize(h->stream));
+    h->host_syncs += 1;
     hb[0] = std::sqrt(nrm2);
   }
   bool force_next = false;
@@ -917,6 +965,7 @@ int run_loop_six(lz_handle h, int n, int* sweeps_out, int j0 = 0) {
       LZ_HIP(h, hipMemcpyAsync(&two[0], h->d_alpha + j, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       LZ_HIP(h, hipMemcpyAsync(&two[1], h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
       LZ_HIP(h, hipStreamSynchronize(h->stream));
+      h->host_syncs += 1;
       ha[(size_t)j] = two[0];
       hb[(size_t)j + 1] = std::sqrt(two[1]);
       normA = std::max(normA, std::fabs(two[0]) + hb[(size_t)j] + hb[(size_t)j + 1]);
@@ -924,6 +973,136 @@ int run_loop_six(lz_handle h, int n, int* sweeps_out, int j0 = 0) {
   }
   *sweeps_out = sweeps;
   return LZ_OK;
+}
+
+// ---- partial re-orthogonalisation, device-resident (round 4; the default of LZ_FLAG_REORTH_PARTIAL) -----------------------
+// The loop above with the host taken out: Simon's omega-recurrence runs in a one-block kernel behind the three-term kernel
+// (k_omega, lz_reorth.hip; on one rank it also folds the ||r||^2 partials, so it costs no launch), which leaves a gate in
+// device memory; the sweep kernels of the next step (pass 1, second-stage sums, pass 2) are always enqueued and return at
+// once when the gate says no sweep is due.  No read-back, no hipStreamSynchronize between the first and the last launch
+// (lz_last_host_syncs == 0 on one rank / over RCCL).  Every rank takes the same decision: its inputs are all-reduced sums.
+// A step without a sweep on one rank with an ELL-ordered fixed-K matrix is TWO streaming kernels: the SpMV forms
+// v_j = r / beta itself wherever it reads x (k_spmv_ell<.., SC>: the separate 16M-byte scale pass is gone; r and y
+// ping-pong between two buffers), and the three-term kernel.  Other matrices keep the (gated) scale kernel.
+// Decisions, coefficients and basis are bit-identical to the host-decided loop (tests/test_gpu_lanczos.py).
+int run_loop_partial_device(lz_handle h, int n) {
+  const double M = (double)h->rows;
+  if (h->om_n < n) {
+    LZ_TRY(dev_alloc(h, h->d_om, omega_state_doubles(n)));
+    LZ_TRY(dev_alloc(h, h->d_omi, omega_state_ints(n)));
+    h->om_n = n;
+  }
+  const int* gate = h->d_omi;
+  const bool one_rank = h->world <= 1 && !(h->tune[6] && h->comm_kind);
+  const bool fuse_scale = one_rank && h->kind == 1 && ell_usable(h->csr, h->flags) && h->tune[18] != 2;
+  // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0; ||r||^2
+  LZ_TRY(step_spmv(h, 0));
+  int np = 0;
+  auto three_term_and_decide = [&](int j, int jm1, const double* d_alpha, const double* d_beta, double* r, bool decide, int jn) -> int {
+    {
+      Scope sc(h, LZ_K_THREE, (jm1 >= 0 ? 32.0 : 24.0) * M, (jm1 >= 0 ? 6.0 : 4.0) * M);
+      np = launch_three_term(r, h->d_V + (int64_t)j * h->ldv, jm1 >= 0 ? h->d_V + (int64_t)jm1 * h->ldv : nullptr, d_alpha, d_beta, h->rows_pad,
+                             h->d_part, h->stream);
+      LZ_TRY(check_launch(h, "three_term"));
+    }
+    Scope sc(h, LZ_K_FINAL, 0, 0);
+    if (one_rank && decide) {
+      launch_omega(h->d_part, np, h->d_nrm2, h->d_alpha, jn, n, h->d_om, h->d_omi, h->stream);
+      return check_launch(h, "final_sum(nrm2) + omega");
+    }
+    launch_final_sum(h->d_part, np, h->d_nrm2, h->stream);
+    LZ_TRY(check_launch(h, "final_sum(nrm2)"));
+    LZ_TRY(comm_allreduce(h, h->d_nrm2, 1));
+    if (decide) {
+      launch_omega(nullptr, 0, h->d_nrm2, h->d_alpha, jn, n, h->d_om, h->d_omi, h->stream);
+      LZ_TRY(check_launch(h, "omega"));
+    }
+    return LZ_OK;
+  };
+  LZ_TRY(three_term_and_decide(0, -1, h->d_alpha, nullptr, h->d_r, true, 0));
+  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+  double* rcur = h->d_r;   // the residual entering the step
+  double* rnext = h->d_r2; // where the fused SpMV writes y (it reads r through its gathers: not in place)
+  for (int j = 0; j < n; ++j) {
+    h->prof_iter = (j % pstride) == pstride / 2;
+    const int bidx = (j + n - 2) % (n - 1);
+    double* vj = h->d_V + (int64_t)j * h->ldv;
+    // the sweep (gated; bytes are accounted after the run from the device's sweep log: the host does not know which ran)
+    {
+      QtwFuse fz;
+      fz.gate = gate;
+      h->qplan.variant = 0;
+      {
+        Scope sc(h, LZ_K_QTW, 0, 0);
+        LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, j + 1, j, rcur, h->d_nrm2, h->d_beta + bidx, h->qplan, h->d_part, 1, h->stream, &fz));
+        LZ_TRY(check_launch(h, "qtw(gated)"));
+      }
+      {
+        Scope sc(h, LZ_K_FINAL, 0, 0);
+        launch_final_rows(h->d_part, j + 1, h->qplan.P, h->d_c, h->stream, true, gate);
+        LZ_TRY(check_launch(h, "final_rows(gated)"));
+      }
+      LZ_TRY(comm_allreduce(h, h->d_c, j + 1));  // (N > 1: issued every step - the host cannot skip a collective the device may need)
+      {
+        Scope sc(h, LZ_K_UPDATE, 0, 0);
+        launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_c, nullptr, h->d_beta + bidx, 0, h->stream, 0, -1, 0, 0, 0, 0, 0, gate);
+        LZ_TRY(check_launch(h, "update(gated)"));
+      }
+    }
+    if (fuse_scale) {
+      SpmvScale ss;
+      ss.r = rcur;
+      ss.nrm2 = h->d_nrm2;
+      ss.vj = vj;
+      ss.beta_slot = h->d_beta + bidx;
+      ss.gate = gate;
+      int npa = 0;
+      {
+        Scope sc(h, LZ_K_SPMV, spmv_bytes(h) + 16.0 * M, spmv_flops(h) + M);  // (the scale pass's 16M bytes ride here: BASELINE.md's accounting of the step is unchanged)
+        npa = launch_spmv_ell(h->csr, vj, rnext, vj, h->d_part, h->stream, &ss);
+        LZ_TRY(check_launch(h, "spmv(ell, scale fused)"));
+      }
+      {
+        Scope sc(h, LZ_K_FINAL, 0, 0);
+        launch_final_sum(h->d_part, npa, h->d_alpha + j, h->stream);
+        LZ_TRY(check_launch(h, "final_sum(alpha)"));
+      }
+      std::swap(rcur, rnext);
+    } else {
+      {
+        Scope sc(h, LZ_K_QTW, 16.0 * M, M);
+        launch_scale_store(vj, rcur, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream, gate);
+        LZ_TRY(check_launch(h, "scale_store(gated)"));
+      }
+      LZ_TRY(step_spmv(h, j));  // r = A V[j] into h->d_r (== rcur), alpha_j
+    }
+    // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
+    LZ_TRY(three_term_and_decide(j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, rcur, j + 1 < n, j + 1));
+  }
+  if (rcur != h->d_r) std::swap(h->d_r, h->d_r2);  // the residual entering step n is what lz_get_residual hands out
+  return LZ_OK;
+}
+
+// after the final synchronisation of lz_run: the device's sweep log -> lz_last_sweeps and the byte / flop accounting of the
+// gated launches (pass 1: 8 j M + 16 M bytes, pass 2 the same; in a swept step the scale kernel / fused scale did no work)
+void account_partial_device(lz_handle h, int n, const std::vector<int>& log, int* sweeps_out) {
+  const double M = (double)h->rows;
+  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+  int sweeps = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!log[(size_t)2 + j]) continue;
+    ++sweeps;
+    // (pass 1's read of r and write of V[j], 16 M bytes, are on the books already: the scale pass is accounted in every step)
+    const double flops = 2.0 * (j + 1) * M;
+    const bool timed = (h->flags & LZ_FLAG_PROFILE) != 0 && (j % pstride) == pstride / 2;
+    for (int cls : {LZ_K_QTW, LZ_K_UPDATE}) {
+      const double bytes = 8.0 * j * M + (cls == LZ_K_UPDATE ? 16.0 * M : 0.0);
+      h->acc.bytes[cls] += bytes;
+      h->acc.flops[cls] += flops;
+      if (timed) h->acc.timed_bytes[cls] += bytes;
+    }
+  }
+  *sweeps_out = sweeps;
 }
 
 // Breakdown report.  The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov
@@ -1023,6 +1202,11 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   // than a quarter of the entries sit further than 2^18 columns from the diagonal.  tune[14]: 1 = never, 2 = always
   // (tests run it on small matrices).
   pb_free(A.pb);
+  // Fixed-K rows (stencils): the ELL-ordered second copy (lz_spmv.hip, k_spmv_ell) - lanes own whole rows, coalesced loads
+  // and gathers, no LDS staging.  tune[17]: 0 auto (built for K in {5, 7, 27}), 1 never (the CSR-order kernel k_spmv_fixed /
+  // the CSR-stream kernel), 2 one row per lane and trip, 3 two adjacent rows per lane.
+  ell_free(A);
+  if (h->tune[17] != 1 && (fixed_k == 5 || fixed_k == 7 || fixed_k == 27)) LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
   const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
     const hipError_t pe = pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]);
@@ -1039,34 +1223,67 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
 int upload_csr(lz_handle h, CsrDev& A, const char* who, int64_t rows, int64_t ncols, int64_t nnz, const int32_t* rowptr,
                const int32_t* colidx, const double* vals, int* fixed_k_out, int* max_nnz_out) {
   if (rowptr[0] != 0 || rowptr[rows] != nnz) return fail(h, LZ_ERR_ARG, std::string(who) + ": rowptr[0] != 0 or rowptr[rows] != nnz");
-  int max_nnz = 0;
-  int fixed_k = (int)(rows > 0 ? rowptr[1] - rowptr[0] : 0);
-  for (int64_t i = 0; i < rows; ++i) {
-    const int64_t d = (int64_t)rowptr[i + 1] - rowptr[i];
-    if (d < 0) return fail(h, LZ_ERR_ARG, std::string(who) + ": rowptr not monotone");
-    if (d > max_nnz) max_nnz = (int)d;
-    if (d != fixed_k) fixed_k = 0;
-  }
-  int64_t far = 0;
-  for (int64_t i = 0; i < rows; ++i)
-    for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-      const int64_t c = colidx[k];
-      if (c < 0 || c >= ncols) return fail(h, LZ_ERR_ARG, std::string(who) + ": column index out of range");
-      far += (c > i ? c - i : i - c) > ((int64_t)1 << 18);
+  const bool dbg = getenv("LZ_DEBUG_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  // one sweep over the rows and their entries, split over host threads (round 3: two single-thread loops, 0.35 s at the
+  // headline's 5e7 entries): row lengths monotone, their maximum, whether all are equal, column range, share of far entries
+  struct Part {
+    int max_nnz = 0;
+    bool same = true, bad_ptr = false, bad_col = false;
+    int64_t far = 0;
+  } parts[kMaxHostThreads];
+  const int64_t k_first = rows > 0 ? (int64_t)rowptr[1] - rowptr[0] : 0;
+  parallel_ranges(rows, 1 << 16, [&](int t, int64_t lo, int64_t hi) {
+    Part& p = parts[t];
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t a = rowptr[i], b = rowptr[i + 1], d = b - a;
+      if (d < 0 || a < 0 || b > nnz) {
+        p.bad_ptr = true;
+        return;
+      }
+      if (d > p.max_nnz) p.max_nnz = (int)d;
+      if (d != k_first) p.same = false;
+      for (int64_t k = a; k < b; ++k) {
+        const int64_t c = colidx[k];
+        if (c < 0 || c >= ncols) {
+          p.bad_col = true;
+          return;
+        }
+        p.far += (c > i ? c - i : i - c) > ((int64_t)1 << 18);
+      }
     }
+  });
+  int max_nnz = 0;
+  int fixed_k = (int)k_first;
+  int64_t far = 0;
+  for (const Part& p : parts) {
+    if (p.bad_ptr) return fail(h, LZ_ERR_ARG, std::string(who) + ": rowptr not monotone");
+    if (p.bad_col) return fail(h, LZ_ERR_ARG, std::string(who) + ": column index out of range");
+    if (p.max_nnz > max_nnz) max_nnz = p.max_nnz;
+    if (!p.same) fixed_k = 0;
+    far += p.far;
+  }
   A.far_frac = nnz > 0 ? (double)far / (double)nnz : 0.0;
+  const double t1 = now();
   pb_free(A.pb);
+  ell_free(A);
   if (fixed_k > 64) fixed_k = 0;
   LZ_TRY(dev_alloc(h, A.rowptr, (size_t)rows + 1));
   LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
   LZ_TRY(dev_alloc(h, A.vals, (size_t)nnz + 2));
-  LZ_HIP(h, hipMemset(A.colidx, 0, ((size_t)nnz + 2) * sizeof(int32_t)));
-  LZ_HIP(h, hipMemset(A.vals, 0, ((size_t)nnz + 2) * sizeof(double)));
-  LZ_HIP(h, hipMemcpy(A.rowptr, rowptr, ((size_t)rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  LZ_HIP(h, hipMemsetAsync(A.colidx + nnz, 0, 2 * sizeof(int32_t), h->stream));  // (the kernels read pairs: two pad entries)
+  LZ_HIP(h, hipMemsetAsync(A.vals + nnz, 0, 2 * sizeof(double), h->stream));
+  LZ_TRY(upload(h, A.rowptr, rowptr, ((size_t)rows + 1) * sizeof(int32_t)));
   if (nnz > 0) {
-    LZ_HIP(h, hipMemcpy(A.colidx, colidx, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
-    LZ_HIP(h, hipMemcpy(A.vals, vals, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    LZ_TRY(upload(h, A.colidx, colidx, (size_t)nnz * sizeof(int32_t)));
+    LZ_TRY(upload(h, A.vals, vals, (size_t)nnz * sizeof(double)));
   }
+  const double t2 = now();
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  if (dbg)
+    fprintf(stderr, "[%s] validation sweep %.3f ms, device alloc %.3f ms, H2D of %.1f MB %.3f ms\n", who, t1 - t0, t2 - t1,
+            (12.0 * nnz + 4.0 * rows) / 1e6, now() - t2);
   *fixed_k_out = fixed_k;
   *max_nnz_out = max_nnz;
   A.host_colidx = colidx;  // for pb_build (fill_csr_meta, same API call): diagonal split, fp32-exact value check
@@ -1132,6 +1349,8 @@ int lz_destroy(lz_handle h) {
   hipFree(h->csr.rowblk);
   pb_free(h->csr.pb);
   pb_free(h->csrT.pb);
+  ell_free(h->csr);
+  ell_free(h->csrT);
   hipFree(h->d_dense);
   hipFree(h->d_V);
   hipFree(h->d_r);
@@ -1156,6 +1375,8 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_send_idx);
   hipFree(h->d_sendbuf);
   hipFree(h->d_xfull);
+  hipFree(h->d_om);
+  hipFree(h->d_omi);
   if (h->h_pinned) hipHostFree(h->h_pinned);
   xfer_free(h->xfer);
   if (h->cstream) {
@@ -1433,9 +1654,10 @@ int lz_set_dense_block(lz_handle h, int64_t M_global, int64_t row0, int64_t rows
   h->n = 0;
   const int64_t lda = (ncols_ext + 1) & ~(int64_t)1;
   LZ_TRY(dev_alloc(h, h->d_dense, (size_t)rows_local * lda + 2));
-  if (lda != ncols_ext) LZ_HIP(h, hipMemset(h->d_dense, 0, ((size_t)rows_local * lda + 2) * sizeof(double)));
-  LZ_HIP(h, hipMemcpy2D(h->d_dense, (size_t)lda * sizeof(double), A, (size_t)ncols_ext * sizeof(double), (size_t)ncols_ext * sizeof(double),
-                        (size_t)rows_local, hipMemcpyHostToDevice));
+  if (lda != ncols_ext) LZ_HIP(h, hipMemsetAsync(h->d_dense, 0, ((size_t)rows_local * lda + 2) * sizeof(double), h->stream));
+  LZ_TRY(upload2d(h, h->d_dense, (size_t)lda * sizeof(double), A, (size_t)ncols_ext * sizeof(double), (size_t)ncols_ext * sizeof(double),
+                  (size_t)rows_local));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
   h->dense_lda = lda;
   h->Mg = M_global;
   h->row0 = row0;
@@ -1716,9 +1938,10 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_TRY(basis_alloc(h, n, 1));
   h->halo_inflight_j = -1;
   const double t1 = now();
-  LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_TRY(upload(h, h->d_V, v0_local, (size_t)h->rows * sizeof(double)));
   const double t2 = now();
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+  h->host_syncs = 0;
   const Loop loop = choose_loop(h, n);
   const bool one_reduce = loop == LOOP_ONE_REDUCE;
   int sweeps = n;
@@ -1739,10 +1962,12 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     case LOOP_FUSED_SMALL: LZ_TRY(run_loop_fused_small(h, n)); break;
     case LOOP_THREE_TERM_FUSED: LZ_TRY(run_loop_three_term_fused(h, n)); break;
     case LOOP_ONE_REDUCE: LZ_TRY(run_loop_onereduce(h, n)); break;
+    case LOOP_PARTIAL_DEVICE: LZ_TRY(run_loop_partial_device(h, n)); break;
     default: LZ_TRY(run_loop_six(h, n, &sweeps)); break;
   }
   h->last_sweeps = sweeps;
-  h->r_state = (h->last_engine == LOOP_SIX) ? 1 : (h->last_engine == LOOP_FUSED_SMALL || h->last_engine == LOOP_THREE_TERM_FUSED) ? 2 : 0;
+  h->r_state = (h->last_engine == LOOP_SIX || h->last_engine == LOOP_PARTIAL_DEVICE) ? 1
+               : (h->last_engine == LOOP_FUSED_SMALL || h->last_engine == LOOP_THREE_TERM_FUSED) ? 2 : 0;
   h->prof_iter = true;
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
   const double t3 = now();
@@ -1751,7 +1976,13 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   double onered_bad = 0.0;
   if (one_reduce) LZ_HIP(h, hipMemcpyAsync(&onered_bad, h->d_nrm2 + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<int> sweep_log;
+  if (loop == LOOP_PARTIAL_DEVICE) {
+    sweep_log.resize(omega_state_ints(n));
+    LZ_HIP(h, hipMemcpyAsync(sweep_log.data(), h->d_omi, sweep_log.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  }
   LZ_HIP(h, hipStreamSynchronize(h->stream));
+  if (loop == LOOP_PARTIAL_DEVICE) account_partial_device(h, n, sweep_log, &h->last_sweeps);
   if (one_reduce && onered_bad != 0.0) {
     // cancellation guard of the one-reduce loop (k_onereduce_prepare): |r|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u lost too
     // many digits at some step (|alpha| >> beta).  Every rank sees the same reduced sums, so every rank takes this branch:
@@ -1809,9 +2040,8 @@ int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_
     return fail(h, LZ_ERR_STATE, "lz_run_resume: not with partial re-orthogonalisation (its omega-recurrence lives on the host) or the one-reduce loop");
   LZ_TRY(basis_alloc(h, n, 1));
   h->halo_inflight_j = -1;
-  LZ_HIP(h, hipMemcpy2DAsync(h->d_V, (size_t)h->ldv * sizeof(double), V_rows, (size_t)ldv_in * sizeof(double), (size_t)h->rows * sizeof(double),
-                             (size_t)j0, hipMemcpyHostToDevice, h->stream));
-  LZ_HIP(h, hipMemcpyAsync(h->d_r, r_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_TRY(upload2d(h, h->d_V, (size_t)h->ldv * sizeof(double), V_rows, (size_t)ldv_in * sizeof(double), (size_t)h->rows * sizeof(double), (size_t)j0));
+  LZ_TRY(upload(h, h->d_r, r_local, (size_t)h->rows * sizeof(double)));
   LZ_HIP(h, hipMemcpyAsync(h->d_alpha, alpha_in, (size_t)j0 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (j0 > 1) LZ_HIP(h, hipMemcpyAsync(h->d_beta, beta_in, (size_t)(j0 - 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
@@ -2405,6 +2635,12 @@ int lz_ritz_quality(lz_handle h, double* out) {
 int lz_last_engine(lz_handle h, int* engine) {
   if (!h || !engine) return LZ_ERR_ARG;
   *engine = h->last_engine;
+  return LZ_OK;
+}
+
+int lz_last_host_syncs(lz_handle h, int64_t* syncs) {
+  if (!h || !syncs) return LZ_ERR_ARG;
+  *syncs = h->host_syncs;
   return LZ_OK;
 }
 

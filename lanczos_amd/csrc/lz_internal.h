@@ -36,6 +36,12 @@ struct CsrDev {
   double avg_row_nnz = 0;
   double far_frac = 0;        // share of entries whose column is > 2^18 away from their row: no L2 reuse of x to speak of
   struct PbDev* pb = nullptr; // column-blocked two-phase layout (lz_spmv_pb.hip), built when the matrix has no column locality
+  // ELL-ordered copy of a fixed-K matrix (lz_spmv.hip, k_spmv_ell): blocks of ell_rb rows, entry k of every row of a block
+  // contiguous - a lane owns whole rows, its loads and the stencil's gathers are coalesced, no LDS transposition.
+  int32_t* ell_c = nullptr;
+  double* ell_v = nullptr;
+  int ell_rb = 0;             // rows per block of the ELL copy (0: none)
+  int ell_variant = 0;        // 0: one row per lane and trip (rows t, t + 256, ...); 1: two adjacent rows per lane (16-byte loads)
   const int32_t* host_colidx = nullptr;  // the caller's arrays, valid ONLY inside lz_set_csr / lz_set_csr_transpose (pb_build reads them)
   const double* host_vals = nullptr;
 };
@@ -51,6 +57,23 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
 // y = A x (rows), part[b] = sum_{rows of block b} x_own[i] * y[i]; returns number of partials written
 int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
                     hipStream_t s);
+// ELL copy of a fixed-K matrix (K in {5, 7, 27}); variant as CsrDev::ell_variant.  ell_free releases it.
+hipError_t ell_build(CsrDev& A, int variant, hipStream_t s);
+void ell_free(CsrDev& A);
+bool ell_usable(const CsrDev& A, int flags);
+// The device-resident partial re-orthogonalisation loop's SpMV: when gate[0] == 0 (no sweep ran on this vector) the kernel
+// forms v_j = r / sqrt(nrm2[0]) ITSELF wherever it reads an entry of x (IEEE division: the same bits wherever it is formed),
+// stores the rows it owns to vj and beta to beta_slot; when gate[0] != 0 the sweep kernels have written vj and it is a plain
+// y = A vj.  y must not alias r.  Returns the number of alpha partials.
+struct SpmvScale {
+  const double* r = nullptr;
+  const double* nrm2 = nullptr;
+  double* vj = nullptr;
+  double* beta_slot = nullptr;
+  const int* gate = nullptr;
+};
+int launch_spmv_ell(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s,
+                    const SpmvScale* sc = nullptr);
 struct StencilArgs {  // by-value kernel argument of the stencil assembly
   int Nx, Ny, Nz, negate, pot_kind, renumber, nranges;
   int64_t row0, rows_local;
@@ -66,7 +89,7 @@ int launch_gemv_dense(const double* A, int64_t M, int64_t cols, int64_t lda, con
 void launch_final_sum(const double* part, int n, double* out, hipStream_t s);
 // c[i] = sum_b part[i*G + b]; transposed (4x4x4 MFMA kernel): c[i] = sum_b part[b*qtw_ldp(nrows) + i]
 inline int qtw_ldp(int nrows) { return (nrows + 15) & ~15; }
-void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed = false);
+void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed = false, const int* gate = nullptr);
 void launch_final_rows_t(const double* part, int G, int ldp, int nout, double* c, hipStream_t s);
 
 struct QtwPlan {
@@ -90,6 +113,7 @@ struct QtwFuse {
   const double* beta_prev = nullptr;
   double* alpha_out = nullptr;
   double* r_out = nullptr;        // where r goes (NOT y itself: with the row split several blocks read the same slice of y)
+  const int* gate = nullptr;      // any mode: the kernel returns at once when gate[0] == 0 (device-resident partial re-orthogonalisation)
 };
 // returns the error of the per-kernel LDS-limit raise (hipFuncSetAttribute), if that was needed and failed
 hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,
@@ -101,8 +125,18 @@ hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, con
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
                    double* beta, int variant, hipStream_t s, int64_t pos_lo = 0, int64_t pos_hi = -1, int raw_c = 0,
                    int64_t pos_lo_b = 0, int64_t pos_hi_b = 0,  // second range: only with the small-range (face) kernel
-                   int cG = 0, int cldp = 0);
-void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s);
+                   int cG = 0, int cldp = 0, const int* gate = nullptr);
+// gate != nullptr: runs only when gate[0] == 0 (the step without a sweep)
+void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s, const int* gate = nullptr);
+// ---- device-resident partial re-orthogonalisation (Simon's omega-recurrence in a one-block kernel) ----
+// State: st[0] = ||A|| estimate, st[1] = force_next, st[2 .. 2 + n + 2) = hb (hb[k] = the norm that formed V[k]), then three
+// rows of n + 1 doubles (omega_{j,:} lives in row j % 3); ist[0] = the gate of the coming step (1: sweep), ist[1] = number of
+// sweeps so far, ist[2 + j] = whether step j swept.
+inline size_t omega_state_doubles(int n) { return (size_t)2 + (n + 2) + 3 * (size_t)(n + 1); }
+inline size_t omega_state_ints(int n) { return (size_t)2 + n + 1; }
+// Prepares the decision for step jn (called after step jn - 1 has left alpha[jn-1] and ||r||^2; jn == 0: after the warm-up).
+// part != nullptr: first nrm2[0] = sum(part[0..np)) in k_final_sum's order (single rank: one launch for both).
+void launch_omega(const double* part, int np, double* nrm2, const double* alpha, int jn, int n, double* st, int* ist, hipStream_t s);
 void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s);
 void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, double* bad, hipStream_t s);
 // r = (r - alpha v_j) - beta v_jm1 ; part[b] = partial ||r||^2 ; returns number of partials

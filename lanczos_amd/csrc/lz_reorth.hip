@@ -21,27 +21,167 @@ namespace lz {
 
 // ------------------------------------------------------------------ second-stage reductions
 constexpr int kFinalThreads = 1024;
-__global__ __launch_bounds__(kFinalThreads) void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
-  __shared__ double sm[kFinalThreads / 64];
+// sum(part[0..n)) by one block of 1024 threads: four strided accumulators per thread (a full group of four while
+// i + 3 * 1024 < n, the remainder into the first), wave shuffle tree, 16 wave sums added in order.  The grouping is part of
+// the contract (final_sum_emulated in lz_device.h replays it).  Up to 24 576 partials (the headline's SpMV leaves 19 532)
+// every load of a thread is issued before its first add: the partials were written by another kernel on other XCDs, each
+// load is a round trip to the memory side, and the plain loop paid eight of them one after the other (4.7 us for this
+// kernel, now one or two) - same adds in the same order, same bits.  The result is valid in thread 0.
+__device__ __forceinline__ double final_sum_1024(const double* __restrict__ part, int n, double* sm) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  int i = threadIdx.x;
-  for (; i + 3 * kFinalThreads < n; i += 4 * kFinalThreads) {
-    a0 += part[i];
-    a1 += part[i + kFinalThreads];
-    a2 += part[i + 2 * kFinalThreads];
-    a3 += part[i + 3 * kFinalThreads];
+  constexpr int GMAX = 6;
+  if (n <= GMAX * 4 * kFinalThreads) {
+    double v[GMAX * 4];
+#pragma unroll
+    for (int q = 0; q < GMAX * 4; ++q) {
+      const int idx = threadIdx.x + q * kFinalThreads;
+      v[q] = idx < n ? part[idx] : 0.0;
+    }
+    bool tail = false;
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) {
+      const int i = threadIdx.x + g * 4 * kFinalThreads;
+      if (!tail && i + 3 * kFinalThreads < n) {
+        a0 += v[4 * g];
+        a1 += v[4 * g + 1];
+        a2 += v[4 * g + 2];
+        a3 += v[4 * g + 3];
+      } else {  // the plain loop's remainder: everything left goes into a0, in index order
+        tail = true;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i + u * kFinalThreads < n) a0 += v[4 * g + u];
+      }
+    }
+  } else {
+    int i = threadIdx.x;
+    for (; i + 3 * kFinalThreads < n; i += 4 * kFinalThreads) {
+      a0 += part[i];
+      a1 += part[i + kFinalThreads];
+      a2 += part[i + 2 * kFinalThreads];
+      a3 += part[i + 3 * kFinalThreads];
+    }
+    for (; i < n; i += kFinalThreads) a0 += part[i];
   }
-  for (; i < n; i += kFinalThreads) a0 += part[i];
-  double acc = wave_sum((a0 + a1) + (a2 + a3));
+  const double acc = wave_sum((a0 + a1) + (a2 + a3));
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) sm[w] = acc;
   __syncthreads();
+  double t = 0.0;
   if (threadIdx.x == 0) {
-    double t = 0.0;
 #pragma unroll
     for (int k = 0; k < kFinalThreads / 64; ++k) t += sm[k];
-    out[0] = t;
   }
+  return t;
+}
+
+__global__ __launch_bounds__(kFinalThreads) void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
+  __shared__ double sm[kFinalThreads / 64];
+  const double t = final_sum_1024(part, n, sm);
+  if (threadIdx.x == 0) out[0] = t;
+}
+
+// ------------------------------------------------------------------ partial re-orthogonalisation: the decision, on the device
+// Simon's omega-recurrence (H. D. Simon 1984): omega_{j,k} estimates v_j . v_k from alpha and beta alone; a sweep is due when
+// max_k |omega_{j,k}| exceeds sqrt(eps), on that vector and the next.  One block; called once per step, AFTER the three-term
+// kernel of step jn - 1 (optionally folding that kernel's ||r||^2 partials first, with k_final_sum's exact grouping), it leaves
+// the gate of step jn in ist[0].  The sweep kernels and the SpMV of step jn read the gate: lz_run never waits for the device.
+// Arithmetic: expression for expression the host loop this replaces (run_loop_six, lz_api.hip; both compiled with
+// -ffp-contract=off, IEEE sqrt and division), every k is independent and the maximum does not depend on the order, so the
+// decisions - and with them every coefficient - are bit-identical to the host-decided run (tests/test_gpu_lanczos.py).
+// State layout: see omega_state_doubles (lz_internal.h).
+__global__ __launch_bounds__(kFinalThreads) void k_omega(const double* __restrict__ part, int np, double* __restrict__ nrm2,
+                                                        const double* __restrict__ alpha, int jn, int n, double* __restrict__ st,
+                                                        int* __restrict__ ist) {
+  __shared__ double sm[kFinalThreads / 64];
+  __shared__ double s_nrm2;
+  __shared__ int s_sweep;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (part) {  // k_final_sum's own code
+    const double t = final_sum_1024(part, np, sm);
+    if (threadIdx.x == 0) {
+      nrm2[0] = t;
+      s_nrm2 = t;
+    }
+  } else if (threadIdx.x == 0) {
+    s_nrm2 = nrm2[0];
+  }
+  __syncthreads();
+  const double eps = 2.220446049250313e-16, thresh = 1.4901161193847656e-08;
+  double* hb = st + 2;
+  double* W = hb + (n + 2);
+  const int ldw = n + 1;
+  const double hbj = sqrt(s_nrm2);
+  if (jn == 0) {  // after the warm-up: clear the state; step 0 always sweeps (a one-row sweep)
+    for (int i = threadIdx.x; i < 3 * ldw; i += kFinalThreads) W[i] = i == 0 ? 1.0 : 0.0;  // omega_{0,0} = v_0 . v_0
+    for (int i = threadIdx.x; i < n + 2; i += kFinalThreads) hb[i] = i == 0 ? hbj : 0.0;
+    if (threadIdx.x == 0) {
+      st[0] = 0.0;
+      st[1] = 0.0;
+      ist[0] = 1;
+      ist[1] = 1;
+      ist[2] = 1;
+    }
+    return;
+  }
+  // beta_j omega_{j,k} = beta_{k+1} omega_{j-1,k+1} + (alpha_k - alpha_{j-1}) omega_{j-1,k} + beta_k omega_{j-1,k-1}
+  //                      - beta_{j-1} omega_{j-2,k}  (+ rounding of size eps ||A||),   k <= j-2
+  const double a_last = alpha[jn - 1];
+  const double hb_prev = hb[jn - 1];
+  double normA = st[0];
+  {
+    const double cand = fabs(a_last) + hb_prev + hbj;
+    if (cand > normA) normA = cand;
+  }
+  const double* cur = W + (size_t)((jn + 2) % 3) * ldw;   // omega_{jn-1,:}
+  const double* prev = W + (size_t)((jn + 1) % 3) * ldw;  // omega_{jn-2,:}
+  double* nw = W + (size_t)(jn % 3) * ldw;
+  double worst = 0.0;
+  for (int k = threadIdx.x; k <= n; k += kFinalThreads) {
+    double v = 0.0;
+    if (k == jn) {
+      v = 1.0;
+    } else if (k == jn - 1) {
+      v = eps;
+    } else if (k + 2 <= jn) {
+      double t = hb[k + 1] * cur[k + 1] + (alpha[k] - a_last) * cur[k] - hb_prev * prev[k];
+      if (k > 0) t += hb[k] * cur[k - 1];
+      t += (t < 0 ? -1.0 : 1.0) * 2.0 * eps * normA;
+      v = t / hbj;
+      const double av = fabs(v);
+      if (av > worst) worst = av;
+    }
+    nw[k] = v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(worst, off, 64);
+    if (o > worst) worst = o;
+  }
+  __syncthreads();  // (sm is reused)
+  if (lane == 0) sm[w] = worst;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+#pragma unroll
+    for (int k = 0; k < kFinalThreads / 64; ++k)
+      if (sm[k] > m) m = sm[k];
+    const bool due = m > thresh;
+    const int sweep = (due || st[1] != 0.0) ? 1 : 0;  // a due sweep also covers the next vector (both feed the recurrence)
+    st[1] = due ? 1.0 : 0.0;
+    st[0] = normA;
+    hb[jn] = hbj;
+    ist[0] = sweep;
+    ist[1] += sweep;
+    ist[2 + jn] = sweep;
+    s_sweep = sweep;
+  }
+  __syncthreads();
+  if (s_sweep)
+    for (int k = threadIdx.x; k < jn; k += kFinalThreads) nw[k] = eps;
+}
+void launch_omega(const double* part, int np, double* nrm2, const double* alpha, int jn, int n, double* st, int* ist, hipStream_t s) {
+  hipLaunchKernelGGL(k_omega, dim3(1), dim3(kFinalThreads), 0, s, part, np, nrm2, alpha, jn, n, st, ist);
 }
 
 __global__ __launch_bounds__(kTPB) void k_final_rows(const double* __restrict__ part, int G, double* __restrict__ c) {
@@ -56,7 +196,8 @@ __global__ __launch_bounds__(kTPB) void k_final_rows(const double* __restrict__ 
 // Transposed partial layout of the 4x4x4 MFMA kernel: part[pid * ldp + row].  One block owns 8 rows (one 64-byte
 // sector of every pid's run): 128 pid lanes x 8 row lanes, fixed summation order.
 __global__ __launch_bounds__(kFinalThreads) void k_final_rows_t(const double* __restrict__ part, int P, int ldp, int nrows,
-                                                              double* __restrict__ c) {
+                                                              double* __restrict__ c, const int* __restrict__ gate) {
+  if (gate && gate[0] == 0) return;  // device-resident partial re-orthogonalisation: no sweep on this vector
   __shared__ double sm[kFinalThreads / 8][8];
   const int rl = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int row = blockIdx.x * 8 + rl;  // < ldp (a multiple of 8); rows >= nrows hold stale values and are never stored
@@ -86,12 +227,12 @@ void launch_final_sum(const double* part, int n, double* out, hipStream_t s) {
 // explicit run length: c[i] = sum_b part[b * ldp + i], i < nout (one-reduce mode: two coefficient runs per block)
 void launch_final_rows_t(const double* part, int G, int ldp, int nout, double* c, hipStream_t s) {
   if (nout <= 0) return;
-  hipLaunchKernelGGL(k_final_rows_t, dim3((nout + 7) / 8), dim3(kFinalThreads), 0, s, part, G, ldp, nout, c);
+  hipLaunchKernelGGL(k_final_rows_t, dim3((nout + 7) / 8), dim3(kFinalThreads), 0, s, part, G, ldp, nout, c, (const int*)nullptr);
 }
-void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed) {
+void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed, const int* gate) {
   if (nrows <= 0) return;
   if (transposed)
-    hipLaunchKernelGGL(k_final_rows_t, dim3((nrows + 7) / 8), dim3(kFinalThreads), 0, s, part, G, qtw_ldp(nrows), nrows, c);
+    hipLaunchKernelGGL(k_final_rows_t, dim3((nrows + 7) / 8), dim3(kFinalThreads), 0, s, part, G, qtw_ldp(nrows), nrows, c, gate);
   else
     hipLaunchKernelGGL(k_final_rows, dim3(nrows), dim3(kTPB), 0, s, part, G, c);
 }
@@ -327,6 +468,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
                                                    const double* __restrict__ r, const double* __restrict__ nrm2,
                                                    double* __restrict__ beta_slot, int64_t L, int ldp,
                                                    double* __restrict__ part, QtwFuse fz) {
+  if (fz.gate && fz.gate[0] == 0) return;  // device-resident partial re-orthogonalisation: no sweep on this vector
   extern __shared__ double2 sw[];
   // Per-wave coefficients are parked in LDS (after the slice of w) and written when the wave is done, as one contiguous
   // run part[pid][0..nrows): 8-byte partial stores trickling into the read stream cost 6 % of the pass
@@ -719,7 +861,8 @@ template <bool FUSED, int P, int RU>
 __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, int64_t ldv, int64_t p0, int64_t n2, int nrows,
                                                       int j, const double* __restrict__ c, const double* __restrict__ r,
                                                       double* __restrict__ beta, int raw_c, int nblk_a, int64_t p0b,
-                                                      int64_t n2b, int cG, int cldp) {
+                                                      int64_t n2b, int cG, int cldp, const int* __restrict__ gate) {
+  if (gate && gate[0] == 0) return;  // device-resident partial re-orthogonalisation: no sweep on this vector
   // blocks [0, nblk_a) cover positions [p0, n2); any further blocks cover a second range [p0b, n2b) (the two faces of a
   // slab in overlap mode leave in one launch)
   int bx = blockIdx.x;
@@ -860,16 +1003,18 @@ __global__ __launch_bounds__(kTPB) void k_update_elem(double* __restrict__ V, in
 
 template <bool FUSED, int P, int RU>
 static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, int nrows, int j, const double* c, const double* r,
-                                double* beta, int raw_c, hipStream_t s, int64_t p0b = 0, int64_t n2b = 0, int cG = 0, int cldp = 0) {
+                                double* beta, int raw_c, hipStream_t s, int64_t p0b = 0, int64_t n2b = 0, int cG = 0, int cldp = 0,
+                                const int* gate = nullptr) {
   const int grid = (int)((n2 - p0 + kTPB * P - 1) / (kTPB * P));
   const int grid_b = n2b > p0b ? (int)((n2b - p0b + kTPB * P - 1) / (kTPB * P)) : 0;
   hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid + grid_b), dim3(kTPB), raw_c == 2 ? (size_t)nrows * sizeof(double) : 0, s, V, ldv, p0,
-                     n2, nrows, j, c, r, beta, raw_c, grid, p0b, n2b, cG, cldp);
+                     n2, nrows, j, c, r, beta, raw_c, grid, p0b, n2b, cG, cldp, gate);
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
                    double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi, int raw_c, int64_t pos_lo_b,
-                   int64_t pos_hi_b, int cG, int cldp) {
+                   int64_t pos_hi_b, int cG, int cldp, const int* gate) {
+  // gate (device-resident partial re-orthogonalisation): scale-then-dot order and the default slice-owner kernels only
   // double2 positions [pos_lo, pos_hi) of the row (default: the whole row)
   const int64_t n2 = pos_hi >= 0 ? pos_hi : (len >> 1);
   const int64_t p0 = pos_lo > 0 ? pos_lo : 0;
@@ -911,7 +1056,7 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
     // 16 positions per lane, one row per trip (still 16 loads in flight): half as many, longer-lived blocks - fewer
     // residency rounds, so V[j] leaves in fewer, larger write bursts (1250 -> 1218 us at the headline)
     if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
-    else launch_update_slice<false, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
+    else launch_update_slice<false, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
     return;
   }
   if (variant == 0 && span <= 4096 && r_fused && nrows > 64 && pos_hi < 0 && pos_lo <= 0) {
@@ -925,22 +1070,24 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
     // a face of the slab (overlap mode) or a tiny vector: a handful of blocks walk all rows, which is a latency chain,
     // not a bandwidth problem - one position per lane (most blocks) and 32 rows in flight per lane
     if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, pos_lo_b, pos_hi_b, cG, cldp);
-    else launch_update_slice<false, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, pos_lo_b, pos_hi_b);
+    else launch_update_slice<false, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, pos_lo_b, pos_hi_b, 0, 0, gate);
   } else if (P == 8) {
     if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
-    else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
+    else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   } else if (P == 4) {
     if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
-    else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
+    else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   } else {
     if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
-    else launch_update_slice<false, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s);
+    else launch_update_slice<false, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   }
 }
 
 // partial re-orthogonalisation mode, steps without a sweep: V[j] = r / sqrt(nrm2) and nothing else
 __global__ __launch_bounds__(kTPB) void k_scale_store(double* __restrict__ vj, const double* __restrict__ r,
-                                                     const double* __restrict__ nrm2, double* __restrict__ beta_slot, int64_t n2) {
+                                                     const double* __restrict__ nrm2, double* __restrict__ beta_slot, int64_t n2,
+                                                     const int* __restrict__ gate) {
+  if (gate && gate[0] != 0) return;  // device-resident partial re-orthogonalisation: the sweep kernels wrote V[j] and beta
   const double beta = sqrt(nrm2[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0) beta_slot[0] = beta;
   const double2* r2 = reinterpret_cast<const double2*>(r);
@@ -952,12 +1099,12 @@ __global__ __launch_bounds__(kTPB) void k_scale_store(double* __restrict__ vj, c
     v2[i] = x;
   }
 }
-void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s) {
+void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s, const int* gate) {
   const int64_t n2 = len >> 1;
   int64_t g = (n2 + kTPB - 1) / kTPB;
   if (g > 4096) g = 4096;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(k_scale_store, dim3((int)g), dim3(kTPB), 0, s, vj, r, nrm2, beta_slot, n2);
+  hipLaunchKernelGGL(k_scale_store, dim3((int)g), dim3(kTPB), 0, s, vj, r, nrm2, beta_slot, n2, gate);
 }
 
 // fused-norm mode: c holds the all-reduced [V_0.r, ..., V_{j-1}.r, r.r]; turn it into the coefficients of

@@ -212,9 +212,190 @@ static int launch_spmv_fixed(const CsrDev& A, const double* x, double* y, const 
   return grid;
 }
 
+// (d) ELL-ordered fixed-K rows (round 4; the default for 5-, 7- and 27-point stencils): the matrix is kept a second time
+// in blocks of RB rows with entry k of every row of a block contiguous, so a LANE owns whole rows: its K value loads and
+// K column loads are coalesced 8-byte (VEC == 1) or 16-byte (VEC == 2: two adjacent rows per lane) accesses, a stencil's
+// k-th gathers of a wave are one contiguous run of x, and the row sum is formed in registers in CSR order (sum += a * x,
+// unfused: SciPy's bits) - no LDS staging of the products, no barrier before the alpha reduction.  All of a lane's loads
+// are issued before the first gather, all gathers before the first use.  Blocks are padded with (value 0, column 0).
+//   SC (the device-resident partial re-orthogonalisation loop, lz_api.hip): x = r / beta is formed per gathered entry
+//   when no sweep ran on this vector (see SpmvScale), and the block stores the rows it owns to V[j].
+template <typename T>
+__device__ __forceinline__ T ld_nt(const T* p) {
+  return __builtin_nontemporal_load(p);
+}
+
+template <int K, int RPT, int VEC, bool SC>
+__global__ __launch_bounds__(kTPB) void k_spmv_ell(const int32_t* __restrict__ ec, const double* __restrict__ ev,
+                                                  const double* __restrict__ x, const double* __restrict__ xown,
+                                                  double* __restrict__ y, int rows, int rows_pad, double* __restrict__ part,
+                                                  SpmvScale sc) {
+  constexpr int RB = kTPB * RPT * VEC;
+  constexpr int NR = RPT * VEC;  // rows per lane
+  __shared__ double sm[kTPB / 64];
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int r0 = blk * RB;
+  const int64_t e0 = (int64_t)blk * K * RB;
+  double a[NR][K];
+  int c[NR][K];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if constexpr (VEC == 1) {
+        const int64_t idx = e0 + (int64_t)k * RB + q * kTPB + threadIdx.x;
+        a[q][k] = ld_nt(ev + idx);
+        c[q][k] = ld_nt(ec + idx);
+      } else {
+        const int64_t idx = e0 + (int64_t)k * RB + q * (2 * kTPB) + 2 * threadIdx.x;
+        const double2 av = ld_stream<1>(reinterpret_cast<const double2*>(ev + idx));
+        const int2 cv = ld_stream<1>(reinterpret_cast<const int2*>(ec + idx));
+        a[2 * q][k] = av.x;
+        a[2 * q + 1][k] = av.y;
+        c[2 * q][k] = cv.x;
+        c[2 * q + 1][k] = cv.y;
+      }
+    }
+  bool scale = false;
+  double beta = 1.0;
+  const double* xs = x;
+  const double* xo = xown;
+  if constexpr (SC) {
+    scale = sc.gate[0] == 0;
+    if (scale) {
+      beta = sqrt(sc.nrm2[0]);
+      xs = sc.r;
+      xo = sc.r;
+      if (blockIdx.x == 0 && threadIdx.x == 0) sc.beta_slot[0] = beta;
+    }
+  }
+  double xv[NR][K];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int k = 0; k < K; ++k) xv[q][k] = xs[c[q][k]];
+  int lrow[NR];
+  double own[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    lrow[q] = VEC == 1 ? r0 + q * kTPB + (int)threadIdx.x : r0 + (q >> 1) * (2 * kTPB) + 2 * (int)threadIdx.x + (q & 1);
+    own[q] = lrow[q] < rows_pad ? xo[lrow[q]] : 0.0;
+  }
+  if constexpr (SC) {
+    if (scale) {
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) xv[q][k] = xv[q][k] / beta;
+        own[q] = own[q] / beta;
+        if (lrow[q] < rows_pad) sc.vj[lrow[q]] = own[q];  // (the pad of r is zero: 0 / beta keeps the pad of V[j] zero)
+      }
+    }
+  }
+  double d = 0.0;
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) sum += a[q][k] * xv[q][k];
+    if (lrow[q] < rows) {
+      y[lrow[q]] = sum;
+      d += own[q] * sum;
+    }
+  }
+  d = block_sum(d, sm);
+  if (threadIdx.x == 0) part[blk] = d;
+}
+
+__global__ __launch_bounds__(kTPB) void k_ell_build(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int RB,
+                                                   int64_t nnz, int32_t* __restrict__ ec, double* __restrict__ ev) {
+  const int64_t e = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  if (e >= nnz) return;
+  const int64_t row = e / K;
+  const int k = (int)(e - row * K);
+  const int64_t b = row / RB;
+  const int lr = (int)(row - b * RB);
+  const int64_t dst = (b * K + k) * RB + lr;
+  ec[dst] = colidx[e];
+  ev[dst] = vals[e];
+}
+
+static int ell_rows_per_block(int K, int variant) { return K > 7 ? kTPB : 2 * kTPB; }
+
+void ell_free(CsrDev& A) {
+  if (A.ell_c) hipFree(A.ell_c);
+  if (A.ell_v) hipFree(A.ell_v);
+  A.ell_c = nullptr;
+  A.ell_v = nullptr;
+  A.ell_rb = 0;
+}
+
+hipError_t ell_build(CsrDev& A, int variant, hipStream_t s) {
+  ell_free(A);
+  const int K = A.fixed_k;
+  if (!(K == 5 || K == 7 || K == 27) || A.rows <= 0) return hipSuccess;
+  if (K == 27) variant = 0;
+  const int RB = ell_rows_per_block(K, variant);
+  const int64_t nblk = (A.rows + RB - 1) / RB;
+  const size_t cap = (size_t)nblk * K * RB;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cap * sizeof(int32_t));
+  if (e != hipSuccess) return e;
+  A.ell_c = static_cast<int32_t*>(p);
+  e = hipMalloc(&p, cap * sizeof(double));
+  if (e != hipSuccess) {
+    ell_free(A);
+    return e;
+  }
+  A.ell_v = static_cast<double*>(p);
+  // only the last block has pad slots, but a memset of the whole copy is cheaper than finding them
+  if ((e = hipMemsetAsync(A.ell_c, 0, cap * sizeof(int32_t), s)) != hipSuccess || (e = hipMemsetAsync(A.ell_v, 0, cap * sizeof(double), s)) != hipSuccess) {
+    ell_free(A);
+    return e;
+  }
+  const int64_t nnz = A.rows * K;
+  hipLaunchKernelGGL(k_ell_build, dim3((unsigned)((nnz + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, A.colidx, A.vals, K, RB, nnz, A.ell_c, A.ell_v);
+  e = hipGetLastError();
+  if (e != hipSuccess) {
+    ell_free(A);
+    return e;
+  }
+  A.ell_rb = RB;
+  A.ell_variant = variant;
+  return hipSuccess;
+}
+
+bool ell_usable(const CsrDev& A, int flags) {
+  return A.ell_rb > 0 && !A.ablation && !(flags & (LZ_FLAG_SPMV_SCALAR | LZ_FLAG_SPMV_STREAM)) && !A.pb;
+}
+
+template <int K, int RPT, int VEC>
+static int launch_spmv_ell_t(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
+  constexpr int RB = kTPB * RPT * VEC;
+  const int grid = (int)((A.rows + RB - 1) / RB);
+  const int rows_pad = (int)round_up(A.rows, kPadDoubles);
+  if (sc)
+    hipLaunchKernelGGL((k_spmv_ell<K, RPT, VEC, true>), dim3(grid), dim3(kTPB), 0, s, A.ell_c, A.ell_v, x, x_own, y, (int)A.rows, rows_pad, part, *sc);
+  else
+    hipLaunchKernelGGL((k_spmv_ell<K, RPT, VEC, false>), dim3(grid), dim3(kTPB), 0, s, A.ell_c, A.ell_v, x, x_own, y, (int)A.rows, rows_pad, part,
+                       SpmvScale());
+  return grid;
+}
+
+int launch_spmv_ell(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
+  if (A.fixed_k == 27) return launch_spmv_ell_t<27, 1, 1>(A, x, y, x_own, part, s, sc);
+  if (A.ell_variant == 1) {
+    if (A.fixed_k == 5) return launch_spmv_ell_t<5, 1, 2>(A, x, y, x_own, part, s, sc);
+    return launch_spmv_ell_t<7, 1, 2>(A, x, y, x_own, part, s, sc);
+  }
+  if (A.fixed_k == 5) return launch_spmv_ell_t<5, 2, 1>(A, x, y, x_own, part, s, sc);
+  return launch_spmv_ell_t<7, 2, 1>(A, x, y, x_own, part, s, sc);
+}
+
 int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
                     hipStream_t s) {
   if (A.rows == 0) return 0;
+  if (ell_usable(A, flags)) return launch_spmv_ell(A, x, y, x_own, part, s);
   if (flags & LZ_FLAG_SPMV_SCALAR) {
     const int grid = (int)((A.rows + kTPB - 1) / kTPB);
     hipLaunchKernelGGL(k_spmv_scalar, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, x, x_own, y, A.rows, part);

@@ -42,6 +42,8 @@
 #include <cstdio>
 #include <vector>
 
+#include <mutex>
+
 #include "lz_device.h"
 
 namespace lz {
@@ -426,11 +428,25 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
   }
 }
 
-// once per process and kernel: dynamic-LDS limit = the CU's 160 KiB (result remembered, returned on every call)
+// once per process, DEVICE and kernel: dynamic-LDS limit = the CU's 160 KiB (result remembered per device ordinal, returned on
+// every call).  hipFuncSetAttribute applies to the current device's function object only, so a second handle on another GPU of
+// the same process (Lanczos.device_id = 1 after 0) needs its own raise; the table is guarded by a mutex.
 constexpr size_t kPbLdsCuMax = 160 * 1024 - 1024;  // the CU's 160 KiB less the kernels' static LDS (the attribute counts dynamic bytes only)
 hipError_t pb_raise_lds_limits() {
-  static hipError_t done = hipErrorNotReady;
-  if (done != hipErrorNotReady) return done;
+  constexpr int kMaxDev = 64;
+  static std::mutex mu;
+  static hipError_t done[kMaxDev];
+  static bool init = false;
+  int dev = 0;
+  const hipError_t ge = hipGetDevice(&dev);
+  if (ge != hipSuccess) return ge;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!init) {
+    for (auto& d : done) d = hipErrorNotReady;
+    init = true;
+  }
+  const bool tracked = dev >= 0 && dev < kMaxDev;
+  if (tracked && done[dev] != hipErrorNotReady) return done[dev];
   hipError_t e = hipSuccess;
   auto up = [&](const void* k) {
     const hipError_t x = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPbLdsCuMax);
@@ -444,7 +460,7 @@ hipError_t pb_raise_lds_limits() {
   up(reinterpret_cast<const void*>(k_pb_rows<2>));
   up(reinterpret_cast<const void*>(k_pb_rows<7>));
 #endif
-  done = e;
+  if (tracked) done[dev] = e;
   return e;
 }
 

@@ -173,4 +173,11 @@ hipError_t xfer_d2h(int dev, hipStream_t stream, Xfer*& state, void* dst, size_t
   return e != hipSuccess ? e : se;
 }
 
+// The other direction of the boundary (host -> device: the CSR arrays of lz_set_csr, a dense matrix, the start vector) does
+// NOT go through this ring.  Round 4 built the twin pipeline (host threads fill the pinned ring, the copy engine drains it) and
+// measured it against the runtime's own path on the headline's 640 MB of CSR, a 4.6 GB dense matrix and the 80 MB start
+// vector (tools/upload_probe.py, profiles/r04/ab_upload_{staged,plain}_h2d.json): 54 vs 57 GB/s for the dense matrix, 75 vs
+// 51 ms for lz_set_csr, 2.8 vs 2.2 ms for the start vector - a resident pageable SOURCE is pinned in place and read at the
+// link's rate by the runtime; it is the page faults of a fresh DESTINATION that made the staged path pay for results.  Removed.
+
 }  // namespace lz

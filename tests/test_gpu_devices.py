@@ -284,3 +284,39 @@ def test_a_dying_worker_ends_the_pool_and_is_reported():
     s.execute_Lanczos(20)  # a new pool
     assert s._handle.pool is not pool and np.array_equal(s.H_eff, H_eff)
     s.close()
+
+
+def test_stalled_worker_ends_the_call_within_its_deadline():
+    """Round 4 (SURVEY section 5 "failure detection"): a worker that stalls - stopped with SIGSTOP here, which is what a rank
+    stuck in a collective looks like from the caller - no longer hangs ``execute_Lanczos``: the command's deadline
+    (``Lanczos.worker_timeout``, otherwise derived from the work) expires, the pool ends every child it started (by pid,
+    SIGKILL for the silent rank), /dev/shm is left clean and the caller gets ``LanczosHipError`` naming the silent rank."""
+    import glob
+    import signal
+    import time
+
+    from lanczos_amd import LanczosHipError
+
+    before = set(glob.glob("/dev/shm/lz_*"))
+    Lanczos.verbose = False
+    s = Lanczos(synthetic.laplacian_2d_5pt(64, 48).to_scipy())
+    s.devices = [0, 0]
+    s.comm_backend = "host"
+    s.execute_Lanczos(20)  # the pool works
+    ref = s.H_eff.copy()
+    pool = s._handle.pool
+    os.kill(pool.procs[1].pid, signal.SIGSTOP)
+    s.worker_timeout = 5.0
+    t = time.time()
+    # (rank 0 sits in the first all-reduce waiting for its stopped peer: it is silent too)
+    with pytest.raises(LanczosHipError, match=r"rank\(s\) \[(0, )?1\].*did not answer within 5 s"):
+        s.execute_Lanczos(20)
+    assert time.time() - t < 40.0
+    assert pool.closed and all(p.poll() is not None for p in pool.procs)
+    assert set(glob.glob("/dev/shm/lz_*")) == before
+    # the object recovers: a fresh pool is started by the next call
+    s.close()
+    s.worker_timeout = None
+    s.execute_Lanczos(20)
+    assert np.array_equal(s.H_eff, ref)
+    s.close()

@@ -65,6 +65,41 @@ def test_spmv_bit_exact(hip, name, flags):
     h.close()
 
 
+def _fixed_k_random(M, K, seed):
+    """M rows of exactly K entries at random (sorted, distinct) columns with real values: fixed-K without any stencil structure"""
+    rng = np.random.default_rng(seed)
+    W = min(M, 256)  # K distinct offsets inside a window of W columns placed anywhere in the row
+    offs = np.argsort(rng.random((M, W)), axis=1)[:, :K]
+    cols = np.sort(rng.integers(0, M - W + 1, (M, 1)) + offs, axis=1)
+    return scipy.sparse.csr_matrix((rng.standard_normal(M * K), cols.ravel().astype(np.int32), np.arange(0, M * K + 1, K, dtype=np.int32)), shape=(M, M))
+
+
+@pytest.mark.parametrize("K,M", [(5, 1300), (7, 2049), (27, 777), (5, 40000), (7, 30011), (27, 5000)])
+def test_spmv_fixed_k_layouts_bit_exact(hip, K, M):
+    """Fixed-K rows: the ELL-ordered copy (default since round 4; knob 17 = 2 one row per lane, 3 two adjacent rows per lane)
+    against the CSR-order kernel (knob 17 = 1) and SciPy - y bit for bit in every layout, ragged last block included; the
+    one-row-per-lane layout also groups the alpha partials like the CSR-order kernel (same bits, K in {5, 7})."""
+    H = _fixed_k_random(M, K, seed=K * M)
+    x = np.random.default_rng(1).uniform(-1, 1, M)
+    ref = H * x
+    alphas = {}
+    for knob in (0, 1, 2, 3):
+        h = hip.Handle(0)
+        h.set_tuning(hip.TUNE_FIXED_LAYOUT, knob)
+        h.set_csr(M, 0, H.indptr, H.indices, H.data)
+        y = h.spmv_host(x)
+        assert np.array_equal(y, ref), (knob, np.abs(y - ref).max())
+        h.basis_alloc(3)
+        h.basis_set_row(1, x)
+        alphas[knob] = h.step_spmv(1)
+        assert np.array_equal(h.r_get(), ref)
+        assert abs(alphas[knob] - np.dot(x, ref)) <= 1e-13 * np.dot(np.abs(x), np.abs(H) * np.abs(x))
+        h.close()
+    assert alphas[0] == alphas[2]
+    if K != 27:
+        assert alphas[1] == alphas[2]  # 512-row blocks, rows t and t + 256 per lane in both
+
+
 def _two_phase_matrices():
     rng = np.random.default_rng(11)
     big = synthetic.random_graph_laplacian(60000, 210000, seed=8).to_scipy()  # several row blocks x 118 column blocks
@@ -108,6 +143,27 @@ def test_spmv_two_phase_bit_exact(hip, name):
         assert np.array_equal(r, H * v)
     assert abs(a - np.dot(v, H * v)) <= 1e-13 * np.dot(np.abs(v), np.abs(H) * np.abs(v))
     h.close()
+
+
+def test_two_phase_layout_on_a_second_device(hip):
+    """the dynamic-LDS limit of the two-phase kernels is raised per DEVICE (hipFuncSetAttribute applies to the
+    current device's function object): a handle on GPU 1 after one on GPU 0 in the same process must still launch with more
+    than 64 KiB of dynamic LDS.  Needs two visible GPUs (skipped on a one-GPU box)."""
+    import ctypes as C
+
+    cnt = C.c_int()
+    hip.load_library().lz_device_count(C.byref(cnt))
+    if cnt.value < 2:
+        pytest.skip("one visible GPU")
+    H = synthetic.random_graph_laplacian(60000, 210000, seed=8).to_scipy()
+    x = np.random.default_rng(1).uniform(-1, 1, H.shape[0])
+    for dev in (0, 1):
+        h = hip.Handle(dev)
+        h.set_tuning(hip.TUNE_SPMV_PLAN, 2)
+        h.set_csr(H.shape[0], 0, H.indptr, H.indices, H.data)
+        assert h.spmv_plan() == "two-phase"
+        assert np.array_equal(h.spmv_host(x), H * x)
+        h.close()
 
 
 def test_two_phase_spmv_in_the_run_loop(hip):

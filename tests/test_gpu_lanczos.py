@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden
-from lanczos_amd import IrrLanczos, Lanczos, synthetic
+from lanczos_amd import IrrLanczos, Lanczos, _capi, synthetic
 from oracle import lanczos_ref as oracle
 
 pytestmark = pytest.mark.gpu
@@ -323,6 +323,24 @@ def test_partial_reorthogonalisation_opt_in(build, n):
     if prefix == n:  # well-conditioned run: every Ritz value is determined
         assert np.abs(th_p - full.H_eigvals).max() <= RTOL * scale
     V = part.V
+    # Round 4: the omega-recurrence and the sweep decision live on the device (engine "partial-device"): lz_run makes no host
+    # synchronisation between its first and its last launch.  Decisions, coefficients and basis are bit-identical to the
+    # host-decided loop (knob 18 = 1, two scalars read back per step) and to the device loop without the fused r / beta
+    # (knob 18 = 2; with an ELL-ordered stencil matrix the SpMV forms v_j = r / beta itself).
+    h = part._get_handle()
+    assert h.last_engine() == "partial-device" and h.last_host_syncs() == 0
+    for knob in (1, 2):
+        other = Lanczos(H)
+        other.reorth = "partial"
+        other._get_handle().set_tuning(_capi.TUNE_PARTIAL_LOOP, knob)
+        other.execute_Lanczos(n)
+        ho = other._get_handle()
+        assert ho.last_engine() == ("kernels" if knob == 1 else "partial-device")
+        assert (ho.last_host_syncs() > n) if knob == 1 else (ho.last_host_syncs() == 0)
+        assert other.sweeps == part.sweeps
+        assert np.array_equal(other.H_eff, part.H_eff)
+        assert np.array_equal(other.V, V)
+        other.close()
     assert np.abs(V.T @ V - np.eye(n)).max() < 1e-6  # semi-orthogonal (sqrt(eps) level), not eps like the full sweep
     # a sweep removes components of size <= sqrt(eps) from v_j, so A V = V T + ... holds to that level (not eps)
     R = H @ V - V @ part.H_eff

@@ -156,7 +156,7 @@ def test_loop_selection(hip, kb):
     Hs = synthetic.laplacian_2d_5pt(20, 20).to_scipy()
     assert _run(kb, Hs, 10, engine_off=False, flags=0)[3] == "kernels"  # not fused-norm mode
     assert _run(kb, Hs, 10, engine_off=False, knob=5)[3] == "step"  # the one-launch-per-step arm
-    assert _run(kb, Hs, 10, engine_off=False, flags=hip.FLAG_FUSED_NORM | hip.FLAG_REORTH_PARTIAL)[3] == "kernels"
+    assert _run(kb, Hs, 10, engine_off=False, flags=hip.FLAG_FUSED_NORM | hip.FLAG_REORTH_PARTIAL)[3] == "partial-device"  # round 4: its own loop
     assert _run(kb, Hs, 10, engine_off=False)[3] == "small"
     for lib in (hip, kb):
         assert _run(lib, Hs, 10, engine_off=True)[3] == "kernels"  # knob 15 = 1: the plain path

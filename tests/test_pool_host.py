@@ -59,10 +59,42 @@ def test_unknown_command_is_an_error_not_a_hang():
     assert pool.closed
 
 
+def test_stalled_worker_meets_its_deadline():
+    """Round 4: a STALLED rank (here: stopped with SIGSTOP mid-protocol - what a collective that never completes looks like
+    from outside) used to hang the caller for ever; every command now has a deadline.  On expiry: LanczosHipError naming the
+    silent rank, every child ended (the silent one with SIGKILL), no /dev/shm segment left."""
+    import signal
+    import time
+
+    before = set(glob.glob("/dev/shm/lz_*"))
+    h = _pool.PoolHandle([0, 0], backend="host")
+    pool = h.pool
+    assert [r["rank"] for r in pool.request({"cmd": "ping"}, timeout=120)] == [0, 1]
+    # deadlines derived from the work: never below the floor, growing with bytes / steps; the override wins
+    h.rows, h.n = 10_000_000, 200
+    assert h.deadline() == h.floor_s and h.deadline(host_bytes=16e9) > h.floor_s + 30 and h._run_deadline(200) > h._run_deadline(20) > h.floor_s
+    h.timeout_override = 3.0
+    assert h.deadline(host_bytes=1e12) == 3.0
+    os.kill(pool.procs[1].pid, signal.SIGSTOP)
+    t = time.time()
+    with pytest.raises(lanczos_amd.LanczosHipError, match=r"rank\(s\) \[1\].*did not answer within 3 s"):
+        pool.request({"cmd": "ping"}, timeout=h.deadline(host_bytes=1e12))  # rank 0 answers, rank 1 never does
+    assert time.time() - t < 30.0
+    assert pool.closed and all(p.poll() is not None for p in pool.procs)
+    assert set(glob.glob("/dev/shm/lz_*")) == before
+
+
 def test_stencil_operator_descriptor():
     op = lanczos_amd.StencilOperator((6, 5, 4), 7)
     assert op.shape == (120, 120) and op.key() == lanczos_amd.StencilOperator((6, 5, 4), 7).key()
     assert op.key() != lanczos_amd.StencilOperator((6, 5, 4), 27).key()
+    # the potential is part of the key by CONTENT: an in-place change (a parameter scan) must invalidate the device copy
+    pot = np.linspace(0.0, 1.0, 120)
+    op_p = lanczos_amd.StencilOperator((6, 5, 4), 7, potential=pot)
+    k0 = op_p.key()
+    assert k0 == lanczos_amd.StencilOperator((6, 5, 4), 7, potential=pot.copy()).key()
+    pot[17] += 1.0
+    assert op_p.key() != k0
     s = Lanczos(op)
     assert s.M == 120
     with pytest.raises(ValueError, match="one entry per grid point"):
