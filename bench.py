@@ -81,6 +81,23 @@ def build_local(kind, dims, lo, hi):
     raise ValueError(kind)
 
 
+def gram_record(tg, k):
+    """bench-line record of lz_ritz_gram (the device Gram matrix behind get_H_eigs' two checks)"""
+    if not tg:
+        return None
+    rec = {"ms": round(tg["ms"], 3), "tflops_symmetric_half": round(tg["flops"] / max(tg["ms"], 1e-9) / 1e9, 2), "bound": "mfma",
+           "peak_tflops": FP64_MFMA_PEAK_TFLOPS, "frac": round(tg["flops"] / max(tg["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 4),
+           "max_dev_from_identity": tg["max_dev_from_identity"],
+           "note": "G = Y^T Y (k x k) of the resident Ritz vectors: upper 16 x 16 tiles in accumulators, Y streamed once, mirrored; flops counted as "
+                   "M k (k + 1) (the symmetric half - the full product would be 2 M k^2); second call of the process; kernel + slice sum"}
+    info = tg.get("info")
+    if info and info.get("shader_clock_mhz", 0) > 0:
+        rec.update({"shader_clock_mhz": round(info["shader_clock_mhz"], 1), "cycles_per_kstep": round(info["cycles_per_kstep"], 1),
+                    "mfma_issue_floor_cycles_per_kstep": info["mfma_issue_floor_cycles_per_kstep"],
+                    "mfma_issue_utilisation_in_cycles": round(info["mfma_issue_floor_cycles_per_kstep"] / max(info["cycles_per_kstep"], 1e-9), 4)})
+    return rec
+
+
 def class_surface(lanczos_amd, local, k):
     """Wall time of the reference's call sequence through lanczos_amd.Lanczos (see the call site)."""
     H = local.to_scipy()
@@ -373,7 +390,18 @@ def main():
             G = solver.h.ritz_gram()
             assert np.abs(G - np.eye(k)).max() < 1e-10
             tr = dict(solver.timings()["ritz"], ms_first_call=0.0, info=solver.h.ritz_info(), chunked_pass="back-transform of every row chunk + its Gram accumulation")
+        # the n x n Gram matrix of the Ritz vectors (the two checks of get_H_eigs, Lanczos.py:157-158), resident Y only: second call
+        tg = None
+        if tr["info"]["chunk_rows"] == 0:
+            G = solver.h.ritz_gram()
+            solver.timings()
+            G = solver.h.ritz_gram()
+            tg = solver.timings()["ritz"]
+            tg["info"] = solver.h.gram_info() if world == 1 else None
+            tg["max_dev_from_identity"] = float(np.abs(G - np.eye(k)).max())
+            assert tg["max_dev_from_identity"] < 1e-10 and np.array_equal(G, G.T)
     except _capi.LanczosHipError as e:  # e.g. no room for a second M x k array next to the basis
+        tg = None
         print(f"[rank {rank}] Ritz back-transform skipped: {e}", file=sys.stderr)
         theta = np.linalg.eigvalsh(solver.H_eff)
         tr = {"ms": 0.0, "flops": 0.0, "ms_first_call": 0.0}
@@ -446,6 +474,7 @@ def main():
                                    "frac": round(tr["flops"] / max(tr["ms"], 1e-9) / 1e9 / FP64_MFMA_PEAK_TFLOPS, 4),
                                    "note": "Y = V^T-layout x S (M x k x k) FP64 MFMA GEMM, outside the timed steps; second call of the process (ms_first_call: the first)",
                                    **({"chunked_pass": tr["chunked_pass"]} if "chunked_pass" in tr else {}), **ritz_clock(tr.get("info"))},
+            "ritz_gram": gram_record(tg, k),
         }
     else:
         line = None

@@ -125,6 +125,7 @@ int lz_set_options(lz_handle h, int flags);
  *   17  fixed-K (stencil) SpMV layout: 0 auto (ELL-ordered second copy for 5, 7 and 27 entries per row: a lane owns whole rows),
  *       1 never (CSR-order kernel with products staged through LDS; CSR-stream for 27), 2 ELL one row per lane and trip,
  *       3 ELL two adjacent rows per lane (16-byte loads)
+ *   19  Gram matrix of the Ritz vectors: 0 auto (accumulator-stationary symmetric kernel where it applies), 1 the split-K TN GEMM always
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
  *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta)
  * The product library returns LZ_ERR_ARG for everything that lives only in the kernel-bench build (make KBENCH=1 ->
@@ -216,6 +217,16 @@ int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* se
 /* all-gather plan: every rank owns `chunk` padded rows; x_full has world*chunk entries. */
 int lz_set_allgather(lz_handle h, int64_t chunk);
 
+/* Optional: allocate the device buffers of the coming run EARLY - the (n, rows_local) Krylov basis and, with with_ritz != 0
+ * and where it fits, the (rows_local, n) Ritz vectors.  A first hipMalloc of 16 GB costs 0.1-0.5 s on this platform; the
+ * class mirror issues this call from a helper thread while it draws the start vector, hashes, validates and uploads the
+ * matrix (Lanczos.py:85-104 does the same work in sequence), so lz_run / lz_ritz_vectors find their buffers ready.  It is the
+ * ONE entry point that may run concurrently with another call on the same handle (lz_set_options / lz_set_tuning / lz_set_csr /
+ * lz_set_dense / lz_build_stencil3d*): it touches only its own fields.  It must have returned before lz_run.  Never fails
+ * for lack of memory (lz_run then allocates, and reports, itself); reserves nothing unless a quarter of the device stays free.
+ * Single rank (rows_local = M). */
+int lz_reserve(lz_handle h, int64_t rows_local, int n, int with_ritz);
+
 /* ---- the Lanczos run --------------------------------------------------- *
  * Replaces Lanczos.py:104-119 (== IrrLanczos.py:222-238): basis allocation,
  * warm-up step and the Krylov loop with full re-orthogonalisation, with the
@@ -269,6 +280,10 @@ int lz_ritz_info(lz_handle h, int64_t* chunk_rows, double* clock4);
  * 288-323): column norms (n) and the (n, n) Gram matrix Y^T Y, computed on the
  * device-resident Y of the last lz_ritz_vectors call (summed over ranks). */
 int lz_ritz_gram(lz_handle h, double* gram_out);
+/* In-kernel clock record of the last lz_ritz_gram when it ran the accumulator-stationary symmetric kernel (48 <= n <= 208, at
+ * least 4096 rows; zeros otherwise): {shader clock in MHz while workgroup 0 ran, shader cycles its wave 0 needed per k-step
+ * (4 rows of Y), the MFMA issue floor of that (MFMAs per k-step and SIMD x 64 cycles), k-steps walked}. */
+int lz_gram_info(lz_handle h, double* info4);
 /* y_i = A * Y[:, i] residual check used by print_good_eigs (Lanczos.py:166-185):
  * out[i] = (A y_i . y_i)^2 / (||A y_i||^2), for all n columns.  One rank: one fused kernel over the CSR matrix.
  * Row-block partition (world > 1): collective; every Ritz vector is exchanged and multiplied like a Lanczos vector

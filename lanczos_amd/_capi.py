@@ -48,6 +48,7 @@ TUNE_SPMV_PLAN = 14         # irregular SpMV plan (0 auto, 1 never two-phase, 2 
 TUNE_LOOP = 15              # loop structure (0 auto, 1 six launches per step always)
 TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 forces it)
 TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto = ELL, 1 CSR order, 2 ELL one row per lane, 3 ELL two rows per lane)
+TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel, 1 split-K TN GEMM)
 TUNE_PARTIAL_LOOP = 18      # partial re-orthogonalisation loop (0 device-resident, 1 host-decided, 2 device-resident without the fused scale)
 
 KERNEL_CLASSES = ("spmv", "qtw", "update", "three_term", "final", "comm", "ritz")
@@ -105,6 +106,7 @@ SIGNATURES = {
     "lz_get_csr": (C.c_int, [_P, _I32, _I32, _D]),
     "lz_set_halo": (C.c_int, [_P, C.c_int, _I32, _I64, _I32, _I64]),
     "lz_set_allgather": (C.c_int, [_P, C.c_int64]),
+    "lz_reserve": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int]),
     "lz_run": (C.c_int, [_P, C.c_int, _D, _D, _D]),
     "lz_get_residual": (C.c_int, [_P, _D]),
     "lz_run_resume": (C.c_int, [_P, C.c_int, C.c_int, _D, C.c_int64, _D, _D, _D, _D, _D]),
@@ -115,6 +117,7 @@ SIGNATURES = {
     "lz_get_ritz_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _D]),
     "lz_ritz_info": (C.c_int, [_P, _I64, _D]),
     "lz_ritz_gram": (C.c_int, [_P, _D]),
+    "lz_gram_info": (C.c_int, [_P, _D]),
     "lz_ritz_quality": (C.c_int, [_P, _D]),
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
     "lz_last_sweeps": (C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -457,6 +460,10 @@ class Handle:
         self.check(self.lib.lz_set_allgather(self._h, int(chunk)))
 
     # -- run
+    def reserve(self, rows_local, n, with_ritz=True):
+        """allocate the basis (and the Ritz vectors) of the coming run now; safe to call from a helper thread (see lz_reserve)"""
+        self.check(self.lib.lz_reserve(self._h, int(rows_local), int(n), 1 if with_ritz else 0))
+
     def run(self, n, v0_local):
         v0 = f64(v0_local)
         if v0.shape != (self.rows,):
@@ -535,6 +542,12 @@ class Handle:
         G = np.empty((self.n, self.n))
         self.check(self.lib.lz_ritz_gram(self._h, dptr(G)))
         return G
+
+    def gram_info(self):
+        """in-kernel clock record of the last ritz_gram (symmetric kernel only): held clock, cycles per k-step, MFMA issue floor"""
+        c = (C.c_double * 4)()
+        self.check(self.lib.lz_gram_info(self._h, c))
+        return {"shader_clock_mhz": c[0], "cycles_per_kstep": c[1], "mfma_issue_floor_cycles_per_kstep": c[2], "ksteps": int(c[3])}
 
     def ritz_quality(self):
         q = np.empty(self.n)

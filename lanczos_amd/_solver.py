@@ -24,6 +24,8 @@ H and the Krylov basis row-block-wise over one worker process per GPU (see
 """
 from __future__ import annotations
 
+import json
+
 import numpy as np
 import scipy.sparse
 import scipy.sparse.linalg
@@ -163,6 +165,7 @@ class LanczosBase:
             self._handle.close()
             self._handle = None
             self._matrix_key = self._matrix_key_alt = None
+            self._reserved = None
 
     def __del__(self):
         try:
@@ -253,6 +256,7 @@ class LanczosBase:
                 self._handle = _capi.Handle(want[0])
             self._handle_devices = (want, self.comm_backend)
             self._matrix_key = self._matrix_key_alt = None
+            self._reserved = None
         if hasattr(self._handle, "timeout_override"):
             self._handle.timeout_override = self.worker_timeout
         return self._handle
@@ -315,6 +319,21 @@ class LanczosBase:
 
         t_0 = time.perf_counter()
         pending_key = self._matrix_key_start()  # hashes H on helper threads while this thread draws v0
+        # ... and the 8nM-byte basis (+ the Ritz vectors) is allocated on another one: a first hipMalloc of 16 GB takes 0.1-0.5 s
+        reserve = None
+        if n >= 2 and self.reorth in ("full", "partial") and not self._multi() and getattr(self, "_reserved", None) != (M, n):
+            import threading
+
+            hres = self._get_handle()
+
+            def _reserve():
+                try:
+                    hres.reserve(M, n)
+                except Exception:  # never fatal: lz_run allocates (and reports) itself
+                    pass
+
+            reserve = threading.Thread(target=_reserve, name="lz-reserve", daemon=True)
+            reserve.start()
         np.random.seed(seed)
         if v0 is None:
             v0 = np.random.uniform(-1, 1, size=(M))
@@ -331,7 +350,12 @@ class LanczosBase:
         h = self._get_handle()
         h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0)
                       | (_capi.FLAG_FUSED_NORM if self.fused_norm else 0))
-        self._upload_matrix(h, pending_key)
+        try:
+            self._upload_matrix(h, pending_key)
+        finally:
+            if reserve is not None:  # lz_reserve must have returned before any other call that touches the buffers
+                reserve.join()
+                self._reserved = (M, n)
         t_2 = time.perf_counter()
         alpha, beta = h.run(n, v0)
         t_3 = time.perf_counter()
@@ -382,9 +406,12 @@ class LanczosBase:
         their rows into one host array, so a checkpoint does not depend on the partition that made it."""
         if not self.Lanczos_has_been_executed:
             raise ValueError(_NOT_EXECUTED)
-        h = self._handle
+        h = self._device()
+        key = self._matrix_key
         return {"alpha": self._alpha.copy(), "beta": self._beta.copy(), "V": np.array(h.get_basis()), "r": h.get_residual(), "M": self.M,
-                "fused_norm": bool(self.fused_norm)}
+                "fused_norm": bool(self.fused_norm), "options": int(self.options), "reorth": str(self.reorth),
+                # what the run was made WITH: resume refuses a different operator of the same size (content hash of H as held then)
+                "matrix_key": json.dumps(key, default=str) if key is not None else ""}
 
     def save_checkpoint(self, path):
         np.savez(path, **self.checkpoint())
@@ -403,12 +430,19 @@ class LanczosBase:
             raise ValueError("resume_Lanczos: n must exceed the %d steps already in the checkpoint" % j0)
         if self.reorth != "full":
             raise NotImplementedError("resume needs reorth='full' (the partial mode's omega-recurrence is not part of the checkpoint)")
+        if "reorth" in ck and str(ck["reorth"]) != "full":
+            raise ValueError("the checkpoint was written by a reorth='%s' run" % str(ck["reorth"]))
+        if "options" in ck and int(ck["options"]) & ~_capi.FLAG_PROFILE != int(self.options) & ~_capi.FLAG_PROFILE:
+            raise ValueError("the checkpoint was written with options=%d, this object has options=%d" % (int(ck["options"]), int(self.options)))
         self._say("+++ Executing Lanczos algorithm")
         self.n = n
-        self.fused_norm = bool(ck["fused_norm"])
+        fused = bool(ck["fused_norm"])  # the norm order of the run being continued (this object's own setting is left alone)
         h = self._get_handle()
-        h.set_options(self.options | (_capi.FLAG_FUSED_NORM if self.fused_norm else 0))
+        h.set_options(self.options | (_capi.FLAG_FUSED_NORM if fused else 0))
         self._upload_matrix(h)
+        stored = str(ck["matrix_key"]) if "matrix_key" in ck else ""
+        if stored and self._matrix_key is not None and stored != json.dumps(self._matrix_key, default=str):
+            raise ValueError("the checkpoint belongs to a different matrix (same size, different content)")
         alpha, beta = h.run_resume(n, ck["V"], ck["r"], ck["alpha"], ck["beta"])
         if h.breakdown:
             import warnings

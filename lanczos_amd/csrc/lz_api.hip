@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <system_error>
 #include <thread>
 
@@ -146,6 +147,10 @@ struct lz_context {
   double* d_S = nullptr;
   int s_npad = 0;
   uint64_t* d_rclk = nullptr;  // in-kernel clock record of the last S-stationary back-transform (lz_ritz_info)
+  double* d_gram = nullptr;    // scratch of lz_ritz_gram (K-slice partials + per-chunk slices + G), kept between calls
+  size_t gram_cap = 0;
+  uint64_t* d_gclk = nullptr;  // in-kernel clock record of the last symmetric Gram kernel (lz_gram_info)
+  bool gram_sym_last = false;
   bool y_chunked = false;
   int64_t y_chunk = 0;     // rows per chunk (multiple of 16)
   int64_t y_cap = 0;       // doubles allocated behind d_Y
@@ -190,6 +195,13 @@ struct lz_context {
   int* d_omi = nullptr;        //   ... gate of the coming step, sweep count, per-step sweep log (omega_state_ints)
   int om_n = 0;
   int64_t host_syncs = 0;      // host <-> device synchronisations between the first and the last launch of the last lz_run
+  // lz_reserve (may be called from a second host thread while this one prepares the matrix): device buffers for the basis and
+  // the Ritz vectors of the coming run, adopted by basis_alloc / lz_ritz_vectors.  Only these fields are touched by it.
+  std::mutex res_mu;
+  double* res_V = nullptr;
+  size_t res_V_count = 0;
+  double* res_Y = nullptr;
+  size_t res_Y_count = 0;
   bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
   lz_timings acc;
 };
@@ -1372,11 +1384,15 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_Y);
   hipFree(h->d_S);
   hipFree(h->d_rclk);
+  hipFree(h->d_gram);
+  hipFree(h->d_gclk);
   hipFree(h->d_send_idx);
   hipFree(h->d_sendbuf);
   hipFree(h->d_xfull);
   hipFree(h->d_om);
   hipFree(h->d_omi);
+  hipFree(h->res_V);
+  hipFree(h->res_Y);
   if (h->h_pinned) hipHostFree(h->h_pinned);
   xfer_free(h->xfer);
   if (h->cstream) {
@@ -1784,7 +1800,21 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
   const size_t vsz = (size_t)n * (size_t)h->ldv;
   const bool fresh = !h->d_V || h->n != n;
   if (fresh) {
-    LZ_TRY(dev_alloc(h, h->d_V, vsz));
+    double* adopted = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(h->res_mu);
+      if (h->res_V && h->res_V_count >= vsz) {
+        adopted = h->res_V;
+        h->res_V = nullptr;
+        h->res_V_count = 0;
+      }
+    }
+    if (adopted) {
+      LZ_TRY(dev_free(h, h->d_V));
+      h->d_V = adopted;
+    } else {
+      LZ_TRY(dev_alloc(h, h->d_V, vsz));
+    }
     if (getenv("LZ_DEBUG_PTR")) fprintf(stderr, "[lz] basis %p (%zu bytes, ld %lld)\n", (void*)h->d_V, vsz * sizeof(double), (long long)h->ldv);
     LZ_TRY(dev_alloc(h, h->d_r, (size_t)h->ldv));
     LZ_TRY(dev_alloc(h, h->d_r2, (size_t)h->ldv));
@@ -1926,6 +1956,48 @@ int lz_spmv_host(lz_handle h, const double* x, double* y) {
   return LZ_OK;
 }
 
+// ---- early allocation of the big buffers ---------------------------------------------------------------------------------
+static size_t y_doubles(int64_t rows, int n) { return (size_t)(round_up(rows, 16) + 16) * (size_t)n + 64; }
+
+int lz_reserve(lz_handle h, int64_t rows_local, int n, int with_ritz) {
+  if (!h) return LZ_ERR_ARG;
+  if (rows_local <= 0 || n < 1) return fail(nullptr, LZ_ERR_ARG, "lz_reserve: bad sizes");
+  if (hipSetDevice(h->dev) != hipSuccess) return LZ_ERR_HIP;  // (h->err belongs to the thread that drives the handle: not written here)
+  const int64_t rows_pad = round_up(rows_local, kPadDoubles);
+  const size_t vsz = (size_t)n * (size_t)skew_stride(h, rows_pad);
+  const size_t ysz = y_doubles(rows_local, n);
+  std::lock_guard<std::mutex> lk(h->res_mu);
+  size_t free_b = 0, total_b = 0;
+  if (!(h->res_V && h->res_V_count >= vsz)) {
+    if (h->res_V) hipFree(h->res_V);
+    h->res_V = nullptr;
+    h->res_V_count = 0;
+    void* p = nullptr;
+    // leave room for the matrix, its layouts and the work vectors: reserve only what leaves a quarter of the device free
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || vsz * sizeof(double) + total_b / 4 > free_b) return LZ_OK;
+    if (hipMalloc(&p, vsz * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      return LZ_OK;  // not an error: basis_alloc allocates (and reports) itself
+    }
+    h->res_V = static_cast<double*>(p);
+    h->res_V_count = vsz;
+  }
+  if (with_ritz && !(h->res_Y && h->res_Y_count >= ysz)) {
+    if (h->res_Y) hipFree(h->res_Y);
+    h->res_Y = nullptr;
+    h->res_Y_count = 0;
+    void* p = nullptr;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || ysz * sizeof(double) + total_b / 4 > free_b) return LZ_OK;
+    if (hipMalloc(&p, ysz * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      return LZ_OK;
+    }
+    h->res_Y = static_cast<double*>(p);
+    h->res_Y_count = ysz;
+  }
+  return LZ_OK;
+}
+
 // ---- the run -----------------------------------------------------------------------
 int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double* beta_out) {
   if (!h) return LZ_ERR_ARG;
@@ -1937,6 +2009,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   const double t0 = now();
   LZ_TRY(basis_alloc(h, n, 1));
   h->halo_inflight_j = -1;
+  h->y_n = 0;  // the Ritz vectors of an earlier run are not this run's: fetches answer LZ_ERR_STATE until lz_ritz_vectors is called again
   const double t1 = now();
   LZ_TRY(upload(h, h->d_V, v0_local, (size_t)h->rows * sizeof(double)));
   const double t2 = now();
@@ -2040,6 +2113,7 @@ int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_
     return fail(h, LZ_ERR_STATE, "lz_run_resume: not with partial re-orthogonalisation (its omega-recurrence lives on the host) or the one-reduce loop");
   LZ_TRY(basis_alloc(h, n, 1));
   h->halo_inflight_j = -1;
+  h->y_n = 0;
   LZ_TRY(upload2d(h, h->d_V, (size_t)h->ldv * sizeof(double), V_rows, (size_t)ldv_in * sizeof(double), (size_t)h->rows * sizeof(double), (size_t)j0));
   LZ_TRY(upload(h, h->d_r, r_local, (size_t)h->rows * sizeof(double)));
   LZ_HIP(h, hipMemcpyAsync(h->d_alpha, alpha_in, (size_t)j0 * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -2246,6 +2320,7 @@ int lz_run_two_sided(lz_handle h, int n, const double* q0, const double* p0, dou
     return fail(h, LZ_ERR_STATE, "lz_run_two_sided: call lz_set_csr_transpose first (NULL arrays if H is symmetric)");
   LZ_HIP(h, hipSetDevice(h->dev));
   LZ_TRY(bi_alloc(h, n, 1));
+  h->y_n = 0;
   const int64_t len = h->rows_pad;
   const size_t rowb = (size_t)h->rows * sizeof(double);
   double* S = h->d_bi;
@@ -2346,8 +2421,6 @@ int ritz_cols_into(lz_handle h, int c0, int nc, double* dst, int64_t ldy) {
   return check_launch(h, "ritz_gemm(columns)");
 }
 
-size_t y_doubles(int64_t rows, int n) { return (size_t)(round_up(rows, 16) + 16) * (size_t)n + 64; }
-
 }  // namespace
 
 extern "C" {
@@ -2375,11 +2448,25 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
   const size_t full = y_doubles(h->rows, n);
   bool chunked = h->tune[16] > 0;
   size_t free_b = 0, total_b = 0;
+  {
+    std::lock_guard<std::mutex> lk(h->res_mu);
+    if (h->res_Y && !chunked && h->res_Y_count >= full && !(h->d_Y && !h->y_chunked && h->y_cap >= (int64_t)full)) {
+      hipFree(h->d_Y);  // (a smaller or chunked buffer of an earlier call)
+      h->d_Y = h->res_Y;
+      h->y_cap = (int64_t)h->res_Y_count;
+      h->y_chunked = false;
+      h->res_Y = nullptr;
+      h->res_Y_count = 0;
+    }
+  }
   if (!chunked && !(h->d_Y && !h->y_chunked && h->y_cap >= (int64_t)full)) {
     LZ_TRY(dev_free(h, h->d_Y));
     h->y_cap = 0;
     LZ_HIP(h, hipMemGetInfo(&free_b, &total_b));
-    chunked = full * sizeof(double) + ((size_t)1 << 30) > free_b;
+    // what has to stay free beside Y: lz_ritz_gram's scratch (K-slice partials + G; 0.25 GB at n = 200, 4 GB at n = 1000 on the
+    // split-K path) plus 512 MB for the runtime and the quality sums
+    const size_t gram_need = (std::max<size_t>(gram_scratch_doubles(n) / ((size_t)n * n), 512) + 2) * (size_t)n * n * sizeof(double);
+    chunked = full * sizeof(double) + gram_need + ((size_t)512 << 20) > free_b;
   }
   h->y_rows = h->rows;
   h->y_n = n;
@@ -2434,7 +2521,8 @@ int lz_get_ritz_rows(lz_handle h, int64_t row0, int64_t nrows, double* Y_out) {
   }
   if (!h->d_V || h->n != n || h->rows != h->y_rows) return fail(h, LZ_ERR_STATE, "lz_get_ritz_rows: the basis of the run is gone");
   for (int64_t r = row0 & ~(int64_t)15; r < row0 + nrows; r += h->y_chunk) {
-    const int64_t nr = std::min<int64_t>(h->y_chunk, h->y_rows - r);
+    // only the 16-row tiles that cover the requested window are re-formed (a 32-row window of C4 used to cost a 4 GiB chunk)
+    const int64_t nr = std::min<int64_t>(std::min<int64_t>(h->y_chunk, round_up(row0 + nrows - r, 16)), h->y_rows - r);
     LZ_TRY(ritz_rows_into(h, r, nr, h->d_Y));
     const int64_t a = std::max(r, row0), b = std::min(r + nr, row0 + nrows);
     const size_t bytes = (size_t)(b - a) * n * sizeof(double);
@@ -2493,18 +2581,35 @@ int lz_ritz_gram(lz_handle h, double* gram_out) {
   const int nz_max = 512;
   const int64_t nchunks = h->y_chunked ? (h->y_rows + h->y_chunk - 1) / h->y_chunk : 1;
   if (h->y_chunked && (!h->d_V || h->n != n || h->rows != h->y_rows)) return fail(h, LZ_ERR_STATE, "lz_ritz_gram: the basis of the run is gone");
-  double* part = nullptr;
-  LZ_TRY(dev_alloc(h, part, (size_t)(nz_max + nchunks + 1) * n * n));
-  double* cpart = part + (size_t)nz_max * n * n;  // one n x n slice per chunk, added in chunk order at the end
+  // scratch: the K-slice partials of one chunk (the symmetric kernel's or the split-K TN GEMM's), one n x n slice per chunk
+  // (added in chunk order at the end), G.  Kept in the handle: a 160-250 MB hipMalloc + hipFree per call cost milliseconds.
+  const size_t slices = std::max<size_t>(gram_scratch_doubles(n) / ((size_t)n * n), (size_t)nz_max);
+  const size_t need = (slices + (size_t)nchunks + 1) * (size_t)n * n;
+  if (h->gram_cap < need) {
+    LZ_TRY(dev_alloc(h, h->d_gram, need));
+    h->gram_cap = need;
+  }
+  if (!h->d_gclk) {
+    LZ_TRY(dev_alloc(h, h->d_gclk, 4));
+  }
+  LZ_HIP(h, hipMemsetAsync(h->d_gclk, 0, 4 * sizeof(uint64_t), h->stream));
+  double* part = h->d_gram;
+  double* cpart = part + slices * n * n;
   double* dG = cpart + (size_t)nchunks * n * n;
   int rc = LZ_OK;
+  h->gram_sym_last = false;
   for (int64_t q = 0; q < nchunks && rc == LZ_OK; ++q) {
     const int64_t r = q * h->y_chunk, nr = std::min<int64_t>(h->y_chunk, h->y_rows - r);
     if (h->y_chunked) rc = ritz_rows_into(h, r, nr, h->d_Y);
     if (rc != LZ_OK) break;
-    Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)nr, 2.0 * (double)nr * n * n);
-    const int nz = launch_gram(h->d_Y, n, nr, n, part, nz_max, h->stream);
-    launch_sum_slices(part, nz, (int64_t)n * n, cpart + (size_t)q * n * n, h->stream);
+    // flops on the books: the symmetric half, n (n + 1) per row (the full product is 2 n^2; the kernel computes the upper tiles)
+    Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)nr, (double)nr * n * (n + 1.0));
+    if (h->tune[19] != 1 && launch_gram_sym(h->d_Y, n, nr, n, part, cpart + (size_t)q * n * n, h->stream, reinterpret_cast<unsigned long long*>(h->d_gclk))) {
+      h->gram_sym_last = true;
+    } else {
+      const int nz = launch_gram(h->d_Y, n, nr, n, part, nz_max, h->stream);
+      launch_sum_slices(part, nz, (int64_t)n * n, cpart + (size_t)q * n * n, h->stream);
+    }
     rc = check_launch(h, "gram");
   }
   if (rc == LZ_OK) {
@@ -2515,9 +2620,23 @@ int lz_ritz_gram(lz_handle h, double* gram_out) {
   hipError_t e = hipSuccess;
   if (rc == LZ_OK) e = hipMemcpyAsync(gram_out, dG, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  hipFree(part);
   if (rc != LZ_OK) return rc;
   if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_gram: ") + hipGetErrorString(e));
+  return LZ_OK;
+}
+
+int lz_gram_info(lz_handle h, double* info4) {
+  if (!h || !info4) return LZ_ERR_ARG;
+  info4[0] = info4[1] = info4[2] = info4[3] = 0.0;
+  if (!h->d_gclk || !h->gram_sym_last) return LZ_OK;
+  LZ_HIP(h, hipSetDevice(h->dev));
+  uint64_t c[4] = {0};
+  LZ_HIP(h, hipMemcpyAsync(c, h->d_gclk, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  info4[0] = c[1] ? 100.0 * (double)c[0] / (double)c[1] : 0.0;  // shader clock in MHz while workgroup 0 ran
+  info4[1] = c[2] ? (double)c[0] / (double)c[2] : 0.0;          // shader cycles per k-step (4 rows of Y) of its wave 0
+  info4[2] = 64.0 * (double)c[3];                               // MFMA issue floor of that: MFMAs per k-step and SIMD x 64 cycles
+  info4[3] = (double)c[2];
   return LZ_OK;
 }
 

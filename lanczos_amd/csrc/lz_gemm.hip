@@ -1,5 +1,7 @@
 // FP64-MFMA kernels: Ritz back-transform Y = V^T-layout x S, Gram matrix Y^T Y, Ritz-vector quality sums.
+#include <algorithm>
 #include <type_traits>
+#include <utility>
 
 #include "lz_device.h"
 
@@ -1219,6 +1221,168 @@ __global__ __launch_bounds__(kTPB) void k_sum_slices(const double* __restrict__ 
 }
 void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s) {
   hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((count + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, part, nz, count, out);
+}
+
+// ------------------------------------------------------------------ Gram matrix G = Y^T Y, accumulator-stationary (round 4)
+// The two checks of get_H_eigs (Lanczos.py:157-158, 288-323) need the n x n Gram matrix of the Ritz vectors.  Until round 3
+// this was k_gemm_tn with A = B = Y: every wave owned 32 columns x all n columns and re-read the whole row slab of Y per
+// k-step, all n^2 entries were computed, 17.7 ms at the headline.  G is symmetric and, in the MFMA's lane layout, the A
+// fragment of column tile i IS the B fragment of column tile i (lane (lr, lk) holds Y[k + lk][16 i + lr] either way).  So:
+// a workgroup of four waves (one per SIMD) owns a K range of rows of Y; per k-step every wave loads the CT fragments of the
+// 4-row slab (one contiguous 4 n doubles: Y is row-major) through a ring that runs PA k-steps ahead, and the CT (CT + 1) / 2
+// upper-triangular 16 x 16 tiles of G - dealt round-robin to the waves at compile time - stay in the accumulators for the
+// whole K range: 91 MFMAs per k-step at n = 200 instead of 182, no operand other than the slab, Y streamed once.
+// Split-K only across workgroups: every workgroup leaves its upper tiles in its own n x n slice, k_sum_slices_sym adds the
+// slices in fixed order and mirrors the result (G[i][j] == G[j][i] bit for bit).
+constexpr int gram_tri_count(int CT) { return CT * (CT + 1) / 2; }
+constexpr int gram_tri_row(int CT, int t) {
+  int i = 0;
+  while (t >= CT - i) {
+    t -= CT - i;
+    ++i;
+  }
+  return i;
+}
+constexpr int gram_tri_col(int CT, int t) {
+  int i = 0;
+  while (t >= CT - i) {
+    t -= CT - i;
+    ++i;
+  }
+  return i + t;
+}
+
+template <int CT, int W, int Q>
+struct GramTile {  // the Q-th tile of wave W: indices as compile-time constants (register arrays must never be indexed at run time)
+  static constexpr int t = W + 4 * Q;
+  static constexpr int i = gram_tri_row(CT, t), j = gram_tri_col(CT, t);
+};
+template <int CT, int W, int... Q>
+__device__ __forceinline__ void gram_mfmas(const double (&f)[CT], double4_t* acc, std::integer_sequence<int, Q...>) {
+  ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[GramTile<CT, W, Q>::i], f[GramTile<CT, W, Q>::j], acc[Q], 0, 0, 0)), ...);
+}
+template <int CT, int W, int Q>
+__device__ __forceinline__ void gram_store_tile(const double4_t& a, int n, int lr, int lk, double* __restrict__ Cz) {
+  const int col = 16 * GramTile<CT, W, Q>::j + lr;
+  if (col >= n) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int r = 16 * GramTile<CT, W, Q>::i + lk + 4 * g;
+    if (r < n) Cz[(int64_t)r * n + col] = a[g];
+  }
+}
+template <int CT, int W, int... Q>
+__device__ __forceinline__ void gram_store(const double4_t* acc, int n, int lr, int lk, double* __restrict__ Cz, std::integer_sequence<int, Q...>) {
+  (gram_store_tile<CT, W, Q>(acc[Q], n, lr, lk, Cz), ...);
+}
+
+template <int CT, int W>
+__device__ __forceinline__ void gram_wave(const double* __restrict__ Y, int64_t ldy, int64_t k_lo, int64_t k_hi, int n,
+                                          double* __restrict__ Cz) {
+  constexpr int NTRI = gram_tri_count(CT);
+  constexpr int NTW = (NTRI - W + 3) / 4;  // this wave's tiles: t = W, W + 4, ...
+  constexpr int PA = 4;                    // k-steps the slab loads run ahead of the MFMAs
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  double4_t acc[NTW > 0 ? NTW : 1];
+#pragma unroll
+  for (int q = 0; q < NTW; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int nsteps = k_hi > k_lo ? (int)((k_hi - k_lo + 3) >> 2) : 0;
+  double ring[PA][CT];
+  auto load = [&](int step, double (&f)[CT]) {
+    int64_t kr = k_lo + 4 * (int64_t)step + lk;
+    const bool ok = kr < k_hi;  // rows past the range contribute zero (A and B are the same registers)
+    if (!ok) kr = k_hi - 1;
+    const double* row = Y + kr * ldy + lr;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const double v = row[16 * t];
+      f[t] = ok ? v : 0.0;
+    }
+  };
+  if (nsteps > 0) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) load(p < nsteps ? p : nsteps - 1, ring[p]);
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += PA) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int st = s0 + p;
+      if (st < nsteps) {
+        gram_mfmas<CT, W>(ring[p], acc, std::make_integer_sequence<int, NTW>());
+        load(st + PA < nsteps ? st + PA : nsteps - 1, ring[p]);  // refill this ring slot
+      }
+    }
+  }
+  gram_store<CT, W>(acc, n, lr, lk, Cz, std::make_integer_sequence<int, NTW>());
+}
+
+// clk (may be null; 4 words): in-kernel clock record of workgroup 0's wave 0, like the Ritz kernels' (lz_gram_info): shader
+// cycles (s_memtime), ticks of the constant 100 MHz counter (s_memrealtime), k-steps walked, MFMAs per k-step of that wave.
+template <int CT>
+__global__ __launch_bounds__(kTPB) void k_gram_sym(const double* __restrict__ Y, int64_t ldy, int64_t rows, int64_t kchunk, int n,
+                                                  double* __restrict__ part, unsigned long long* __restrict__ clk) {
+  const int64_t k_lo = (int64_t)blockIdx.x * kchunk;
+  const int64_t k_hi = k_lo + kchunk < rows ? k_lo + kchunk : rows;
+  double* Cz = part + (int64_t)blockIdx.x * n * n;
+  const bool rec = clk != nullptr && blockIdx.x == 0 && threadIdx.x < 64;
+  unsigned long long c0 = 0, t0 = 0;
+  if (rec) {
+    c0 = clock64();
+    t0 = wall_clock64();
+  }
+  switch (threadIdx.x >> 6) {  // wave-uniform: every wave runs its own fully unrolled tile list
+    case 0: gram_wave<CT, 0>(Y, ldy, k_lo, k_hi, n, Cz); break;
+    case 1: gram_wave<CT, 1>(Y, ldy, k_lo, k_hi, n, Cz); break;
+    case 2: gram_wave<CT, 2>(Y, ldy, k_lo, k_hi, n, Cz); break;
+    default: gram_wave<CT, 3>(Y, ldy, k_lo, k_hi, n, Cz); break;
+  }
+  if (rec && threadIdx.x == 0) {
+    clk[0] = clock64() - c0;
+    clk[1] = wall_clock64() - t0;
+    clk[2] = (unsigned long long)((k_hi - k_lo + 3) >> 2);
+    clk[3] = (unsigned long long)((gram_tri_count(CT) + 3) / 4);
+  }
+}
+
+// out[r][c] = sum_z slice_z[r][c] for the upper 16 x 16 tiles, mirrored into the lower ones (fixed order of z)
+__global__ __launch_bounds__(kTPB) void k_sum_slices_sym(const double* __restrict__ part, int nz, int n, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x;
+  const int64_t count = (int64_t)n * n;
+  if (i >= count) return;
+  const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+  const int64_t src = (r >> 4) <= (c >> 4) ? i : (int64_t)c * n + r;
+  double a0 = 0.0, a1 = 0.0;
+  int z = 0;
+  for (; z + 1 < nz; z += 2) {
+    a0 += part[(int64_t)z * count + src];
+    a1 += part[(int64_t)(z + 1) * count + src];
+  }
+  if (z < nz) a0 += part[(int64_t)z * count + src];
+  out[i] = a0 + a1;
+}
+
+// G = Y^T Y into out (n x n, symmetric, complete); `part` = scratch of gram_scratch_doubles(n) doubles.
+// Returns false when the shape is not covered (n > 208 or a handful of rows): the caller takes launch_gram + launch_sum_slices.
+size_t gram_scratch_doubles(int n) { return (size_t)kGramMaxSlices * n * n; }
+bool launch_gram_sym(const double* Y, int64_t ldy, int64_t rows, int n, double* part, double* out, hipStream_t s, unsigned long long* clk) {
+  const int CT = (n + 15) / 16;
+  if (CT < 3 || CT > 13 || rows < 4096 || ldy != n) return false;
+  int nz = (int)std::min<int64_t>(kGramMaxSlices, (rows + 1023) / 1024);
+  int64_t kchunk = (rows + nz - 1) / nz;
+  kchunk = (kchunk + 3) & ~(int64_t)3;
+  nz = (int)((rows + kchunk - 1) / kchunk);
+#define LZ_GS(ct)                                                                                      \
+  case ct:                                                                                             \
+    hipLaunchKernelGGL((k_gram_sym<ct>), dim3(nz), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, part, clk); \
+    break;
+  switch (CT) {
+    LZ_GS(3) LZ_GS(4) LZ_GS(5) LZ_GS(6) LZ_GS(7) LZ_GS(8) LZ_GS(9) LZ_GS(10) LZ_GS(11) LZ_GS(12) LZ_GS(13)
+    default: return false;
+  }
+#undef LZ_GS
+  hipLaunchKernelGGL(k_sum_slices_sym, dim3((unsigned)(((int64_t)n * n + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, part, nz, n, out);
+  return true;
 }
 
 // G = Y^T Y as nz K-chunk partials (n x n each) in `part`; returns nz.  Y needs 16 doubles of slack at its end.

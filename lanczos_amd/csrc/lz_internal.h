@@ -180,6 +180,11 @@ void launch_ritz_gemm_cols(const double* V, int64_t ldv, int64_t rows, int kcoun
 // G = Y^T Y as K-chunk partials (n x n each); returns the number of chunks (<= nz_max)
 int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part, int nz_max, hipStream_t s);
 void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s);
+// accumulator-stationary symmetric Gram kernel (48 <= n <= 208, >= 4096 rows): out = Y^T Y complete; false: not covered
+constexpr int kGramMaxSlices = 768;
+size_t gram_scratch_doubles(int n);
+bool launch_gram_sym(const double* Y, int64_t ldy, int64_t rows, int n, double* part, double* out, hipStream_t s,
+                     unsigned long long* clk = nullptr);
 // per-block [s1 (n), s2 (n)] partials of the Ritz-vector quality sums; returns the number of blocks
 int launch_ritz_quality(const CsrDev& A, const double* Y, int64_t ldy, int n, double* part, hipStream_t s);
 // x[r] = Y[r * ldy + col] for r < rows, 0 for rows <= r < rows_pad

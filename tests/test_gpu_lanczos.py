@@ -233,6 +233,40 @@ def test_device_gram_and_quality_match_numpy():
     assert "Eigvec InnerProd" in buf.getvalue() and len(buf.getvalue().splitlines()) == 22
 
 
+@pytest.mark.parametrize("M,n,chunk", [(4096, 48, 0), (70001, 100, 0), (30011, 200, 0), (20000, 208, 0), (50000, 117, 0), (30011, 200, 8000), (5000, 33, 0)])
+def test_symmetric_gram_kernel(hip, M, n, chunk):
+    """Round 4: the accumulator-stationary symmetric Gram kernel (k_gram_sym: upper 16 x 16 tiles of Y^T Y kept in the
+    accumulators, Y streamed once, result mirrored) against NumPy and against the split-K TN GEMM it replaces (knob 19 = 1),
+    on a Y that is NOT orthonormal (random S) so every entry is exercised: ragged last column tile, ragged last k-step,
+    resident and chunked Y.  n = 33 (two column tiles) stays on the old path."""
+    A = synthetic.random_graph_laplacian(M, 3 * M, seed=5)
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    out = {}
+    S = np.random.default_rng(3).standard_normal((n, n))
+    for knob in (0, 1):
+        h = hip.Handle(0)
+        h.set_tuning(hip.TUNE_GRAM_KERNEL, knob)
+        if chunk:
+            h.set_tuning(hip.TUNE_RITZ_CHUNK_ROWS, chunk)
+        h.set_options(hip.FLAG_FUSED_NORM)
+        h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+        h.run(n, v0)
+        V = h.get_basis()
+        h.ritz_vectors(S, fetch=False)
+        G = h.ritz_gram()
+        info = h.gram_info()
+        assert (info["ksteps"] > 0) == (knob == 0 and n >= 48)
+        out[knob] = G
+        h.close()
+    Y = V.T @ S
+    ref = Y.T @ Y
+    scale = np.abs(ref).max()
+    assert np.array_equal(out[0], out[0].T)  # mirrored, not computed twice
+    assert np.abs(out[0] - ref).max() <= 1e-12 * scale
+    assert np.abs(out[1] - ref).max() <= 1e-12 * scale
+
+
 def test_get_H_eigs_asserts_fire_on_device_gram():
     """A basis that is not orthonormal must trip the reference's asserts (evaluated on the device Gram)."""
     from lanczos_amd import _capi
@@ -638,7 +672,21 @@ def test_checkpoint_and_resume_is_bit_identical(tmp_path, build, n1, n2, fused):
     assert np.array_equal(r2, whole.checkpoint()["r"])
     with pytest.raises(ValueError, match="must exceed"):
         third.resume_Lanczos(n1, ck)
-    for s in (whole, second, third):
+    # the resumed run's norm order is the checkpoint's, but the object's own setting is left alone; a checkpoint
+    # is refused by a different operator of the same size and by other options; a closed object says so clearly
+    assert second.fused_norm is Lanczos.fused_norm
+    H_other = H + (scipy.sparse.identity(H.shape[0], format="csr") if scipy.sparse.issparse(H) else np.eye(H.shape[0]))
+    other = Lanczos(H_other)
+    with pytest.raises(ValueError, match="different matrix"):
+        other.resume_Lanczos(n2, ck)
+    other.options = _capi.FLAG_SPMV_STREAM
+    with pytest.raises(ValueError, match="options"):
+        other.resume_Lanczos(n2, ck)
+    other.close()
+    third.close()
+    with pytest.raises(_capi.LanczosHipError, match="released"):
+        third.checkpoint()
+    for s in (whole, second):
         s.close()
 
 
