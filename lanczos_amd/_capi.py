@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -266,6 +267,7 @@ class Handle:
             self._h = None
             raise LanczosHipError(st, msg)
         self._keep = []  # keeps ctypes callbacks alive
+        self._reserve_lock = threading.Lock()  # lz_reserve may run on a helper thread: it must not meet lz_destroy
         self.breakdown = False
         global _live_handles
         if _live_handles is None:
@@ -281,9 +283,16 @@ class Handle:
             raise LanczosHipError(st, self.lib.lz_last_error(self._h).decode())
 
     def close(self):
-        if getattr(self, "_h", None):
-            self.lib.lz_destroy(self._h)
-            self._h = None
+        lock = getattr(self, "_reserve_lock", None)
+        if lock is not None:
+            lock.acquire()
+        try:
+            if getattr(self, "_h", None):
+                self.lib.lz_destroy(self._h)
+                self._h = None
+        finally:
+            if lock is not None:
+                lock.release()
 
     def __del__(self):
         try:
@@ -462,7 +471,9 @@ class Handle:
     # -- run
     def reserve(self, rows_local, n, with_ritz=True):
         """allocate the basis (and the Ritz vectors) of the coming run now; safe to call from a helper thread (see lz_reserve)"""
-        self.check(self.lib.lz_reserve(self._h, int(rows_local), int(n), 1 if with_ritz else 0))
+        with self._reserve_lock:
+            if self._h:
+                self.check(self.lib.lz_reserve(self._h, int(rows_local), int(n), 1 if with_ritz else 0))
 
     def run(self, n, v0_local):
         v0 = f64(v0_local)

@@ -161,6 +161,7 @@ class LanczosBase:
 
     def close(self):
         """Release the device memory (and, with ``devices``, end the worker processes) now rather than at exit."""
+        self._join_bg()
         if self._handle is not None:
             self._handle.close()
             self._handle = None
@@ -177,8 +178,16 @@ class LanczosBase:
         if self.verbose:
             print(msg)
 
+    def _join_bg(self):
+        """wait for the helper thread that reserves device buffers (started by ``_execute``)"""
+        bg = getattr(self, "_bg", None)
+        if bg is not None:
+            bg.join()
+            self._bg = None
+
     def _device(self):
         """the live handle behind the lazily fetched results (V, H_eigvecs, windows of them)"""
+        self._join_bg()
         if self._handle is None:
             raise _capi.LanczosHipError(-4, "the device state of this run was released (close()); run execute_Lanczos again")
         return self._handle
@@ -318,6 +327,7 @@ class LanczosBase:
         import time
 
         t_0 = time.perf_counter()
+        self._join_bg()
         pending_key = self._matrix_key_start()  # hashes H on helper threads while this thread draws v0
         # ... and the 8nM-byte basis (+ the Ritz vectors) is allocated on another one: a first hipMalloc of 16 GB takes 0.1-0.5 s
         reserve = None
@@ -325,15 +335,22 @@ class LanczosBase:
             import threading
 
             hres = self._get_handle()
+            basis_ready = threading.Event()
 
             def _reserve():
                 try:
-                    hres.reserve(M, n)
+                    hres.reserve(M, n, with_ritz=False)  # the basis: lz_run needs it
                 except Exception:  # never fatal: lz_run allocates (and reports) itself
+                    pass
+                basis_ready.set()
+                try:
+                    hres.reserve(M, n, with_ritz=True)  # the Ritz vectors: while the solve runs (lz_reserve touches only its own fields)
+                except Exception:
                     pass
 
             reserve = threading.Thread(target=_reserve, name="lz-reserve", daemon=True)
             reserve.start()
+            self._bg = reserve
         np.random.seed(seed)
         if v0 is None:
             v0 = np.random.uniform(-1, 1, size=(M))
@@ -353,8 +370,8 @@ class LanczosBase:
         try:
             self._upload_matrix(h, pending_key)
         finally:
-            if reserve is not None:  # lz_reserve must have returned before any other call that touches the buffers
-                reserve.join()
+            if reserve is not None:  # the basis must be reserved (or given up on) before lz_run looks for it
+                basis_ready.wait()
                 self._reserved = (M, n)
         t_2 = time.perf_counter()
         alpha, beta = h.run(n, v0)

@@ -1247,7 +1247,12 @@ int upload_csr(lz_handle h, CsrDev& A, const char* who, int64_t rows, int64_t nc
   } parts[kMaxHostThreads];
   const int64_t k_first = rows > 0 ? (int64_t)rowptr[1] - rowptr[0] : 0;
   parallel_ranges(rows, 1 << 16, [&](int t, int64_t lo, int64_t hi) {
-    Part& p = parts[t];
+    Part p;  // a local: the threads' slots of `parts` share cache lines
+    struct Publish {
+      Part& dst;
+      const Part& src;
+      ~Publish() { dst = src; }
+    } publish{parts[t], p};
     for (int64_t i = lo; i < hi; ++i) {
       const int64_t a = rowptr[i], b = rowptr[i + 1], d = b - a;
       if (d < 0 || a < 0 || b > nnz) {

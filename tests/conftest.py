@@ -76,7 +76,10 @@ def kb(hip):
     links).  The arms left the product library in round 3; their bit-identity tests load this build instead."""
     import types
 
-    if not os.path.isfile(hip.KBENCH_LIB_PATH):
+    srcdir = os.path.join(ROOT, "lanczos_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(srcdir, f)) for f in os.listdir(srcdir) if f.endswith((".hip", ".h")))
+    newest = max(newest, os.path.getmtime(os.path.join(ROOT, "include", "lanczos_hip.h")))
+    if not os.path.isfile(hip.KBENCH_LIB_PATH) or os.path.getmtime(hip.KBENCH_LIB_PATH) < newest:  # missing or stale
         import subprocess
 
         subprocess.run(["make", "-C", os.path.join(ROOT, "lanczos_amd", "csrc"), "-j4", "KBENCH=1"], check=True)
