@@ -340,7 +340,8 @@ int lz_set_csr_transpose(lz_handle h, int64_t nnz, const int32_t* rowptr, const 
 int lz_run_two_sided(lz_handle h, int n, const double* q0, const double* p0, double* alpha_out, double* beta_out,
                      double* gamma_out);
 /* Step API for unit parity tests and for the static IrrLanczos.bireorthogonalize(V1, V2, q_basis, p_basis, j):
- * allocate the four bases (zeroed), move rows, run the default branch of bireorthogonalize on row j (j >= 1). */
+ * allocate the four bases (zeroed), move rows, run the default branch of bireorthogonalize on row j (j >= 0; with j = 0 there
+ * is nothing to project on: the pair is rescaled to q.p = +-1 and seeds the two orthonormal bases, IrrLanczos.py:418-438). */
 int lz_bi_alloc(lz_handle h, int n);
 int lz_bi_set_row(lz_handle h, int which, int j, const double* row);
 int lz_bi_get_row(lz_handle h, int which, int j, double* row);

@@ -2211,6 +2211,15 @@ int bi_reorth(lz_handle h, int jj, bool from_rs) {
     pend = (defer && dots == 0) ? pbuf[cur] : nullptr;
     cur ^= 1;
   };
+  if (jj == 0) {
+    // j = 0 (the static method's own call shape; the driver starts at j = 1): both projection loops are empty - rescale the pair
+    // to q.p = +-1 (:418-420) and seed the two orthonormal bases with it (:423-424, 437-438)
+    link(0, 0, 1, q, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
+    link(1, 0, 2, q, p, q, p, f, nullptr, nullptr, nullptr, nullptr, 2);
+    link(1, 0, 2, qb, pb, q, p, f, nullptr, nullptr, nullptr, nullptr, 2);
+    link(1, 0, 3, qb, pb, qb, pb, f, nullptr, nullptr, nullptr, nullptr, 2);
+    return check_launch(h, "bireorthogonalize(j = 0)");
+  }
   // project q on the orthonormalised p's and p on the orthonormalised q's, one vector at a time (:409-416)
   for (int i = 0; i < jj; ++i) {
     const double *a = bi_row(h, 3, i), *b = bi_row(h, 2, i);
@@ -2296,7 +2305,6 @@ int lz_bi_get_row(lz_handle h, int which, int j, double* row) {
 int lz_step_bireorth(lz_handle h, int j) {
   if (!h) return LZ_ERR_ARG;
   LZ_TRY(bi_check_row(h, 0, j));
-  if (j < 1) return fail(h, LZ_ERR_ARG, "lz_step_bireorth: j must be >= 1");
   LZ_HIP(h, hipSetDevice(h->dev));
   LZ_TRY(bi_reorth(h, j, false));
   LZ_HIP(h, hipStreamSynchronize(h->stream));

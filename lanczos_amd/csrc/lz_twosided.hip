@@ -300,6 +300,7 @@ void launch_bi(int first, int pend, int dots, double* x, double* y, const double
     case 102: LZ_BI(1, 0, 2); break;  // rescale + norms
     case 103: LZ_BI(1, 0, 3); break;  // normalise
     case 2: LZ_BI(0, 0, 2); break;    // norms only
+    case 1: LZ_BI(0, 0, 1); break;    // q.p of a stored pair (bireorthogonalize with j = 0: nothing to project on)
     default: break;
   }
 #undef LZ_BI

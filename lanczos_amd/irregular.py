@@ -26,7 +26,8 @@ class IrrLanczos(LanczosBase):
 
         Reference behaviour kept: only ``v0=None`` works (the second start vector exists only on that branch, :98-102);
         the start pair comes from the global legacy RNG (two draws) and is scaled to ``q0 . p0 = +-1``; no breakdown
-        check.  ``dtype`` other than float64 is not supported by the device path."""
+        check.  ``dtype=np.float32``: inputs rounded to float32 where the reference rounds them, recurrence in float64 (the
+        device path's only precision), results published as float32, with a one-line notice."""
         if n > self.M:
             raise ValueError("n cannot be larger than M!")
         assert self.H.shape[0] == self.H.shape[1]
@@ -35,11 +36,19 @@ class IrrLanczos(LanczosBase):
         _use_cuda_or_notice(self, use_cuda)
         if self._multi():
             raise NotImplementedError("the two-sided variant runs on one GPU (devices must be None or a single entry)")
-        if np.dtype(dtype) != np.float64:
-            raise NotImplementedError("the device path computes in float64 only")
+        dtype = np.dtype(dtype)
+        if dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise NotImplementedError("dtype must be float64 or float32")
+        if dtype != np.float64:
+            # The reference would run its whole recurrence in that precision (:90-96, 114-125).  The device path has float64
+            # kernels only: the INPUTS are rounded to `dtype` exactly where the reference rounds them (the matrix at :91-92, the
+            # start pair at :115-119), the recurrence runs in float64, and alpha / beta / gamma / V are published in `dtype` -
+            # results at least as accurate as a float32 recurrence, not bit-comparable with one (no caller in the reference
+            # passes dtype).
+            print("+++ dtype=%s: inputs rounded to %s, recurrence in float64 on the MI355X, results published as %s." % (dtype.name, dtype.name, dtype.name))
         M = self.M
-        H = scipy.sparse.csr_matrix(self.H, dtype=np.float64)          # :91
-        HT = scipy.sparse.csr_matrix(H.transpose(), dtype=np.float64)  # :92
+        H = scipy.sparse.csr_matrix(scipy.sparse.csr_matrix(self.H, dtype=dtype), dtype=np.float64)  # :91
+        HT = scipy.sparse.csr_matrix(H.transpose(), dtype=np.float64)                                # :92
         np.random.seed(seed)
         if v0 is None:
             v0 = np.random.uniform(-1, 1, size=(M))
@@ -54,6 +63,8 @@ class IrrLanczos(LanczosBase):
         if n < 2:
             # with n == 1 the loop body never runs and :163 reads an unassigned residual
             raise UnboundLocalError("local variable 'r' referenced before assignment")
+        if dtype != np.float64:
+            v0, v1 = v0.astype(dtype).astype(np.float64), v1.astype(dtype).astype(np.float64)  # q[0] = v0, p[0] = v1 into dtype arrays (:115-119)
 
         kind, rowptr, colidx, vals = _pack_matrix(H)
         _, t_rowptr, t_colidx, t_vals = _pack_matrix(HT)
@@ -70,6 +81,8 @@ class IrrLanczos(LanczosBase):
         alpha, beta, gamma = h.run_two_sided(n, v0, v1)
         self._timings = h.timings()
         self.sweeps = n - 1
+        if dtype != np.float64:
+            alpha, beta, gamma = alpha.astype(dtype), beta.astype(dtype), gamma.astype(dtype)
 
         # H_eff exactly as :165-174 lays it out (row i >= 1 carries gamma[i-1], not gamma[i], right of the diagonal)
         H_eff = np.zeros((n, n))
@@ -83,7 +96,7 @@ class IrrLanczos(LanczosBase):
             H_eff[i, i + 1] = gamma[i - 1]
         self._alpha, self._beta, self._gamma = alpha, beta, gamma
         self._H_eff = H_eff
-        self._V = None
+        self._V = None if dtype == np.float64 else h.get_basis().T.astype(dtype)  # (the reference's q is a dtype array, :114)
         self.H = H  # the reference's GPU branch leaves a SciPy CSR in self.H (:183)
         self.H_eigs_have_been_found = False
         self._say("+++ Lanczos executed successfully.")
@@ -121,7 +134,9 @@ class IrrLanczos(LanczosBase):
     def bireorthogonalize(V1, V2, q_basis, p_basis, j, use_cuda=True, mem_safe=False):
         """In place on row ``j`` of the four (n, M) arrays, the reference's default branch (IrrLanczos.py:408-441):
         project ``V1[j]`` on ``p_basis[:j]`` and ``V2[j]`` on ``q_basis[:j]`` (sequential Gram-Schmidt), rescale the
-        pair to ``V1[j] . V2[j] = +-1``, then extend the two orthonormal bases by row ``j``.  ``mem_safe=True`` is the
+        pair to ``V1[j] . V2[j] = +-1``, then extend the two orthonormal bases by row ``j``.  ``j = 0`` (nothing to project on)
+        updates all four rows and then raises ``ValueError`` exactly as the reference does (its closing ``np.max`` runs over an
+        empty array).  ``mem_safe=True`` is the
         reference's other branch (:398-407, no caller there): one sweep of ``V1[j]`` against all rows of ``V2`` and of
         ``V2[j]`` against all rows of ``V1``, each coefficient over that row's own squared norm; ``q_basis`` /
         ``p_basis`` are not read.  Both run on the device."""
@@ -145,10 +160,10 @@ class IrrLanczos(LanczosBase):
             finally:
                 h.close()
             return
-        if j < 1:
-            raise ValueError("bireorthogonalize needs j >= 1")
         arrs = [np.asarray(a) for a in (V1, V2, q_basis, p_basis)]
         n, M = arrs[0].shape
+        if not 0 <= j < n:
+            raise IndexError("index %d is out of bounds for axis 0 with size %d" % (j, n))
         h = _capi.Handle(LanczosBase.device_id)
         try:
             eye_ptr = np.arange(M + 1, dtype=np.int32)
@@ -162,3 +177,8 @@ class IrrLanczos(LanczosBase):
                 a[j] = h.bi_get_row(which, j)
         finally:
             h.close()
+        if j == 0:
+            # The reference's last statement (IrrLanczos.py:441) takes the maximum over the j earlier basis rows: with j = 0 that
+            # is np.max of an empty array, which raises - AFTER all four rows have been updated in place (pinned by
+            # tests/golden/bireorth_default_j0.npz, an output of the reference's own static method).  Same here.
+            raise ValueError("zero-size array to reduction operation maximum which has no identity")

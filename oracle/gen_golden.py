@@ -169,6 +169,35 @@ def mem_safe_main():
     print(f"bireorth_mem_safe            ref-vs-oracle max|diff|={worst:.3e}")
 
 
+def bireorth_j0_main():
+    """The static IrrLanczos.bireorthogonalize(V1, V2, q_basis, p_basis, j=0) - default branch (IrrLanczos.py:408-441) on the
+    reference's CPU branch.  With j = 0 both projection loops are empty: the pair is rescaled to V1[0].V2[0] = +-1 and seeds the
+    two orthonormal bases - and the LAST statement (:441, the maximum of an empty array) raises ValueError, after every array
+    has been updated in place.  Recorded: the four row-0 outputs and the exception's type and text."""
+    rng = np.random.default_rng(77)
+    n, M = 4, 257
+    arrs = [rng.uniform(-1, 1, (n, M)) for _ in range(4)]
+    arrs[1][0] = -np.abs(arrs[1][0]) * np.sign(arrs[0][0])  # V1[0].V2[0] < 0: the sign factor of :420 matters
+    ref = [a.copy() for a in arrs]
+    err = None
+    try:
+        quiet(ref_irregular.IrrLanczos.bireorthogonalize, *ref, 0, use_cuda=False)
+    except Exception as e:  # noqa: BLE001 - the point is to record what the reference raises
+        err = e
+    assert isinstance(err, ValueError), err
+    ora = [a.copy() for a in arrs]
+    two_sided_ref.bireorthogonalize(*ora, 0)
+    worst = max(np.abs(o - r).max() for o, r in zip(ora, ref))
+    for a, r in zip(arrs, ref):
+        assert np.array_equal(a[1:], r[1:])
+    data = dict(numpy_version=np.__version__, error_type=type(err).__name__, error_text=str(err), ref_vs_oracle_maxabs=worst)
+    for name, a, r in zip(("V1", "V2", "q_basis", "p_basis"), arrs, ref):
+        data[name] = a
+        data[name + "_out0"] = r[0].copy()
+    np.savez_compressed(os.path.join(OUT, "bireorth_default_j0.npz"), **data)
+    print(f"bireorth_default_j0          ref-vs-oracle max|diff|={worst:.3e}; the reference raises {type(err).__name__}: {err}")
+
+
 def deuteron_potential(x, y, z):
     # same functional form/constants the reference's driver uses (3Ddeuteron.py:51-61); data, not code of the path
     r = np.sqrt(x**2 + y**2 + z**2)
@@ -182,6 +211,8 @@ def main():
         return two_sided_main()
     if "--mem-safe-only" in sys.argv:
         return mem_safe_main()
+    if "--bireorth-j0-only" in sys.argv:
+        return bireorth_j0_main()
 
     # (i) C1: dense 512 x 512 random symmetric, n = 20, explicit v0
     A = synthetic.dense_symmetric(512, seed=0)
@@ -260,6 +291,7 @@ def main():
     # the Irregular copy's two-sided variant (IrrLanczos.py:77-187)
     two_sided_main()
     mem_safe_main()
+    bireorth_j0_main()
 
 
 if __name__ == "__main__":

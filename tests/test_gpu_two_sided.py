@@ -8,6 +8,7 @@ tightly."""
 import os
 
 import numpy as np
+import scipy.sparse
 import pytest
 
 from conftest import GOLDEN_DIR, load_golden, two_sided_names
@@ -86,6 +87,24 @@ def test_bireorthogonalize_step_matches_oracle():
     assert abs(np.linalg.norm(got[2][j]) - 1) < 1e-14 and np.abs(got[2][:j] @ got[2][j]).max() < 1e-13
 
 
+def test_bireorthogonalize_j0_behaves_like_the_reference():
+    """``bireorthogonalize(V1, V2, q_basis, p_basis, 0)`` (IrrLanczos.py:408-441 with both projection loops empty): the reference
+    rescales the pair, seeds both orthonormal bases IN PLACE and then raises ValueError from its closing ``np.max`` over an empty
+    array.  Held to the reference's own outputs (tests/golden/bireorth_default_j0.npz: the four rows and the exception)."""
+    d = np.load(os.path.join(GOLDEN_DIR, "bireorth_default_j0.npz"))
+    arrs = [d[k].copy() for k in ("V1", "V2", "q_basis", "p_basis")]
+    with pytest.raises(ValueError) as ei:
+        IrrLanczos.bireorthogonalize(*arrs, 0)
+    assert str(d["error_type"]) == "ValueError" and str(ei.value) == str(d["error_text"])
+    for k, got in zip(("V1", "V2", "q_basis", "p_basis"), arrs):
+        want = d[k + "_out0"]
+        assert np.abs(got[0] - want).max() <= 1e-13 * np.abs(want).max(), k
+        assert np.array_equal(got[1:], d[k][1:])  # only row 0 is touched
+    assert d["V1"][0] @ d["V2"][0] < 0 and abs(arrs[0][0] @ arrs[1][0] - 1) < 1e-13  # the sign factor of :420 flipped V2[0]
+    with pytest.raises(IndexError):
+        IrrLanczos.bireorthogonalize(*arrs, 4)
+
+
 def test_bireorthogonalize_mem_safe_matches_the_reference():
     """the static method's other branch (IrrLanczos.py:398-407) against outputs of the reference's own static method
     (tests/golden/bireorth_mem_safe.npz): rows past j filled or zero, j = 0, and a longer random case against the oracle"""
@@ -107,6 +126,24 @@ def test_bireorthogonalize_mem_safe_matches_the_reference():
     assert np.abs(V1[j] - R1[j]).max() <= 1e-13 * np.abs(R1[j]).max() and np.abs(V2[j] - R2[j]).max() <= 1e-13 * np.abs(R2[j]).max()
     with pytest.raises(ValueError, match="0 <= j < n"):
         IrrLanczos.bireorthogonalize(V1, V2, None, None, n, mem_safe=True)
+
+
+def test_float32_dtype_is_accepted_with_a_notice(capsys):
+    """``execute_Lanczos(..., dtype=np.float32)`` (IrrLanczos.py:77, no caller in the reference): inputs rounded to float32 where
+    the reference rounds them, recurrence in float64, results published as float32 - within float32 rounding of the float64 run
+    on the float32-rounded matrix, and V comes back as a float32 array like the reference's ``q``."""
+    rng = np.random.default_rng(12)
+    A = scipy.sparse.random(400, 400, density=0.02, random_state=rng, format="csr") + scipy.sparse.diags(np.linspace(1, 3, 400))
+    IrrLanczos.verbose = False
+    s32 = IrrLanczos(A)
+    s32.execute_Lanczos(6, dtype=np.float32)
+    assert "dtype=float32" in capsys.readouterr().out
+    assert s32.V.dtype == np.float32 and s32.V.shape == (400, 6) and s32.H_eff.dtype == np.float64
+    s64 = IrrLanczos(scipy.sparse.csr_matrix(A, dtype=np.float32))  # the same rounded matrix, float64 run
+    s64.execute_Lanczos(6)
+    # (the start pair is rounded to float32 as well, and the two-sided recurrence amplifies a perturbation ~2x per step)
+    assert np.abs(s32.H_eff - s64.H_eff).max() <= 1e-4 * np.abs(s64.H_eff).max()
+    assert np.array_equal(s32.H_eff, s32.H_eff.astype(np.float32).astype(np.float64))  # coefficients are float32 values
 
 
 def test_nonsymmetric_uses_the_transpose():
@@ -161,6 +198,8 @@ def test_error_behaviour():
         s.execute_Lanczos(4, use_cuda=False)
     with pytest.raises(ValueError, match="Lanczos Algorithm has not been called."):
         s.H_eff
+    with pytest.raises(NotImplementedError, match="float64 or float32"):
+        s.execute_Lanczos(4, dtype=np.float16)
     s.strict_use_cuda = False
     s.execute_Lanczos(4, use_cuda=False)  # accepted: one notice line, then the HIP path
     t = IrrLanczos(A)
