@@ -280,27 +280,6 @@ int upload2d(lz_handle h, void* dst, size_t dpitch, const void* src, size_t spit
   return LZ_OK;
 }
 
-// run fn(t, lo, hi) over [0, count) on a few host threads (the validation sweeps over all nnz of lz_set_csr)
-template <class F>
-void parallel_ranges(int64_t count, int64_t min_per_thread, F fn) {
-  const unsigned hc = std::thread::hardware_concurrency();
-  int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, hc ? hc / 2 : 1), count / std::max<int64_t>(min_per_thread, 1)));
-  if (xfer_threads() == 0) T = 1;  // LZ_XFER_THREADS=0: no helper threads anywhere
-  std::vector<std::thread> pool;
-  const int64_t per = (count + T - 1) / T;
-  int started = 0;
-  try {
-    for (int t = 1; t < T; ++t) {
-      pool.emplace_back(fn, t, std::min(count, t * per), std::min(count, (t + 1) * per));
-      ++started;
-    }
-  } catch (const std::system_error&) {
-  }
-  fn(0, (int64_t)0, std::min(count, per));
-  for (int t = started + 1; t < T; ++t) fn(t, std::min(count, t * per), std::min(count, (t + 1) * per));  // threads that could not be had
-  for (auto& th : pool) th.join();
-}
-constexpr int kMaxHostThreads = 16;
 
 // ---- roctx ranges (opt-in: LZ_ROCTX=1) --------------------------------------
 // Host-side phase markers for `rocprofv3 --marker-trace`: one range per kernel class around its launches.  The marker

@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "lanczos_hip.h"
@@ -19,6 +22,29 @@ constexpr int kNumCU = 256;
 constexpr int kNumXCD = 8;
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+int xfer_threads();
+// run fn(t, lo, hi) over [0, count) on a few host threads (the validation sweeps over all nnz of lz_set_csr)
+template <class F>
+inline void parallel_ranges(int64_t count, int64_t min_per_thread, F fn) {
+  const unsigned hc = std::thread::hardware_concurrency();
+  int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, hc ? hc / 2 : 1), count / std::max<int64_t>(min_per_thread, 1)));
+  if (xfer_threads() == 0) T = 1;  // LZ_XFER_THREADS=0: no helper threads anywhere
+  std::vector<std::thread> pool;
+  const int64_t per = (count + T - 1) / T;
+  int started = 0;
+  try {
+    for (int t = 1; t < T; ++t) {
+      pool.emplace_back(fn, t, std::min(count, t * per), std::min(count, (t + 1) * per));
+      ++started;
+    }
+  } catch (const std::system_error&) {
+  }
+  fn(0, (int64_t)0, std::min(count, per));
+  for (int t = started + 1; t < T; ++t) fn(t, std::min(count, t * per), std::min(count, (t + 1) * per));  // threads that could not be had
+  for (auto& th : pool) th.join();
+}
+constexpr int kMaxHostThreads = 16;
 
 // ---- CSR SpMV ----------------------------------------------------------
 struct CsrDev {

@@ -40,6 +40,7 @@
 // is, so every run produces the same bits.
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 #include <mutex>
@@ -73,6 +74,8 @@ struct PbDev {
   uint32_t* gdst = nullptr;    // np / 8: slot in T2 of every group of 8 stream entries
   double* pvals = nullptr;     // np (values that need fp64)
   float* pvals32 = nullptr;    // np (every value exactly representable in fp32: half the bytes, same products)
+  bool constv = false;         // every off-diagonal value is the SAME number (graph Laplacians D - Adj: -1): no value stream at all
+  double cval = 0.0;
   double* dvals = nullptr;     // rows: the diagonal entry of every row (0 where a row has none); nullptr: diagonal not split off
   int maxrows = 0;             // longest row block (rows)
   double* T2 = nullptr;        // np products
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ ro
       const int cb = col / W;
       const int p = atomicAdd(&cursor[cb], 1);
       const int64_t t = (int64_t)cbptr[cb] + toff[(int64_t)rb * nCB + cb] + p;
-      pvals[t] = (VT)vals[k];
+      if (pvals) pvals[t] = (VT)vals[k];
       pcol[t] = (uint16_t)(col - cb * W);
       perm[k] = (uint16_t)(ls[cb] + p);
     }
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ ro
     const int n = len[(int64_t)rb * nCB + c];
     const int64_t t0 = (int64_t)cbptr[c] + toff[(int64_t)rb * nCB + c];  // a multiple of 8: every tile is padded
     for (int p = n; p < pad8(n); ++p) {  // pad slots: zero-valued entries, so that whole sectors are written
-      pvals[t0 + p] = (VT)0;
+      if (pvals) pvals[t0 + p] = (VT)0;  // (without a value stream a pad slot receives cval * v[c0]: never read - perm maps real entries only)
       pcol[t0 + p] = 0;
     }
     for (int g = 0; g < pad8(n) / kPbPad; ++g) gdst[(t0 >> kPbPadLog) + g] = segbase + (uint32_t)(ls[c] + kPbPad * g);
@@ -185,11 +188,18 @@ __device__ __forceinline__ double2 pb_ld_vals(const float* pv, int64_t pair) {
   return make_double2((double)v.x, (double)v.y);  // exact: the layout keeps fp32 only where every value round-trips
 }
 
+// no value stream (PbDev::constv): every product is cval * v[column]
+struct PbConst {
+  double c;
+};
+__device__ __forceinline__ double2 pb_ld_vals(const PbConst* pv, int64_t) { return make_double2(0.0, 0.0); }
+
 template <int U, class VT>
 __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __restrict__ cbptr, const VT* __restrict__ pvals,
                                                            const uint16_t* __restrict__ pcol, const uint32_t* __restrict__ gdst,
                                                            const double* __restrict__ x, int64_t ncols, int W,
-                                                           double* __restrict__ T2) {
+                                                           double* __restrict__ T2, double cval) {
+  constexpr bool kConst = std::is_same<VT, PbConst>::value;
   extern __shared__ double xs[];
   const int cb = blockIdx.x;
   const int64_t c0 = (int64_t)cb * W;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t p = base + (int64_t)u * kPbThreads;
-      a[u] = pb_ld_vals(pvals, p);
+      a[u] = kConst ? make_double2(cval, cval) : pb_ld_vals(pvals, p);
       c[u] = __builtin_nontemporal_load(pc2 + p);
       d[u] = __builtin_nontemporal_load(gdst + (p >> (kPbPadLog - 1)));
     }
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
     for (int u = 0; u < U; ++u) {
       const int64_t p = base + (int64_t)u * kPbThreads;
       const bool ok = p < p1;
-      a[u] = ok ? pb_ld_vals(pvals, p) : make_double2(0.0, 0.0);
+      a[u] = ok ? (kConst ? make_double2(cval, cval) : pb_ld_vals(pvals, p)) : make_double2(0.0, 0.0);
       c[u] = ok ? __builtin_nontemporal_load(pc2 + p) : 0u;
       d[u] = ok ? __builtin_nontemporal_load(gdst + (p >> (kPbPadLog - 1))) : 0u;
     }
@@ -454,6 +464,7 @@ hipError_t pb_raise_lds_limits() {
   };
   up(reinterpret_cast<const void*>(k_pb_products<4, double>));
   up(reinterpret_cast<const void*>(k_pb_products<4, float>));
+  up(reinterpret_cast<const void*>(k_pb_products<4, PbConst>));
   up(reinterpret_cast<const void*>(k_pb_rows<0>));
 #ifdef LZ_KBENCH
   up(reinterpret_cast<const void*>(k_pb_rows<1>));
@@ -504,22 +515,53 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   const int nCB = (int)((A.ncols + W - 1) / W);
   // The diagonal split needs a row's own column to be its local index: the whole square matrix on this rank.
   bool diag = A.host_colidx != nullptr && A.rows == A.ncols;
-  if (diag) {  // a row that stores its diagonal TWICE (unsummed duplicates are legal CSR) has one slot for two products: no split then
-    for (int64_t r = 0; r < A.rows && diag; ++r) {
-      int nd = 0;
-      for (int64_t k = rowptr_host[r]; k < rowptr_host[r + 1]; ++k) nd += A.host_colidx[k] == r;
-      if (nd > 1) diag = false;
-    }
-  }
   bool f32 = A.host_vals != nullptr;
-  if (f32)
-    for (int64_t k = 0; k < A.nnz; ++k) {
-      const double v = A.host_vals[k];
-      if ((double)(float)v != v) {  // (NaN fails too: such a matrix keeps its fp64 stream)
-        f32 = false;
-        break;
+  bool constv = A.host_vals != nullptr && A.host_colidx != nullptr;
+  double cval = 0.0;
+  std::vector<uint8_t> ndiag;  // per row: how many of its entries sit on the diagonal (row-block planning below)
+  if (A.host_colidx) {
+    // One sweep over the caller's arrays on a few host threads (round 3: three single-thread sweeps over all nnz):
+    //  * a row that stores its diagonal TWICE (unsummed duplicates are legal CSR) has one slot for two products: no split then
+    //  * fp32 value stream only where EVERY value round-trips through float (NaN fails too: such a matrix keeps fp64)
+    //  * no value stream at all where every OFF-diagonal value is one and the same number (graph Laplacians: -1)
+    ndiag.assign((size_t)A.rows, 0);
+    bool have_c = false;
+    for (int64_t r = 0; r < A.rows && !have_c; ++r)
+      for (int64_t k = rowptr_host[r]; k < rowptr_host[r + 1]; ++k)
+        if (A.host_colidx[k] != r) {
+          cval = A.host_vals ? A.host_vals[k] : 0.0;
+          have_c = true;
+          break;
+        }
+    struct Part {
+      bool dup = false, not32 = false, notconst = false;
+    } parts[kMaxHostThreads];
+    const bool square = A.rows == A.ncols;
+    parallel_ranges(A.rows, 1 << 16, [&](int t, int64_t lo, int64_t hi) {
+      Part p;
+      for (int64_t r = lo; r < hi; ++r) {
+        int nd = 0;
+        for (int64_t k = rowptr_host[r]; k < rowptr_host[r + 1]; ++k) {
+          const bool on = square && A.host_colidx[k] == r;
+          nd += on;
+          if (A.host_vals) {
+            const double v = A.host_vals[k];
+            if ((double)(float)v != v) p.not32 = true;
+            if (!on && !(v == cval)) p.notconst = true;
+          }
+        }
+        if (nd > 1) p.dup = true;
+        ndiag[(size_t)r] = (uint8_t)std::min(nd, 255);
       }
+      parts[t] = p;
+    });
+    for (const Part& p : parts) {
+      if (p.dup) diag = false;
+      if (p.not32) f32 = false;
+      if (p.notconst) constv = false;
     }
+    if (!have_c || !diag) constv = false;  // (without the diagonal split the diagonal values ride in the stream too)
+  }
   // Row blocks.  Phase 2 keeps in LDS: the padded segment (off-diagonal products + at most 7 pad slots per column block),
   // one diagonal product per row, and an aligned window of the block's perm entries (2 bytes per CSR entry).
   const int64_t lds_budget = kPbLdsMax - 32 - (int64_t)(kPbPad - 1) * nCB * 8 - 32;
@@ -536,9 +578,7 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
     int64_t e = r, ent = 0, off = 0;
     while (e < A.rows && e - r < kPbMaxRows) {
       const int64_t nr = (int64_t)rowptr_host[e + 1] - rowptr_host[e];
-      int64_t nd = 0;
-      if (diag)
-        for (int64_t k = rowptr_host[e]; k < rowptr_host[e + 1]; ++k) nd += A.host_colidx[k] == e;
+      const int64_t nd = diag ? ndiag[(size_t)e] : 0;
       const int64_t ent2 = ent + nr, off2 = off + nr - nd, rows2 = e - r + 1;
       if (ent2 > cap || off2 > off_max || 8 * off2 + (diag ? 8 * rows2 : 0) + 2 * (ent2 + 16) > lds_budget) break;
       ent = ent2;
@@ -626,7 +666,10 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   pb->lds2 = lds2;
   chk(pb_alloc(pb->pcol, (size_t)np + 8));
   chk(pb_alloc(pb->gdst, (size_t)np / kPbPad + 8));
-  if (f32)
+  pb->constv = constv;
+  pb->cval = cval;
+  if (constv) {
+  } else if (f32)
     chk(pb_alloc(pb->pvals32, (size_t)np + 8));
   else
     chk(pb_alloc(pb->pvals, (size_t)np + 8));
@@ -635,7 +678,10 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
   if (e == hipSuccess) chk(hipMemcpyAsync(pb->rbseg, seg.data(), seg.size() * sizeof(int2), hipMemcpyHostToDevice, s));
   if (e == hipSuccess) {
     const size_t sm = (size_t)(2 * nCB + 1) * sizeof(int);
-    if (f32)
+    if (constv)
+      hipLaunchKernelGGL(k_pb_place<float>, dim3(nRB), dim3(256), sm, s, A.rowptr, A.colidx, A.vals, pb->rbptr, (int)W, nCB, pb->cbptr, len, toff,
+                         pb->rbseg, pb->perm, pb->pcol, pb->gdst, (float*)nullptr, pb->dvals);
+    else if (f32)
       hipLaunchKernelGGL(k_pb_place<float>, dim3(nRB), dim3(256), sm, s, A.rowptr, A.colidx, A.vals, pb->rbptr, (int)W, nCB, pb->cbptr, len, toff,
                          pb->rbseg, pb->perm, pb->pcol, pb->gdst, pb->pvals32, pb->dvals);
     else
@@ -668,12 +714,15 @@ int pb_num_partials(const PbDev* pb) { return pb->nRB; }
 // Returns the number of partials.
 int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s) {
   const size_t lds1 = (size_t)pb->W * sizeof(double);
-  if (pb->pvals32)
+  if (pb->constv)
+    hipLaunchKernelGGL((k_pb_products<4, PbConst>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, (const PbConst*)nullptr, pb->pcol, pb->gdst, x,
+                       A.ncols, pb->W, pb->T2, pb->cval);
+  else if (pb->pvals32)
     hipLaunchKernelGGL((k_pb_products<4, float>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals32, pb->pcol, pb->gdst, x, A.ncols,
-                       pb->W, pb->T2);
+                       pb->W, pb->T2, 0.0);
   else
     hipLaunchKernelGGL((k_pb_products<4, double>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, pb->gdst, x, A.ncols,
-                       pb->W, pb->T2);
+                       pb->W, pb->T2, 0.0);
   const int grid = std::min(pb->nRB, pb->ncu);  // one segment fills a CU's LDS: one persistent workgroup per CU
   const int segcap = pb->segmax;
 #define LZ_PB_ROWS(abl)                                                                                                        \
@@ -702,7 +751,7 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
 // stream entry of phase 1's input, 1 if the diagonal is split off}
 void pb_layout_info(const PbDev* pb, int64_t* np, int* in_bytes_x2, int* diag) {
   *np = pb->np;
-  *in_bytes_x2 = (pb->pvals32 ? 8 : 16) + 4 + 1;  // twice (value + 2-byte column + 4 bytes of destination per 8 entries)
+  *in_bytes_x2 = (pb->constv ? 0 : pb->pvals32 ? 8 : 16) + 4 + 1;  // twice (value + 2-byte column + 4 bytes of destination per 8 entries)
   *diag = pb->dvals != nullptr;
 }
 
