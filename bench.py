@@ -523,7 +523,13 @@ def main():
                 tp = max(boot.allgather_obj(tp))
             tmp = solver.timings()
             theta_part = np.linalg.eigvalsh(solver.H_eff)
+            # semi-orthogonality of the basis this mode leaves (sqrt(eps) by design): device Gram matrix of its Ritz vectors
+            # Y = V S, |Y^T Y - I|_max = |S^T (V^T V - I) S|_max
+            solver.get_H_eigs(fetch=False)
+            gdev = float(np.abs(solver.h.ritz_gram() - np.eye(k)).max())
+            solver.timings()
             partial = {
+                "basis_semi_orthogonality_max_dev": gdev,
                 "iterations_per_s": round(2 * k / tp, 1), "ms_per_solve": round(1e3 * tp / 2, 3), "sweeps": solver.h.last_sweeps(), "of": k,
                 "engine": solver.h.last_engine(), "host_syncs_inside_lz_run": solver.h.last_host_syncs(),
                 "device_ms_per_solve": round(tmp["total_ms"] / 2, 3),

@@ -122,9 +122,9 @@ int lz_set_options(lz_handle h, int flags);
  *   15  loop structure (0 auto: three launches per step for small problems, five up to 4e6 rows per rank, else six; 1 six always)
  *   16  rows per chunk of the CHUNKED Ritz mode (0 auto: chunked only when Y does not fit beside the basis; > 0 forces it: tests)
  *   11  two-sided Gram-Schmidt links (0 / 1: streaming kernel + fold kernel per link)
- *   17  fixed-K (stencil) SpMV layout: 0 auto (ELL-ordered second copy for 5, 7 and 27 entries per row: a lane owns whole rows),
- *       1 never (CSR-order kernel with products staged through LDS; CSR-stream for 27), 2 ELL one row per lane and trip,
- *       3 ELL two adjacent rows per lane (16-byte loads)
+ *   17  fixed-K (stencil) SpMV layout: 0 auto (CSR-order kernel with products staged through LDS; the ELL-ordered second copy -
+ *       a lane owns whole rows - is built and used only by the partial re-orthogonalisation loop's fused SpMV), 1 never ELL,
+ *       2 ELL for every SpMV, one row per lane and trip, 3 ELL, two adjacent rows per lane (16-byte loads)
  *   19  Gram matrix of the Ritz vectors: 0 auto (accumulator-stationary symmetric kernel where it applies), 1 the split-K TN GEMM always
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
  *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta)

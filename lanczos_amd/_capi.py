@@ -48,7 +48,7 @@ TUNE_POISON_BASIS = 13      # 1 = NaN-poison a fresh basis allocation (test knob
 TUNE_SPMV_PLAN = 14         # irregular SpMV plan (0 auto, 1 never two-phase, 2 always)
 TUNE_LOOP = 15              # loop structure (0 auto, 1 six launches per step always)
 TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 forces it)
-TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto = ELL, 1 CSR order, 2 ELL one row per lane, 3 ELL two rows per lane)
+TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto: CSR order, ELL only in the partial loop; 1 never ELL; 2 / 3 ELL always, one / two rows per lane)
 TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel, 1 split-K TN GEMM)
 TUNE_PARTIAL_LOOP = 18      # partial re-orthogonalisation loop (0 device-resident, 1 host-decided, 2 device-resident without the fused scale)
 

@@ -985,6 +985,12 @@ int run_loop_partial_device(lz_handle h, int n) {
   }
   const int* gate = h->d_omi;
   const bool one_rank = h->world <= 1 && !(h->tune[6] && h->comm_kind);
+  if (one_rank && h->kind == 1 && h->tune[18] != 2 && h->tune[17] != 1 && !h->csr.ell_rb && !h->csr.pb &&
+      (h->csr.fixed_k == 5 || h->csr.fixed_k == 7))
+    // first partial run on this matrix: the ELL copy the fused r / beta needs.  (5 and 7 entries per row: its alpha partials
+    // are grouped exactly like k_spmv_fixed's - 512-row blocks, rows t and t + 256 per lane - so the fused and the unfused loop
+    // produce the same bits; 27-point rows keep the scale kernel + the CSR-stream SpMV)
+    LZ_HIP(h, ell_build(h->csr, 0, h->stream));
   const bool fuse_scale = one_rank && h->kind == 1 && ell_usable(h->csr, h->flags) && h->tune[18] != 2;
   // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0; ||r||^2
   LZ_TRY(step_spmv(h, 0));
@@ -1194,10 +1200,15 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   // (tests run it on small matrices).
   pb_free(A.pb);
   // Fixed-K rows (stencils): the ELL-ordered second copy (lz_spmv.hip, k_spmv_ell) - lanes own whole rows, coalesced loads
-  // and gathers, no LDS staging.  tune[17]: 0 auto (built for K in {5, 7, 27}), 1 never (the CSR-order kernel k_spmv_fixed /
-  // the CSR-stream kernel), 2 one row per lane and trip, 3 two adjacent rows per lane.
+  // and gathers, no LDS staging.  Measured against the CSR-order kernel k_spmv_fixed on the headline, C2 and two 3-D grids
+  // (profiles/r04/ab_spmv_ell.json): the same time to within 2 % either way - both sit at the rate this part streams a
+  // 90 % read / 10 % write mix - so the plain SpMV keeps the CSR-order kernel and no second copy is made.  The ELL copy is what
+  // the device-resident partial re-orthogonalisation loop needs for its fused r / beta (a lane owns whole rows): that loop
+  // builds it on first use.  tune[17]: 0 auto (as just said), 1 never (not even for the partial loop), 2 ELL for every SpMV,
+  // one row per lane and trip, 3 ELL with two adjacent rows per lane.
   ell_free(A);
-  if (h->tune[17] != 1 && (fixed_k == 5 || fixed_k == 7 || fixed_k == 27)) LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
+  A.ell_default = h->tune[17] >= 2;  // the plain SpMV takes the ELL copy only on request: measured no faster than the CSR-order kernel
+  if (h->tune[17] >= 2 && (fixed_k == 5 || fixed_k == 7 || fixed_k == 27)) LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
   const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
     const hipError_t pe = pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]);

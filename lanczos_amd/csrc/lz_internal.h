@@ -68,6 +68,7 @@ struct CsrDev {
   double* ell_v = nullptr;
   int ell_rb = 0;             // rows per block of the ELL copy (0: none)
   int ell_variant = 0;        // 0: one row per lane and trip (rows t, t + 256, ...); 1: two adjacent rows per lane (16-byte loads)
+  bool ell_default = false;   // true: every SpMV takes the ELL copy (knob 17 >= 2); false: only the partial loop's fused SpMV does
   const int32_t* host_colidx = nullptr;  // the caller's arrays, valid ONLY inside lz_set_csr / lz_set_csr_transpose (pb_build reads them)
   const double* host_vals = nullptr;
 };

@@ -395,7 +395,7 @@ int launch_spmv_ell(const CsrDev& A, const double* x, double* y, const double* x
 int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
                     hipStream_t s) {
   if (A.rows == 0) return 0;
-  if (ell_usable(A, flags)) return launch_spmv_ell(A, x, y, x_own, part, s);
+  if (A.ell_default && ell_usable(A, flags)) return launch_spmv_ell(A, x, y, x_own, part, s);
   if (flags & LZ_FLAG_SPMV_SCALAR) {
     const int grid = (int)((A.rows + kTPB - 1) / kTPB);
     hipLaunchKernelGGL(k_spmv_scalar, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, x, x_own, y, A.rows, part);

@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+import scipy.sparse
 
 from conftest import golden_names, load_golden
 from lanczos_amd import IrrLanczos, Lanczos, _capi, synthetic

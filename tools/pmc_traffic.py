@@ -6,7 +6,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, cs in acc.items():
