@@ -543,6 +543,9 @@ __global__ __launch_bounds__(512) void k_gemm_tn_sl2(const double* __restrict__ 
   constexpr int NP = NF / 2;                                  // paired column tiles
   constexpr int FR = NF + R4;                                 // B fragments per k-step
   constexpr int PA = NF >= 7 ? 6 : 8;  // 16-byte V fragments in flight per wave (7-8 full tiles: 224+ accumulator registers leave room for 6)
+  // (Four instantiations - 7 full column tiles: n = 105-112 and 117-124 - spill 4-7 registers: loop-invariant pointers, one save /
+  // reload per 32-row tile.  Round 4 tried shallower rings (PA = 6 / 4) for them: the allocator lands on the same 256 + spills
+  // whatever the ring depth, so the cause is not the ring; left as is - a 28-byte scratch access per ~400 MFMAs.)
   extern __shared__ double sS[];  // [KS][FR][64]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int lr = lane & 15, lk = lane >> 4;
