@@ -72,7 +72,8 @@ enum lz_flags {
   LZ_FLAG_REORTH_PARTIAL = 64 /* opt-in: partial re-orthogonalisation (Simon 1984).  The reference sweeps the whole basis
                                  every step; with this flag the sweep (same kernels, same arithmetic) runs only when the
                                  omega-recurrence estimate of the loss of orthogonality exceeds sqrt(eps), on that and the
-                                 next step.  The basis stays semi-orthogonal (<= sqrt(eps)), which keeps T - and so the
+                                 next step.  The recurrence and the decision live on the device (no host synchronisation
+                                 inside lz_run: lz_last_host_syncs).  The basis stays semi-orthogonal (<= sqrt(eps)), which keeps T - and so the
                                  Ritz values - within O(eps ||A||) of the full-sweep run; V itself differs at that level. */
 };
 
@@ -292,8 +293,10 @@ int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
 int lz_last_sweeps(lz_handle h, int* sweeps);
-/* How the last lz_run was executed (choose_loop, lz_api.hip).  0: six launches per step (also: partial re-orthogonalisation,
- * every kernel A/B arm, more than 4e6 rows per rank).  2: the fused-launch path of small problems (a vector of at most eight
+/* How the last lz_run was executed (choose_loop, lz_loops.hip).  0: six launches per step (also: the host-decided partial
+ * re-orthogonalisation loop, every kernel A/B arm, more than 4e6 rows per rank).  7: LZ_FLAG_REORTH_PARTIAL with the decision on
+ * the device (round 4, the default of that flag): the sweep kernels of every step are enqueued and return at once when the
+ * device-side omega-recurrence says no sweep is due; with an ELL-ordered stencil matrix the SpMV forms r / beta itself.  2: the fused-launch path of small problems (a vector of at most eight
  * pass-1 slices, one rank, fused-norm mode): the second-stage reductions and the three-term recurrence ride in the prologue
  * of their consumer kernels - three launches per step, bit-identical results.  3: up to 4e6 rows per rank in fused-norm mode
  * with the full sweep: the three-term recurrence rides in the prologue of the next step's pass 1 (five launches per step,

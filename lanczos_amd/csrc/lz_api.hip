@@ -1,45 +1,17 @@
-// C ABI of liblanczos_hip.so: context, device memory, the Lanczos run loop and
-// the (optional) multi-rank collectives.  See include/lanczos_hip.h for the
-// contract and the reference call sites each entry point replaces.
-#include <dlfcn.h>
-#include <rccl/rccl.h>
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdlib>
-#include <cstdio>
-#include <cstring>
-#include <mutex>
-#include <system_error>
-#include <thread>
-
-#include "lz_internal.h"
+// C ABI of liblanczos_hip.so, part 1: library / device, the handle, options, communicators, the basis and the single-step entry
+// points; plus the helpers every part shares (error reporting, per-launch profiling scope, collectives).  The run loops are
+// in lz_loops.hip, matrix setup in lz_matrix.hip, Ritz vectors / Gram / quality in lz_ritz.hip, the two-sided variant in
+// lz_twosided_api.hip.  See include/lanczos_hip.h for the contract and the reference call sites each entry point replaces.
+#include "lz_context.h"
 
 using namespace lz;
 
-namespace {
+namespace lz {
+namespace api {
 
 std::string g_create_error;
 
-struct EventRec {
-  int cls;
-  hipEvent_t a, b;
-};
 
-struct RcclApi {
-  void* lib = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
 RcclApi g_rccl;
 
 // RCCL must pair with the HIP runtime THIS library is bound to: its streams and device pointers are handed to
@@ -93,121 +65,6 @@ const char* load_rccl() {
   return nullptr;
 }
 
-}  // namespace
-
-struct lz_context {
-  int dev = 0;
-  hipStream_t stream = nullptr;
-  std::string err;
-  std::string name;
-  int flags = 0;
-  int tune[24] = {0};  // A/B knobs, see lz_set_tuning
-
-  // partition
-  int64_t Mg = 0, row0 = 0, rows = 0, ncols_ext = 0;
-  int64_t rows_pad = 0;  // owned rows padded to 32 doubles
-  int64_t ldv = 0;       // stride between basis rows (>= rows_pad, + ghost tail in halo mode)
-
-  // matrix
-  int kind = 0;  // 0 none, 1 csr, 2 dense
-  CsrDev csr;
-  double* d_dense = nullptr;
-  int64_t dense_lda = 0;  // row stride of the device copy (even: 16-byte aligned rows)
-
-  // basis and work vectors
-  int n = 0;
-  double* d_V = nullptr;
-  double* d_r = nullptr;
-  double* d_r2 = nullptr;     // fused small-problem path: r of the three-term recurrence (d_r then holds the SpMV output)
-  double* d_alpha = nullptr;  // n
-  double* d_beta = nullptr;   // n
-  double* d_c = nullptr;      // n + 1
-  double* d_nrm2 = nullptr;   // 2 : [0] = ||r||^2
-  double* d_part = nullptr;   // partials
-  size_t part_cap = 0;
-  double* d_xtmp = nullptr;   // lz_spmv_host scratch
-  QtwPlan qplan;
-
-  // two-sided Lanczos (IrrLanczos.py:77-187): H^T, the three extra bases P / Qb / Pb (Q is d_V), s, gamma, scalars
-  CsrDev csrT;
-  bool has_T = false;      // false: H declared symmetric, H^T x runs on csr
-  bool T_declared = false; // lz_set_csr_transpose was called for the current matrix
-  double* d_B3 = nullptr;  // 3 * n * ldv
-  int bi_n = 0;
-  double* d_s = nullptr;
-  double* d_gamma = nullptr;  // n + 1
-  double* d_bi = nullptr;     // [0..3] raw sums S, [4..6] factors f
-
-  // Ritz vectors: Y = V^T-layout x S.  Resident (d_Y holds all y_rows rows) when it fits beside the basis; otherwise
-  // CHUNKED: d_Y is a y_chunk-row buffer, the padded S stays on the device (d_S) and every consumer (Gram matrix, row
-  // fetch, quality sums) re-forms the rows it needs - a 16-row tile of Y depends only on the same 16 columns of V.
-  double* d_Y = nullptr;
-  int64_t y_rows = 0;
-  int y_n = 0;
-  double* d_S = nullptr;
-  int s_npad = 0;
-  uint64_t* d_rclk = nullptr;  // in-kernel clock record of the last S-stationary back-transform (lz_ritz_info)
-  double* d_gram = nullptr;    // scratch of lz_ritz_gram (K-slice partials + per-chunk slices + G), kept between calls
-  size_t gram_cap = 0;
-  uint64_t* d_gclk = nullptr;  // in-kernel clock record of the last symmetric Gram kernel (lz_gram_info)
-  bool gram_sym_last = false;
-  bool y_chunked = false;
-  int64_t y_chunk = 0;     // rows per chunk (multiple of 16)
-  int64_t y_cap = 0;       // doubles allocated behind d_Y
-
-  // communication
-  int world = 1, rank = 0;
-  int comm_kind = 0;  // 0 none, 1 rccl, 2 host callbacks
-  ncclComm_t comm = nullptr;
-  lz_host_allreduce_fn h_ar = nullptr;
-  lz_host_exchange_fn h_ex = nullptr;
-  lz_host_allgather_fn h_ag = nullptr;
-  void* h_user = nullptr;
-  std::vector<double> hbuf_a, hbuf_b;
-  int xmode = 0;  // 0 none, 1 halo, 2 allgather
-  std::vector<int32_t> peers;
-  std::vector<int64_t> scount, rcount, soff, roff;
-  std::vector<int64_t> sstart;  // >= 0: the peer's send list is the contiguous run x[sstart .. sstart+scount) (stencil faces)
-  bool all_contig = false;
-  // LZ_FLAG_OVERLAP_HALO: the boundary positions of V[j] are updated first, their halo exchange runs on `cstream`
-  // while the compute stream updates the interior; the SpMV waits for `e_halo`.
-  hipStream_t cstream = nullptr;
-  hipEvent_t e_bnd = nullptr, e_halo = nullptr;
-  int halo_inflight_j = -1;
-  std::vector<std::pair<int64_t, int64_t>> bnd_ranges, int_ranges;  // double2 position ranges of a basis row
-  int64_t total_send = 0, total_recv = 0;
-  int32_t* d_send_idx = nullptr;
-  double* d_sendbuf = nullptr;
-  int64_t ag_chunk = 0;
-  double* d_xfull = nullptr;
-
-  // timing
-  std::vector<EventRec> events;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
-  hipEvent_t run_a = nullptr, run_b = nullptr;
-  bool run_timed = false;
-  int last_sweeps = 0;
-  int last_engine = 0;  // which loop ran last (enum Loop)
-  int r_state = 0;      // what d_r holds after the last run: 0 nothing usable, 1 the residual entering step n, 2 y = A v_{n-1} (three-term pending)
-  Xfer* xfer = nullptr;        // staging ring of the large device -> host copies (lz_xfer.hip), created at the first one
-  double* h_pinned = nullptr;  // 8 pinned doubles for the per-step scalar read-back of the host-decided partial-reorth loop (tune[18] == 1)
-  double* d_om = nullptr;      // device-resident partial re-orthogonalisation: omega-recurrence state (omega_state_doubles)
-  int* d_omi = nullptr;        //   ... gate of the coming step, sweep count, per-step sweep log (omega_state_ints)
-  int om_n = 0;
-  int64_t host_syncs = 0;      // host <-> device synchronisations between the first and the last launch of the last lz_run
-  // lz_reserve (may be called from a second host thread while this one prepares the matrix): device buffers for the basis and
-  // the Ritz vectors of the coming run, adopted by basis_alloc / lz_ritz_vectors.  Only these fields are touched by it.
-  std::mutex res_mu;
-  double* res_V = nullptr;
-  size_t res_V_count = 0;
-  double* res_Y = nullptr;
-  size_t res_Y_count = 0;
-  bool prof_iter = true;  // false while lz_run skips an iteration under profile sampling (tune[7])
-  lz_timings acc;
-};
-
-namespace {
-
 int fail(lz_handle h, int code, const std::string& msg) {
   if (h)
     h->err = msg;
@@ -215,26 +72,6 @@ int fail(lz_handle h, int code, const std::string& msg) {
     g_create_error = msg;
   return code;
 }
-
-#define LZ_HIP(h, call)                                                                                   \
-  do {                                                                                                    \
-    hipError_t e_ = (call);                                                                               \
-    if (e_ != hipSuccess)                                                                                 \
-      return fail(h, e_ == hipErrorOutOfMemory ? LZ_ERR_NOMEM : LZ_ERR_HIP,                               \
-                  std::string(#call) + ": " + hipGetErrorString(e_));                                     \
-  } while (0)
-
-#define LZ_NCCL(h, call)                                                                                  \
-  do {                                                                                                    \
-    ncclResult_t r_ = (call);                                                                             \
-    if (r_ != ncclSuccess) return fail(h, LZ_ERR_COMM, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
-  } while (0)
-
-#define LZ_TRY(expr)          \
-  do {                        \
-    int rc_ = (expr);         \
-    if (rc_ != LZ_OK) return rc_; \
-  } while (0)
 
 // Row stride of the basis.  Every streaming kernel has several rows in flight at the SAME column offset, so a stride
 // that is a multiple of a large power of two (M = 2^20, 160^3 = 2^15 * 125, ...) lands them on the same HBM channels.
@@ -251,24 +88,6 @@ int check_launch(lz_handle h, const char* what) {
   return LZ_OK;
 }
 
-template <class T>
-int dev_free(lz_handle h, T*& p) {
-  if (p) {
-    LZ_HIP(h, hipFree(p));
-    p = nullptr;
-  }
-  return LZ_OK;
-}
-
-template <class T>
-int dev_alloc(lz_handle h, T*& p, size_t count) {
-  LZ_TRY(dev_free(h, p));
-  void* q = nullptr;
-  LZ_HIP(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
-  p = static_cast<T*>(q);
-  return LZ_OK;
-}
-
 // host -> device on the handle's stream.  The runtime's own path: a resident pageable source is pinned in place and read at
 // the link's rate (57 GB/s measured); a staged pipeline like lz_xfer.hip's was built and measured slower (see lz_xfer.hip).
 int upload(lz_handle h, void* dst, const void* src, size_t bytes) {
@@ -280,7 +99,7 @@ int upload2d(lz_handle h, void* dst, size_t dpitch, const void* src, size_t spit
   return LZ_OK;
 }
 
-
+namespace {
 // ---- roctx ranges (opt-in: LZ_ROCTX=1) --------------------------------------
 // Host-side phase markers for `rocprofv3 --marker-trace`: one range per kernel class around its launches.  The marker
 // library is dlopen'ed on first use, like RCCL; nothing is linked and nothing happens without the environment variable.
@@ -306,47 +125,41 @@ bool roctx_on() {
   }
   return g_roctx.push && g_roctx.pop;
 }
+}  // namespace
 
 // ---- profiling events ---------------------------------------------------
-struct Scope {
-  lz_handle h;
-  int cls;
-  hipEvent_t a = nullptr, b = nullptr;
-  bool on;
-  bool marked = false;
-  Scope(lz_handle h_, int cls_, double bytes, double flops) : h(h_), cls(cls_) {
-    if (roctx_on()) {
-      g_roctx.push(kClassNames[cls]);
-      marked = true;
-    }
-    h->acc.bytes[cls] += bytes;
-    h->acc.flops[cls] += flops;
-    h->acc.launches[cls] += 1;
-    on = (h->flags & LZ_FLAG_PROFILE) != 0 && h->prof_iter;
-    if (on) {
-      h->acc.timed_bytes[cls] += bytes;
-      h->acc.timed_launches[cls] += 1;
-      if (!h->free_events.empty()) {
-        a = h->free_events.back().first;
-        b = h->free_events.back().second;
-        h->free_events.pop_back();
-      } else {
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
-          on = false;
-          return;
-        }
+Scope::Scope(lz_handle h_, int cls_, double bytes, double flops) : h(h_), cls(cls_) {
+  if (roctx_on()) {
+    g_roctx.push(kClassNames[cls]);
+    marked = true;
+  }
+  h->acc.bytes[cls] += bytes;
+  h->acc.flops[cls] += flops;
+  h->acc.launches[cls] += 1;
+  on = (h->flags & LZ_FLAG_PROFILE) != 0 && h->prof_iter;
+  if (on) {
+    h->acc.timed_bytes[cls] += bytes;
+    h->acc.timed_launches[cls] += 1;
+    if (!h->free_events.empty()) {
+      a = h->free_events.back().first;
+      b = h->free_events.back().second;
+      h->free_events.pop_back();
+    } else {
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        on = false;
+        return;
       }
-      hipEventRecord(a, h->stream);
     }
+    hipEventRecord(a, h->stream);
   }
-  ~Scope() {
-    if (marked) g_roctx.pop();
-    if (on) {
-      hipEventRecord(b, h->stream);
-      h->events.push_back({cls, a, b});
-    }
+}
+Scope::~Scope() {
+  if (marked) g_roctx.pop();
+  if (on) {
+    hipEventRecord(b, h->stream);
+    h->events.push_back({cls, a, b});
   }
-};
+}
 
 int drain_events(lz_handle h) {
   if (h->events.empty() && !h->run_timed) return LZ_OK;
@@ -447,858 +260,16 @@ int comm_exchange_x(lz_handle h, int j, const double** x_out) {
   return fail(h, LZ_ERR_STATE, "world > 1 but neither lz_set_halo nor lz_set_allgather was called");
 }
 
-// ---- the individual steps (device-resident scalars, no host sync) --------
-int ensure_part(lz_handle h, size_t need) {
-  if (need <= h->part_cap) return LZ_OK;
-  LZ_TRY(dev_alloc(h, h->d_part, need));
-  h->part_cap = need;
-  return LZ_OK;
-}
-
-double spmv_bytes(lz_handle h) {
-  if (h->kind == 1) return 12.0 * h->csr.nnz + 4.0 * (h->rows + 1) + 16.0 * h->rows;
-  return 8.0 * (double)h->rows * (double)h->Mg + 8.0 * (double)h->Mg + 8.0 * h->rows;  // A block, x once, y
-}
-double spmv_flops(lz_handle h) { return h->kind == 1 ? 2.0 * h->csr.nnz : 2.0 * (double)h->rows * (double)h->Mg; }
-
-// r = A V[j]; alpha_dst[0] = V[j] . r, summed over ranks unless reduce == false (one-reduce mode: the partial sum rides
-// in the next all-reduce)
-int step_spmv(lz_handle h, int j, double* alpha_dst = nullptr, bool reduce = true, int* np_out = nullptr) {
-  if (!alpha_dst) alpha_dst = h->d_alpha + j;
-  const double* x = nullptr;
-  if (h->halo_inflight_j == j) {  // exchange already issued on the comm stream behind the boundary update
-    LZ_HIP(h, hipStreamWaitEvent(h->stream, h->e_halo, 0));
-    x = h->d_V + (int64_t)j * h->ldv;
-    h->halo_inflight_j = -1;
-  } else {
-    LZ_TRY(comm_exchange_x(h, j, &x));
-  }
-  const double* xown = h->d_V + (int64_t)j * h->ldv;
-  int np = 0;
-  {
-    Scope sc(h, LZ_K_SPMV, spmv_bytes(h), spmv_flops(h));
-    if (h->kind == 1)
-      np = launch_spmv_csr(h->csr, x, h->d_r, xown, h->d_part, h->flags, h->stream);
-    else
-      np = launch_gemv_dense(h->d_dense, h->rows, h->ncols_ext, h->dense_lda, x, xown, h->d_r, h->d_part, h->stream);
-    LZ_TRY(check_launch(h, "spmv"));
-  }
-  if (np_out) {  // fused small-problem mode: the consumer kernel adds the block partials itself
-    *np_out = np;
-    return LZ_OK;
-  }
-  {
-    Scope sc(h, LZ_K_FINAL, 0, 0);
-    launch_final_sum(h->d_part, np, alpha_dst, h->stream);
-    LZ_TRY(check_launch(h, "final_sum(alpha)"));
-  }
-  return reduce ? comm_allreduce(h, alpha_dst, 1) : LZ_OK;
-}
-
-// V[j] = r / sqrt(nrm2) (if scale), then c = V[0:nrows] . V[j]; V[j] = 2 V[j] - c^T V[0:nrows]
-int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in_run_loop = false) {
-  const double M = (double)h->rows;
-  // fused-norm mode (the Python layers default to it): the reduced sums are [V_i . r (i < j), r . r] - one all-reduce at N > 1 -; beta and the scaling by
-  // 1/beta are applied afterwards.  Only valid for the in-loop call shape (row j is the newest row).
-  const bool fused = scale && (h->flags & LZ_FLAG_FUSED_NORM) && !(h->flags & LZ_FLAG_REORTH_PARTIAL) && nrows == j + 1;
-  h->qplan.variant = h->tune[1];  // A/B knob may change between launches on one handle (same allocation for every arm)
-  {
-    Scope sc(h, LZ_K_QTW, 8.0 * (nrows - 1) * M + (scale && !fused ? 16.0 : 8.0) * M, 2.0 * nrows * M);
-    LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, nrows, j, scale ? h->d_r : nullptr, h->d_nrm2, h->d_beta + beta_idx, h->qplan,
-                         h->d_part, fused ? 2 : (scale ? 1 : 0), h->stream));
-    LZ_TRY(check_launch(h, "qtw"));
-  }
-  {
-    Scope sc(h, LZ_K_FINAL, 0, 0);
-    launch_final_rows(h->d_part, nrows, h->qplan.P, h->d_c, h->stream, h->qplan.family == 2);
-    LZ_TRY(check_launch(h, "final_rows"));
-  }
-  LZ_TRY(comm_allreduce(h, h->d_c, nrows));
-  const bool overlap = in_run_loop && (h->flags & LZ_FLAG_OVERLAP_HALO) && h->xmode == 1 && h->all_contig && h->comm_kind == 1 &&
-                       !h->peers.empty() && (h->world > 1 || h->tune[6]);
-  // inside lz_run the default (slice-owner) update kernel turns the reduced sums into beta and the coefficients itself
-  const bool raw_c = fused && in_run_loop && (h->tune[8] == 0 || h->tune[8] >= 3);
-  if (fused && !raw_c) {
-    Scope sc(h, LZ_K_FINAL, 0, 0);
-    launch_fused_prepare(h->d_c, j, h->d_beta + beta_idx, h->stream);
-    LZ_TRY(check_launch(h, "fused_prepare"));
-  }
-  if (!overlap) {
-    Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + 16.0 * M, 2.0 * nrows * M);
-    launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream, 0, -1,
-                  raw_c ? 1 : 0);
-    LZ_TRY(check_launch(h, "update"));
-    return LZ_OK;
-  }
-  // 1. boundary positions (the faces the neighbours need), 2. their exchange on the comm stream, 3. interior
-  double* vj = h->d_V + (int64_t)j * h->ldv;
-  {
-    Scope sc(h, LZ_K_UPDATE, 8.0 * (nrows - 1) * M + 16.0 * M, 2.0 * nrows * M);
-    // both faces leave in ONE launch of the small-range kernel (the face kernel is a latency chain over the rows)
-    const bool small = h->tune[8] == 0;
-    for (size_t q = 0; q < h->bnd_ranges.size(); q += 2) {
-      const auto& ra = h->bnd_ranges[q];
-      const bool pair = small && q + 1 < h->bnd_ranges.size() && ra.second - ra.first <= 16384 &&
-                        h->bnd_ranges[q + 1].second - h->bnd_ranges[q + 1].first <= 16384;
-      launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream,
-                    ra.first, ra.second, raw_c ? 1 : 0, pair ? h->bnd_ranges[q + 1].first : 0, pair ? h->bnd_ranges[q + 1].second : 0);
-      if (!pair && q + 1 < h->bnd_ranges.size())
-        launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream,
-                      h->bnd_ranges[q + 1].first, h->bnd_ranges[q + 1].second, raw_c ? 1 : 0);
-    }
-    LZ_TRY(check_launch(h, "update(boundary)"));
-    LZ_HIP(h, hipEventRecord(h->e_bnd, h->stream));
-    for (auto& rg : h->int_ranges)
-      launch_update(h->d_V, h->ldv, h->rows_pad, nrows, j, h->d_c, fused ? h->d_r : nullptr, h->d_beta + beta_idx, h->tune[8], h->stream,
-                    rg.first, rg.second, raw_c ? 1 : 0);
-    LZ_TRY(check_launch(h, "update(interior)"));
-  }
-  LZ_HIP(h, hipStreamWaitEvent(h->cstream, h->e_bnd, 0));
-  h->acc.bytes[LZ_K_COMM] += 8.0 * (h->total_send + h->total_recv);
-  h->acc.launches[LZ_K_COMM] += 1;
-  LZ_NCCL(h, g_rccl.GroupStart());
-  for (size_t p = 0; p < h->peers.size(); ++p) {
-    if (h->scount[p] > 0)
-      LZ_NCCL(h, g_rccl.Send(vj + h->sstart[p], (size_t)h->scount[p], ncclDouble, h->peers[p], h->comm, h->cstream));
-    if (h->rcount[p] > 0)
-      LZ_NCCL(h, g_rccl.Recv(vj + h->rows_pad + h->roff[p], (size_t)h->rcount[p], ncclDouble, h->peers[p], h->comm, h->cstream));
-  }
-  LZ_NCCL(h, g_rccl.GroupEnd());
-  LZ_HIP(h, hipEventRecord(h->e_halo, h->cstream));
-  h->halo_inflight_j = j;
-  return LZ_OK;
-}
-
-// r = r - alpha V[j] - beta V[jm1]; d_nrm2[0] = sum over ranks of ||r||^2
-int step_three_term(lz_handle h, int j, int jm1, const double* d_alpha, const double* d_beta, bool need_norm = true) {
-  const double M = (double)h->rows;
-  int np = 0;
-  {
-    Scope sc(h, LZ_K_THREE, (jm1 >= 0 ? 32.0 : 24.0) * M, (jm1 >= 0 ? 6.0 : 4.0) * M);
-    np = launch_three_term(h->d_r, h->d_V + (int64_t)j * h->ldv, jm1 >= 0 ? h->d_V + (int64_t)jm1 * h->ldv : nullptr, d_alpha,
-                           d_beta, h->rows_pad, h->d_part, h->stream);
-    LZ_TRY(check_launch(h, "three_term"));
-  }
-  if (!need_norm) return LZ_OK;  // fused-norm mode: ||r||^2 travels with the next Q^T r all-reduce
-  {
-    Scope sc(h, LZ_K_FINAL, 0, 0);
-    launch_final_sum(h->d_part, np, h->d_nrm2, h->stream);
-    LZ_TRY(check_launch(h, "final_sum(nrm2)"));
-  }
-  return comm_allreduce(h, h->d_nrm2, 1);
-}
-
-// ---- one-reduce mode (LZ_FLAG_ONE_REDUCE): the whole Krylov loop with ONE all-reduce per iteration ---------------------
-// State entering step j: r holds the two-term residual r'' = A u - beta v_{j-2} of the newest vector u = v_{j-1} (at j = 0:
-// r'' = A v0, u = v0 in basis row 0), and the local partial of alpha = u.(A u) sits in the reduce buffer.  Step j:
-//   pass 1 dots rows 0..j-1 against BOTH columns (r'', u) + the three self terms   -> one all-reduce with alpha
-//   prepare: alpha, c_i = V_i.r'' - alpha V_i.u, |r|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u
-//   r = r'' - alpha u;  update: beta = |r|, V[j] = 2 r/beta - sum c_i/beta V_i - ...   (unchanged kernels from here)
-//   exchange V[j]; r = A V[j] (alpha partial into the buffer); r'' = r - beta V[j-1]
-inline int onered_ldp(int m) { return qtw_ldp(m + 2); }
-inline int onered_slot(int m) { return onered_ldp(m) + m + 2; }  // where alpha lives in the reduce buffer at a step with m rows
-
-int run_loop_onereduce(lz_handle h, int n) {
-  const double M = (double)h->rows;
-  LZ_TRY(step_spmv(h, 0, h->d_c + onered_slot(0), false));  // warm-up: r'' = A v0 (Lanczos.py:108), alpha0 partial
-  for (int j = 0; j < n; ++j) {
-    const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-    h->prof_iter = (j % pstride) == pstride / 2;
-    const int bidx = (j + n - 2) % (n - 1);
-    const int m = j, urow = j > 0 ? j - 1 : 0, ldp = onered_ldp(m);
-    double* u = h->d_V + (int64_t)urow * h->ldv;
-    h->qplan.variant = 0;
-    {
-      Scope sc(h, LZ_K_QTW, 8.0 * m * M + 16.0 * M, 4.0 * (m + 1) * M);
-      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, m, urow, h->d_r, nullptr, nullptr, h->qplan, h->d_part, 3, h->stream));
-      LZ_TRY(check_launch(h, "qtw(two columns)"));
-    }
-    {
-      Scope sc(h, LZ_K_FINAL, 0, 0);
-      launch_final_rows_t(h->d_part, h->qplan.G, 2 * ldp, ldp + m + 2, h->d_c, h->stream);
-      LZ_TRY(check_launch(h, "final_rows"));
-    }
-    LZ_TRY(comm_allreduce(h, h->d_c, onered_slot(m) + 1));  // THE collective of this iteration
-    {
-      Scope sc(h, LZ_K_FINAL, 0, 0);
-      launch_onereduce_prepare(h->d_c, m, ldp, h->d_alpha + urow, h->d_nrm2 + 1, h->stream);  // j = 0: alpha[0] of the warm-up, rewritten below
-      LZ_TRY(check_launch(h, "onereduce_prepare"));
-    }
-    {
-      Scope sc(h, LZ_K_THREE, 24.0 * M, 2.0 * M);
-      launch_three_term(h->d_r, u, nullptr, h->d_alpha + urow, nullptr, h->rows_pad, h->d_part, h->stream);  // r = r'' - alpha u
-      LZ_TRY(check_launch(h, "three_term(alpha)"));
-    }
-    {
-      Scope sc(h, LZ_K_UPDATE, 8.0 * j * M + 16.0 * M, 2.0 * (j + 1) * M);
-      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_c, h->d_r, h->d_beta + bidx, h->tune[8] == 0 || h->tune[8] >= 3 ? h->tune[8] : 0,
-                    h->stream, 0, -1, 1);
-      LZ_TRY(check_launch(h, "update"));
-    }
-    const bool last = j == n - 1;
-    LZ_TRY(step_spmv(h, j, last ? h->d_alpha + j : h->d_c + onered_slot(j + 1), last));  // the last alpha has no pass to ride on
-    if (!last && j > 0) {
-      Scope sc(h, LZ_K_THREE, 24.0 * M, 2.0 * M);
-      launch_three_term(h->d_r, h->d_V + (int64_t)(j - 1) * h->ldv, nullptr, h->d_beta + bidx, nullptr, h->rows_pad, h->d_part, h->stream);
-      LZ_TRY(check_launch(h, "three_term(beta)"));  // r'' = A V[j] - beta V[j-1]; at j = 0 the reference's V[-1] is the zero row
-    }
-  }
-  return LZ_OK;
-}
-
-// ---- small problems: three launches per step instead of six ---------------------------------------------------------------
-// When a vector is a handful of pass-1 slices, every kernel of a step does microseconds of work and the step costs what
-// its six dependent launches cost.  Here the two second-stage reductions and the three-term recurrence ride in the
-// prologue of their consumer: [pass 1: alpha from the SpMV's block partials, r = (y - alpha v) - beta v', stage, dots]
-// [pass 2: coefficients from pass 1's block partials, update] [SpMV].  Same arithmetic, same summation trees: bit-identical
-// to the six-launch path (tests/test_gpu_small.py).
-inline size_t fused_coff(lz_handle h) {  // where pass 1's partials start in d_part (behind the SpMV's alpha partials)
-  const size_t npmax = std::max<size_t>((size_t)h->rows / 4 + 2, (size_t)std::max(h->csr.n_rowblk, 1)) + 64;
-  return (npmax + 63) / 64 * 64;
-}
-
-int run_loop_fused_small(lz_handle h, int n) {
-  const double M = (double)h->rows;
-  const size_t coff = fused_coff(h);
-  int np = 0;
-  LZ_TRY(step_spmv(h, 0, nullptr, false, &np));  // warm-up: y = A v0 (Lanczos.py:108)
-  for (int j = 0; j < n; ++j) {
-    const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-    h->prof_iter = (j % pstride) == pstride / 2;
-    const int bidx = (j + n - 2) % (n - 1);
-    QtwFuse fz;
-    fz.apart = h->d_part;
-    fz.np = np;
-    fz.jprev = j > 0 ? j - 1 : 0;   // j == 0: the warm-up's alpha0 and r = A v0 - alpha0 v0 (Lanczos.py:109-110)
-    fz.jprev2 = j >= 2 ? j - 2 : -1;  // the reference's V[-1] term at its step 0 is the zero row
-    fz.beta_prev = h->d_beta + (j >= 2 ? j - 2 : 0);
-    fz.alpha_out = h->d_alpha + fz.jprev;
-    fz.r_out = h->d_r2;
-    h->qplan.variant = 0;
-    {
-      Scope sc(h, LZ_K_QTW, 8.0 * j * M + 40.0 * M, 2.0 * (j + 1) * M + 4.0 * M);
-      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_r, nullptr, nullptr, h->qplan, h->d_part + coff, 4, h->stream, &fz));
-      LZ_TRY(check_launch(h, "qtw(fused three-term)"));
-    }
-    {
-      Scope sc(h, LZ_K_UPDATE, 8.0 * j * M + 16.0 * M, 2.0 * (j + 1) * M);
-      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_part + coff, h->d_r2, h->d_beta + bidx, 0, h->stream, 0, -1, 2, 0, 0, h->qplan.G,
-                    qtw_ldp(j + 1));
-      LZ_TRY(check_launch(h, "update(fused reduction)"));
-    }
-    LZ_TRY(step_spmv(h, j, nullptr, false, &np));
-  }
-  {
-    Scope sc(h, LZ_K_FINAL, 0, 0);
-    launch_final_sum(h->d_part, np, h->d_alpha + (n - 1), h->stream);  // the last alpha has no consumer kernel to ride in
-    LZ_TRY(check_launch(h, "final_sum(alpha)"));
-  }
-  return LZ_OK;
-}
-
-
-// The default loop of problems that are neither small nor huge (any number of ranks, fused-norm mode, full
-// re-orthogonalisation, at most kThreeTermFusedMaxRows rows per rank - measured: C2 (10^6 rows) +3.6 %, 6 400 .. 350 000 rows
-// +4 .. 11 %, the headline's 10^7 rows +0.4 %: there the separate three-term kernel streams at a higher rate than the
-// prologue does, and the six-launch loop stays):
-// the three-term recurrence r = (A v_j - alpha_j v_j) - beta_{j-1} v_{j-1} rides in the prologue of the NEXT step's pass 1
-// (k_qtw_mfma4<4>, alpha read back from its slot after the all-reduce) instead of being a pass of its own - five launches
-// per step, one read-modify-write of r less, bit-identical coefficients and basis (tests/test_gpu_small.py).
-// lz_set_tuning(h, 15, 1) selects the six-launch loop.
-constexpr int64_t kThreeTermFusedMaxRows = 4'000'000;
-int run_loop_three_term_fused(lz_handle h, int n) {
-  const double M = (double)h->rows;
-  LZ_TRY(step_spmv(h, 0));  // warm-up: y = A v0, alpha_0 (Lanczos.py:108-109)
-  for (int j = 0; j < n; ++j) {
-    const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-    h->prof_iter = (j % pstride) == pstride / 2;
-    const int bidx = (j + n - 2) % (n - 1);
-    QtwFuse fz;
-    fz.apart = nullptr;
-    fz.np = 0;
-    fz.jprev = j > 0 ? j - 1 : 0;     // j == 0: the warm-up's r = A v0 - alpha0 v0 (Lanczos.py:110)
-    fz.jprev2 = j >= 2 ? j - 2 : -1;  // the reference's V[-1] term at its step 0 is the zero row
-    fz.beta_prev = h->d_beta + (j >= 2 ? j - 2 : 0);
-    fz.alpha_out = h->d_alpha + fz.jprev;
-    fz.r_out = h->d_r2;
-    h->qplan.variant = 0;
-    {
-      Scope sc(h, LZ_K_QTW, 8.0 * j * M + 40.0 * M, 2.0 * (j + 1) * M + 4.0 * M);
-      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_r, nullptr, nullptr, h->qplan, h->d_part, 4, h->stream, &fz));
-      LZ_TRY(check_launch(h, "qtw(three-term in the prologue)"));
-    }
-    {
-      Scope sc(h, LZ_K_FINAL, 0, 0);
-      launch_final_rows(h->d_part, j + 1, h->qplan.P, h->d_c, h->stream, h->qplan.family == 2);
-      LZ_TRY(check_launch(h, "final_rows"));
-    }
-    LZ_TRY(comm_allreduce(h, h->d_c, j + 1));
-    {
-      Scope sc(h, LZ_K_UPDATE, 8.0 * j * M + 16.0 * M, 2.0 * (j + 1) * M);
-      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_c, h->d_r2, h->d_beta + bidx, 0, h->stream, 0, -1, 1);
-      LZ_TRY(check_launch(h, "update"));
-    }
-    LZ_TRY(step_spmv(h, j));
-  }
-  return LZ_OK;
-}
-
-}  // namespace
-extern "C" {
-static int basis_alloc(lz_handle h, int n, int zero_rows);
-}
-
-namespace {
-
-#ifdef LZ_KBENCH
-constexpr int kSmallStepMaxN = 64;  // per-step kernels: every block redoes both passes over all n rows
-// ---- kernel-bench build only: the retired small-problem engines (lz_small.hip) ------------------------------------------
-// The whole run as ONE cooperative kernel (tune[15] == 2; 3 = on a plain grid), or one launch per step (tune[15] == 5,
-// n <= 64).  Both are bit-identical to the multi-kernel path and both measured no faster than the three launches per step
-// that are the default for small problems (a device-coherent round trip costs ~2 us on MI355X, about
-// what a kernel boundary costs), so they left the product library in round 3; tests/test_gpu_small.py keeps their
-// bit-identity checks against liblanczos_kbench.so.
-bool small_args(lz_handle h, int n, SmallArgs& sa) {
-  memset(&sa, 0, sizeof sa);
-  sa.kind = h->kind;
-  if (h->kind == 2) {
-    sa.dense = h->d_dense;
-    sa.lda = h->dense_lda;
-    sa.nparts = (int)((h->rows + 3) / 4);
-  } else {
-    const CsrDev& A = h->csr;
-    const bool fixed = !(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7);
-    // (one lane walks one row in the engine: rows of more than 32 entries would turn into a chain of dependent loads)
-    if (A.pb || A.max_row_nnz > 32 || (fixed && A.fixed_rb != 512)) return false;
-    sa.rowptr = A.rowptr;
-    sa.colidx = A.colidx;
-    sa.vals = A.vals;
-    sa.rowblk = fixed ? nullptr : A.rowblk;
-    sa.nparts = fixed ? (int)((h->rows + 511) / 512) : A.n_rowblk;
-  }
-  if (sa.nparts > 1024 || h->part_cap < (size_t)(2048 + h->rows_pad)) return false;
-  sa.rows = (int)h->rows;
-  sa.rows_pad = (int)h->rows_pad;
-  sa.n = n;
-  sa.ldv = h->ldv;
-  sa.V = h->d_V;
-  sa.y = h->d_r;
-  sa.drow = h->d_part;
-  sa.x0 = h->d_part + 2048;  // d_part holds >= 4096 doubles; rows_pad <= 1280
-  sa.pc = h->d_c;
-  sa.alpha = h->d_alpha;
-  sa.beta = h->d_beta;
-  sa.bar = reinterpret_cast<unsigned*>(h->d_nrm2);  // 16 bytes, zeroed by basis_alloc
-  sa.xcc = reinterpret_cast<unsigned*>(h->d_part + 3400);
-  return true;
-}
-bool small_engine_applies(lz_handle h) {
-  SmallArgs sa;
-  return small_args(h, 2, sa);
-}
-
-int run_small_engine(lz_handle h, int n, const double* v0_local, bool steps, bool* ran) {
-  SmallArgs sa;
-  *ran = small_args(h, n, sa);
-  if (!*ran) return LZ_OK;
-  LZ_HIP(h, hipMemcpyAsync(h->d_part + 2048, h->d_V, (size_t)h->rows_pad * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  if (steps) {
-    // one launch per step: first SpMV, steps j = -1 .. n-2, the last alpha
-    const int nb = h->kind == 2 ? (int)std::min<int64_t>(256, (h->rows + 3) / 4) : (int)std::max<int64_t>(1, (h->rows + kTPB - 1) / kTPB);
-    const double Mr = (double)h->rows;
-    LZ_HIP(h, launch_small_step(sa, 0, -1, nb, h->stream));
-    for (int j = -1; j <= n - 2; ++j) {
-      const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-      h->prof_iter = ((j + 1) % pstride) == pstride / 2;
-      Scope sc(h, LZ_K_UPDATE, spmv_bytes(h) + 16.0 * (j + 2) * Mr + 40.0 * Mr, spmv_flops(h) + 4.0 * (j + 2) * Mr);
-      LZ_HIP(h, launch_small_step(sa, 1, j, nb, h->stream));
-    }
-    h->prof_iter = true;
-    LZ_HIP(h, launch_small_step(sa, 2, n - 1, 1, h->stream));
-    return check_launch(h, "small_step");
-  }
-  h->acc.launches[LZ_K_FINAL] += 1;
-  // tune[15] == 2: the participating blocks share one XCD (every eighth block of the grid); 3: plain grid over all XCDs
-  LZ_HIP(h, launch_small_run(sa, small_grid(sa.rows_pad), h->tune[15] == 2, h->stream));
-  LZ_TRY(check_launch(h, "small_run"));
-  unsigned status = 0;
-  LZ_HIP(h, hipMemcpyAsync(&status, sa.bar + 2, sizeof status, hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  if (status != 0) {
-    // the engine refused (its blocks were not dealt to one XCD) or a barrier timed out: the caller repeats the run
-    if (getenv("LZ_DEBUG_TIMING")) fprintf(stderr, "[lz_run] small-problem engine gave up (status %u): multi-kernel path\n", status);
-    *ran = false;
-    LZ_TRY(basis_alloc(h, n, 1));
-    LZ_HIP(h, hipMemcpyAsync(h->d_V, v0_local, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
-  }
-  return LZ_OK;
-}
-#endif  // LZ_KBENCH
-
-// ---- which loop structure runs the Krylov iteration --------------------------------------------------------------------
-// (the values are what lz_last_engine reports)
-enum Loop {
-  LOOP_SIX = 0,               // six launches per step; also the partial re-orthogonalisation mode and every A/B arm of a kernel
-  LOOP_SMALL_ENGINE = 1,      // kernel-bench build only: the whole run as one cooperative kernel (lz_small.hip)
-  LOOP_FUSED_SMALL = 2,       // <= 8 pass-1 slices, one rank: three launches per step (run_loop_fused_small)
-  LOOP_THREE_TERM_FUSED = 3,  // up to 4e6 rows per rank: five launches per step (run_loop_three_term_fused)
-  LOOP_SMALL_STEP = 4,        // kernel-bench build only: one launch per step
-  LOOP_ONE_REDUCE_REPEATED = 5,  // a one-reduce run whose cancellation guard fired: repeated on the default loop
-  LOOP_ONE_REDUCE = 6,        // LZ_FLAG_ONE_REDUCE: one all-reduce per iteration
-  LOOP_PARTIAL_DEVICE = 7     // LZ_FLAG_REORTH_PARTIAL, default: the omega-recurrence and the sweep decision live on the device
-};
-
-Loop choose_loop(lz_handle h, int n) {
-  const int f = h->flags;
-  const bool default_kernels = h->qplan.family == 2 && !(f & (LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->tune[1] == 0 && h->tune[8] == 0;
-  const bool full_fused = (f & LZ_FLAG_FUSED_NORM) && !(f & LZ_FLAG_REORTH_PARTIAL);
-  if ((f & LZ_FLAG_ONE_REDUCE) && !(f & LZ_FLAG_REORTH_PARTIAL) && h->qplan.family == 2) return LOOP_ONE_REDUCE;
-  // partial re-orthogonalisation: device-resident decisions with the default kernels (tune[18] == 1: the host-decided loop,
-  // two scalars read back per step - kept for the bit-identity test and as an A/B arm)
-  if ((f & LZ_FLAG_REORTH_PARTIAL) && default_kernels && h->tune[18] != 1 && !(f & LZ_FLAG_OVERLAP_HALO)) return LOOP_PARTIAL_DEVICE;
-  const bool one_rank = h->world == 1 && h->comm_kind == 0;
-#ifdef LZ_KBENCH
-  const bool want_steps = h->tune[15] == 5 && n <= kSmallStepMaxN;
-  if ((h->tune[15] == 2 || h->tune[15] == 3 || want_steps) && one_rank && full_fused && default_kernels && !(f & LZ_FLAG_SPMV_SCALAR) &&
-      h->qplan.L == 512 && h->rows_pad <= kSmallMaxPadRows && n <= kSmallMaxPadRows && small_engine_applies(h))
-    return want_steps ? LOOP_SMALL_STEP : LOOP_SMALL_ENGINE;
-  const bool knob_auto = h->tune[15] == 0 || h->tune[15] == 5;
-#else
-  const bool knob_auto = h->tune[15] == 0;
-#endif
-  if (!knob_auto || !full_fused || !default_kernels) return LOOP_SIX;
-  if (one_rank && h->qplan.G <= 8 && n <= 4096 && h->part_cap >= fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G) return LOOP_FUSED_SMALL;
-  if (!(f & LZ_FLAG_OVERLAP_HALO) && h->rows_pad <= kThreeTermFusedMaxRows) return LOOP_THREE_TERM_FUSED;
-  return LOOP_SIX;
-}
-
-// ---- the plain loop: six launches per step (pass 1, second-stage sums, pass 2, SpMV, alpha sum, three-term), with the
-// opt-in partial re-orthogonalisation (Simon's omega-recurrence on the host) --------------------------------------------
-int run_loop_six(lz_handle h, int n, int* sweeps_out, int j0 = 0) {
-  const bool fused = (h->flags & LZ_FLAG_FUSED_NORM) != 0 && !(h->flags & LZ_FLAG_REORTH_PARTIAL);
-  if (j0 == 0) {
-    // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0
-    LZ_TRY(step_spmv(h, 0));
-    LZ_TRY(step_three_term(h, 0, -1, h->d_alpha, nullptr, !fused));
-  } else if (!fused) {
-    // resumed run (lz_run_resume): steps 0 .. j0-1 are in the basis, r is the residual entering step j0; the scale-then-dot order
-    // wants ||r||^2 in d_nrm2: r = r - 0 * V[0] leaves r unchanged bit for bit and refreshes it
-    LZ_HIP(h, hipMemsetAsync(h->d_c + n, 0, sizeof(double), h->stream));
-    LZ_TRY(step_three_term(h, 0, -1, h->d_c + n, nullptr, true));
-  }
-  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-  const bool partial = (h->flags & LZ_FLAG_REORTH_PARTIAL) != 0;
-  // Partial re-orthogonalisation (opt-in): Simon's omega-recurrence on the host, fed with alpha_j and beta_{j+1}
-  // (two doubles copied back per step).  omega_{j,k} estimates v_j . v_k; a sweep is due when it exceeds sqrt(eps).
-  const double eps = 2.220446049250313e-16, thresh = 1.4901161193847656e-08;
-  std::vector<double> w_prev, w_cur, w_new, ha, hb;  // omega_{j-2,:}, omega_{j-1,:}, omega_{j,:}; alpha_k; beta_k (norm forming V[k])
-  if (partial) {
-    if (!h->h_pinned) LZ_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), 8 * sizeof(double), hipHostMallocDefault));
-    w_prev.assign((size_t)n + 1, 0.0);
-    w_cur.assign((size_t)n + 1, 0.0);
-    w_cur[0] = 1.0;  // omega_{0,0} = v_0 . v_0 (until round 4 this row was all zero, which made a spurious sweep due at j = 2)
-    w_new.assign((size_t)n + 1, 0.0);
-    ha.assign((size_t)n + 1, 0.0);
-    hb.assign((size_t)n + 1, 0.0);
-    double nrm2 = 0.0;
-    LZ_HIP(h, hipMemcpyAsync(&nrm2, h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    LZ_HIP(h, hipStreamSynchronize(h->stream));
-    h->host_syncs += 1;
-    hb[0] = std::sqrt(nrm2);
-  }
-  bool force_next = false;
-  double normA = 0.0;
-  int sweeps = 0;
-  for (int j = j0; j < n; ++j) {
-    h->prof_iter = (j % pstride) == pstride / 2;  // centred sample: same mean j as the full run
-    const int bidx = (j + n - 2) % (n - 1);  // beta[j-1] with Python's negative index at j = 0
-    bool sweep = true;
-    if (partial) {
-      bool due = false;
-      if (j >= 1) {
-        // beta_j omega_{j,k} = beta_{k+1} omega_{j-1,k+1} + (alpha_k - alpha_{j-1}) omega_{j-1,k} + beta_k omega_{j-1,k-1}
-        //                      - beta_{j-1} omega_{j-2,k}  (+ rounding of size eps ||A||),   k <= j-2
-        std::fill(w_new.begin(), w_new.end(), 0.0);
-        w_new[(size_t)j] = 1.0;
-        w_new[(size_t)j - 1] = eps;
-        double worst = 0.0;
-        for (int k = 0; k + 2 <= j; ++k) {
-          double t = hb[(size_t)k + 1] * w_cur[(size_t)k + 1] + (ha[(size_t)k] - ha[(size_t)j - 1]) * w_cur[(size_t)k] -
-                     hb[(size_t)j - 1] * w_prev[(size_t)k];
-          if (k > 0) t += hb[(size_t)k] * w_cur[(size_t)k - 1];
-          t += (t < 0 ? -1.0 : 1.0) * 2.0 * eps * normA;
-          w_new[(size_t)k] = t / hb[(size_t)j];
-          worst = std::max(worst, std::fabs(w_new[(size_t)k]));
-        }
-        due = worst > thresh;
-        std::swap(w_prev, w_cur);
-        std::swap(w_cur, w_new);
-      }
-      sweep = (j == 0) || due || force_next;  // a due sweep also covers the next vector (both feed the recurrence)
-      force_next = due;
-      if (sweep)
-        for (int k = 0; k < j; ++k) w_cur[(size_t)k] = eps;
-    }
-    if (sweep) {
-      ++sweeps;
-      LZ_TRY(step_reorth(h, j, j + 1, true, bidx, true));
-    } else {
-      Scope sc(h, LZ_K_QTW, 16.0 * (double)h->rows, (double)h->rows);
-      launch_scale_store(h->d_V + (int64_t)j * h->ldv, h->d_r, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream);
-      LZ_TRY(check_launch(h, "scale_store"));
-    }
-    LZ_TRY(step_spmv(h, j));
-    // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
-    LZ_TRY(step_three_term(h, j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, !fused || partial));
-    if (partial) {
-      double* two = h->h_pinned;
-      LZ_HIP(h, hipMemcpyAsync(&two[0], h->d_alpha + j, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      LZ_HIP(h, hipMemcpyAsync(&two[1], h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      LZ_HIP(h, hipStreamSynchronize(h->stream));
-      h->host_syncs += 1;
-      ha[(size_t)j] = two[0];
-      hb[(size_t)j + 1] = std::sqrt(two[1]);
-      normA = std::max(normA, std::fabs(two[0]) + hb[(size_t)j] + hb[(size_t)j + 1]);
-    }
-  }
-  *sweeps_out = sweeps;
-  return LZ_OK;
-}
-
-// ---- partial re-orthogonalisation, device-resident (round 4; the default of LZ_FLAG_REORTH_PARTIAL) -----------------------
-// The loop above with the host taken out: Simon's omega-recurrence runs in a one-block kernel behind the three-term kernel
-// (k_omega, lz_reorth.hip; on one rank it also folds the ||r||^2 partials, so it costs no launch), which leaves a gate in
-// device memory; the sweep kernels of the next step (pass 1, second-stage sums, pass 2) are always enqueued and return at
-// once when the gate says no sweep is due.  No read-back, no hipStreamSynchronize between the first and the last launch
-// (lz_last_host_syncs == 0 on one rank / over RCCL).  Every rank takes the same decision: its inputs are all-reduced sums.
-// A step without a sweep on one rank with an ELL-ordered fixed-K matrix is TWO streaming kernels: the SpMV forms
-// v_j = r / beta itself wherever it reads x (k_spmv_ell<.., SC>: the separate 16M-byte scale pass is gone; r and y
-// ping-pong between two buffers), and the three-term kernel.  Other matrices keep the (gated) scale kernel.
-// Decisions, coefficients and basis are bit-identical to the host-decided loop (tests/test_gpu_lanczos.py).
-int run_loop_partial_device(lz_handle h, int n) {
-  const double M = (double)h->rows;
-  if (h->om_n < n) {
-    LZ_TRY(dev_alloc(h, h->d_om, omega_state_doubles(n)));
-    LZ_TRY(dev_alloc(h, h->d_omi, omega_state_ints(n)));
-    h->om_n = n;
-  }
-  const int* gate = h->d_omi;
-  const bool one_rank = h->world <= 1 && !(h->tune[6] && h->comm_kind);
-  if (one_rank && h->kind == 1 && h->tune[18] != 2 && h->tune[17] != 1 && !h->csr.ell_rb && !h->csr.pb &&
-      (h->csr.fixed_k == 5 || h->csr.fixed_k == 7))
-    // first partial run on this matrix: the ELL copy the fused r / beta needs.  (5 and 7 entries per row: its alpha partials
-    // are grouped exactly like k_spmv_fixed's - 512-row blocks, rows t and t + 256 per lane - so the fused and the unfused loop
-    // produce the same bits; 27-point rows keep the scale kernel + the CSR-stream SpMV)
-    LZ_HIP(h, ell_build(h->csr, 0, h->stream));
-  const bool fuse_scale = one_rank && h->kind == 1 && ell_usable(h->csr, h->flags) && h->tune[18] != 2;
-  // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0; ||r||^2
-  LZ_TRY(step_spmv(h, 0));
-  int np = 0;
-  auto three_term_and_decide = [&](int j, int jm1, const double* d_alpha, const double* d_beta, double* r, bool decide, int jn) -> int {
-    {
-      Scope sc(h, LZ_K_THREE, (jm1 >= 0 ? 32.0 : 24.0) * M, (jm1 >= 0 ? 6.0 : 4.0) * M);
-      np = launch_three_term(r, h->d_V + (int64_t)j * h->ldv, jm1 >= 0 ? h->d_V + (int64_t)jm1 * h->ldv : nullptr, d_alpha, d_beta, h->rows_pad,
-                             h->d_part, h->stream);
-      LZ_TRY(check_launch(h, "three_term"));
-    }
-    Scope sc(h, LZ_K_FINAL, 0, 0);
-    if (one_rank && decide) {
-      launch_omega(h->d_part, np, h->d_nrm2, h->d_alpha, jn, n, h->d_om, h->d_omi, h->stream);
-      return check_launch(h, "final_sum(nrm2) + omega");
-    }
-    launch_final_sum(h->d_part, np, h->d_nrm2, h->stream);
-    LZ_TRY(check_launch(h, "final_sum(nrm2)"));
-    LZ_TRY(comm_allreduce(h, h->d_nrm2, 1));
-    if (decide) {
-      launch_omega(nullptr, 0, h->d_nrm2, h->d_alpha, jn, n, h->d_om, h->d_omi, h->stream);
-      LZ_TRY(check_launch(h, "omega"));
-    }
-    return LZ_OK;
-  };
-  LZ_TRY(three_term_and_decide(0, -1, h->d_alpha, nullptr, h->d_r, true, 0));
-  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-  double* rcur = h->d_r;   // the residual entering the step
-  double* rnext = h->d_r2; // where the fused SpMV writes y (it reads r through its gathers: not in place)
-  for (int j = 0; j < n; ++j) {
-    h->prof_iter = (j % pstride) == pstride / 2;
-    const int bidx = (j + n - 2) % (n - 1);
-    double* vj = h->d_V + (int64_t)j * h->ldv;
-    // the sweep (gated; bytes are accounted after the run from the device's sweep log: the host does not know which ran)
-    {
-      QtwFuse fz;
-      fz.gate = gate;
-      h->qplan.variant = 0;
-      {
-        Scope sc(h, LZ_K_QTW, 0, 0);
-        LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, j + 1, j, rcur, h->d_nrm2, h->d_beta + bidx, h->qplan, h->d_part, 1, h->stream, &fz));
-        LZ_TRY(check_launch(h, "qtw(gated)"));
-      }
-      {
-        Scope sc(h, LZ_K_FINAL, 0, 0);
-        launch_final_rows(h->d_part, j + 1, h->qplan.P, h->d_c, h->stream, true, gate);
-        LZ_TRY(check_launch(h, "final_rows(gated)"));
-      }
-      LZ_TRY(comm_allreduce(h, h->d_c, j + 1));  // (N > 1: issued every step - the host cannot skip a collective the device may need)
-      {
-        Scope sc(h, LZ_K_UPDATE, 0, 0);
-        launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, h->d_c, nullptr, h->d_beta + bidx, 0, h->stream, 0, -1, 0, 0, 0, 0, 0, gate);
-        LZ_TRY(check_launch(h, "update(gated)"));
-      }
-    }
-    if (fuse_scale) {
-      SpmvScale ss;
-      ss.r = rcur;
-      ss.nrm2 = h->d_nrm2;
-      ss.vj = vj;
-      ss.beta_slot = h->d_beta + bidx;
-      ss.gate = gate;
-      int npa = 0;
-      {
-        Scope sc(h, LZ_K_SPMV, spmv_bytes(h) + 16.0 * M, spmv_flops(h) + M);  // (the scale pass's 16M bytes ride here: BASELINE.md's accounting of the step is unchanged)
-        npa = launch_spmv_ell(h->csr, vj, rnext, vj, h->d_part, h->stream, &ss);
-        LZ_TRY(check_launch(h, "spmv(ell, scale fused)"));
-      }
-      {
-        Scope sc(h, LZ_K_FINAL, 0, 0);
-        launch_final_sum(h->d_part, npa, h->d_alpha + j, h->stream);
-        LZ_TRY(check_launch(h, "final_sum(alpha)"));
-      }
-      std::swap(rcur, rnext);
-    } else {
-      {
-        Scope sc(h, LZ_K_QTW, 16.0 * M, M);
-        launch_scale_store(vj, rcur, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream, gate);
-        LZ_TRY(check_launch(h, "scale_store(gated)"));
-      }
-      LZ_TRY(step_spmv(h, j));  // r = A V[j] into h->d_r (== rcur), alpha_j
-    }
-    // at j = 0 the reference subtracts beta * V[-1], the still-zero last row: a no-op
-    LZ_TRY(three_term_and_decide(j, j > 0 ? j - 1 : -1, h->d_alpha + j, h->d_beta + bidx, rcur, j + 1 < n, j + 1));
-  }
-  if (rcur != h->d_r) std::swap(h->d_r, h->d_r2);  // the residual entering step n is what lz_get_residual hands out
-  return LZ_OK;
-}
-
-// after the final synchronisation of lz_run: the device's sweep log -> lz_last_sweeps and the byte / flop accounting of the
-// gated launches (pass 1: 8 j M + 16 M bytes, pass 2 the same; in a swept step the scale kernel / fused scale did no work)
-void account_partial_device(lz_handle h, int n, const std::vector<int>& log, int* sweeps_out) {
-  const double M = (double)h->rows;
-  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
-  int sweeps = 0;
-  for (int j = 0; j < n; ++j) {
-    if (!log[(size_t)2 + j]) continue;
-    ++sweeps;
-    // (pass 1's read of r and write of V[j], 16 M bytes, are on the books already: the scale pass is accounted in every step)
-    const double flops = 2.0 * (j + 1) * M;
-    const bool timed = (h->flags & LZ_FLAG_PROFILE) != 0 && (j % pstride) == pstride / 2;
-    for (int cls : {LZ_K_QTW, LZ_K_UPDATE}) {
-      const double bytes = 8.0 * j * M + (cls == LZ_K_UPDATE ? 16.0 * M : 0.0);
-      h->acc.bytes[cls] += bytes;
-      h->acc.flops[cls] += flops;
-      if (timed) h->acc.timed_bytes[cls] += bytes;
-    }
-  }
-  *sweeps_out = sweeps;
-}
-
-// Breakdown report.  The reference divides by beta blindly (Lanczos.py:113): an exhausted Krylov
-// space gives it a residual of rounding noise (or an exact zero and then inf/NaN), and it carries on.  So does this
-// run - the coefficients are delivered exactly as computed - but the status says so: a beta at or below 64 eps times
-// the scale of T (max |alpha|, |beta|), or any non-finite coefficient.  beta[n-2] is also where step j = 0 parks its
-// norm before step n-1 overwrites it, so every entry of beta_out has been a divisor.
-int breakdown_status(lz_handle h, int n, const double* alpha_out, const double* beta_out) {
-  double tscale = 0.0;
-  for (int j = 0; j < n; ++j) {
-    if (std::isfinite(alpha_out[j])) tscale = std::max(tscale, std::fabs(alpha_out[j]));
-    if (j < n - 1 && std::isfinite(beta_out[j])) tscale = std::max(tscale, std::fabs(beta_out[j]));
-  }
-  const double tiny = 64.0 * 2.220446049250313e-16 * tscale;
-  for (int j = 0; j < n; ++j) {
-    const bool bad_a = !std::isfinite(alpha_out[j]);
-    const bool bad_b = j < n - 1 && !(std::isfinite(beta_out[j]) && beta_out[j] > tiny);
-    if (bad_a || bad_b) {
-      char msg[200];
-      if (bad_b && std::isfinite(beta_out[j]))
-        snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - beta[%d] = %.3e <= 64 eps * %.3e: the Krylov space is exhausted, later vectors are rounding noise",
-                 j, beta_out[j], tscale);
-      else
-        snprintf(msg, sizeof msg, "lz_run: Lanczos breakdown - %s[%d] is not finite (a residual norm reached zero)", bad_b ? "beta" : "alpha", j);
-      h->err = msg;
-      return LZ_WARN_BREAKDOWN;
-    }
-  }
-  return LZ_OK;
-}
-
 int require_basis(lz_handle h, int j) {
   if (!h->d_V) return fail(h, LZ_ERR_STATE, "no basis allocated (call lz_run or lz_basis_alloc first)");
   if (j < 0 || j >= h->n) return fail(h, LZ_ERR_ARG, "basis row index out of range");
   return LZ_OK;
 }
 
-void build_rowblocks(const int32_t* rowptr, int64_t rows, int rows_cap, int nnz_cap, std::vector<int32_t>& blk) {
-  blk.clear();
-  blk.push_back(0);
-  int64_t r = 0;
-  while (r < rows) {
-    int64_t e = r;
-    const int64_t k0 = rowptr[r];
-    while (e < rows && e - r < rows_cap && (int64_t)rowptr[e + 1] - k0 <= nnz_cap) ++e;
-    if (e == r) e = r + 1;  // a single row longer than the LDS tile: block of its own
-    blk.push_back((int32_t)e);
-    r = e;
-  }
-}
+}  // namespace api
+}  // namespace lz
 
-// shared tail of lz_set_csr / lz_build_stencil3d: row blocks for the CSR-stream kernel + bookkeeping
-int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t rows_local, int64_t ncols_ext, int64_t nnz, int fixed_k,
-                  int max_nnz);
-
-int finish_csr(lz_handle h, const int32_t* rowptr_host, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext,
-               int64_t nnz, int fixed_k, int max_nnz) {
-  LZ_TRY(fill_csr_meta(h, h->csr, rowptr_host, rows_local, ncols_ext, nnz, fixed_k, max_nnz));
-  h->T_declared = false;  // a new H invalidates H^T and the two-sided bases
-  h->has_T = false;
-  h->bi_n = 0;
-  h->Mg = M_global;
-  h->row0 = row0;
-  h->rows = rows_local;
-  h->ncols_ext = ncols_ext;
-  h->rows_pad = round_up(rows_local, kPadDoubles);
-  h->ldv = skew_stride(h, h->rows_pad);
-  h->xmode = 0;
-  h->kind = 1;
-  return LZ_OK;
-}
-
-int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t rows_local, int64_t ncols_ext, int64_t nnz, int fixed_k,
-                  int max_nnz) {
-  std::vector<int32_t> blk;
-  int rows_cap = h->tune[2] > 0 ? h->tune[2] : 512;
-  // One batch of the CSR-stream kernel covers 2048 entries (256 lanes x 4 steps x 2): for long rows (27-point
-  // stencils) a tile of exactly one batch is fastest (profiles/r01/ab_spmv_27pt_tile.json); short ragged rows keep 4096.
-  int nnz_cap = h->tune[4] > 0 ? h->tune[4] : ((double)nnz / (double)rows_local >= 12.0 ? 2048 : 4096);
-  if (nnz_cap > 16384) nnz_cap = 16384;
-  build_rowblocks(rowptr_host, rows_local, rows_cap, nnz_cap, blk);
-  A.blk_nnz_cap = nnz_cap;
-  A.ablation = h->tune[3];
-  A.fixed_rb = h->tune[5] > 0 ? h->tune[5] : 512;
-  LZ_TRY(dev_alloc(h, A.rowblk, blk.size()));
-  LZ_HIP(h, hipMemcpy(A.rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  A.n_rowblk = (int)blk.size() - 1;
-  A.rows = rows_local;
-  A.ncols = ncols_ext;
-  A.nnz = nnz;
-  A.fixed_k = fixed_k;
-  A.max_row_nnz = max_nnz;
-  A.avg_row_nnz = (double)nnz / (double)rows_local;
-  // Matrices without column locality (random graphs): the SpMV is bound by cache-missing 8-byte gathers, so it runs as
-  // the column-blocked two-phase kernel pair that gathers out of LDS only (lz_spmv_pb.hip; 2.5x on config C3, same
-  // bits).  Auto: the vector is larger than the L2s can hold (>= 2^20 columns), rows are not a fixed-K stencil, and more
-  // than a quarter of the entries sit further than 2^18 columns from the diagonal.  tune[14]: 1 = never, 2 = always
-  // (tests run it on small matrices).
-  pb_free(A.pb);
-  // Fixed-K rows (stencils): the ELL-ordered second copy (lz_spmv.hip, k_spmv_ell) - lanes own whole rows, coalesced loads
-  // and gathers, no LDS staging.  Measured against the CSR-order kernel k_spmv_fixed on the headline, C2 and two 3-D grids
-  // (profiles/r04/ab_spmv_ell.json): the same time to within 2 % either way - both sit at the rate this part streams a
-  // 90 % read / 10 % write mix - so the plain SpMV keeps the CSR-order kernel and no second copy is made.  The ELL copy is what
-  // the device-resident partial re-orthogonalisation loop needs for its fused r / beta (a lane owns whole rows): that loop
-  // builds it on first use.  tune[17]: 0 auto (as just said), 1 never (not even for the partial loop), 2 ELL for every SpMV,
-  // one row per lane and trip, 3 ELL with two adjacent rows per lane.
-  ell_free(A);
-  A.ell_default = h->tune[17] >= 2;  // the plain SpMV takes the ELL copy only on request: measured no faster than the CSR-order kernel
-  if (h->tune[17] >= 2 && (fixed_k == 5 || fixed_k == 7 || fixed_k == 27)) LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
-  const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
-  if (want) {
-    const hipError_t pe = pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]);
-    A.host_colidx = nullptr;  // (the caller's arrays are only valid during this call)
-    A.host_vals = nullptr;
-    LZ_HIP(h, pe);
-  }
-  A.host_colidx = nullptr;
-  A.host_vals = nullptr;
-  return LZ_OK;
-}
-
-// validate + upload one CSR matrix into A (arrays padded by 2 entries: the kernels read pairs)
-int upload_csr(lz_handle h, CsrDev& A, const char* who, int64_t rows, int64_t ncols, int64_t nnz, const int32_t* rowptr,
-               const int32_t* colidx, const double* vals, int* fixed_k_out, int* max_nnz_out) {
-  if (rowptr[0] != 0 || rowptr[rows] != nnz) return fail(h, LZ_ERR_ARG, std::string(who) + ": rowptr[0] != 0 or rowptr[rows] != nnz");
-  const bool dbg = getenv("LZ_DEBUG_TIMING") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = now();
-  // one sweep over the rows and their entries, split over host threads (round 3: two single-thread loops, 0.35 s at the
-  // headline's 5e7 entries): row lengths monotone, their maximum, whether all are equal, column range, share of far entries
-  struct Part {
-    int max_nnz = 0;
-    bool same = true, bad_ptr = false, bad_col = false;
-    int64_t far = 0;
-  } parts[kMaxHostThreads];
-  const int64_t k_first = rows > 0 ? (int64_t)rowptr[1] - rowptr[0] : 0;
-  parallel_ranges(rows, 1 << 16, [&](int t, int64_t lo, int64_t hi) {
-    Part p;  // a local: the threads' slots of `parts` share cache lines
-    struct Publish {
-      Part& dst;
-      const Part& src;
-      ~Publish() { dst = src; }
-    } publish{parts[t], p};
-    for (int64_t i = lo; i < hi; ++i) {
-      const int64_t a = rowptr[i], b = rowptr[i + 1], d = b - a;
-      if (d < 0 || a < 0 || b > nnz) {
-        p.bad_ptr = true;
-        return;
-      }
-      if (d > p.max_nnz) p.max_nnz = (int)d;
-      if (d != k_first) p.same = false;
-      for (int64_t k = a; k < b; ++k) {
-        const int64_t c = colidx[k];
-        if (c < 0 || c >= ncols) {
-          p.bad_col = true;
-          return;
-        }
-        p.far += (c > i ? c - i : i - c) > ((int64_t)1 << 18);
-      }
-    }
-  });
-  int max_nnz = 0;
-  int fixed_k = (int)k_first;
-  int64_t far = 0;
-  for (const Part& p : parts) {
-    if (p.bad_ptr) return fail(h, LZ_ERR_ARG, std::string(who) + ": rowptr not monotone");
-    if (p.bad_col) return fail(h, LZ_ERR_ARG, std::string(who) + ": column index out of range");
-    if (p.max_nnz > max_nnz) max_nnz = p.max_nnz;
-    if (!p.same) fixed_k = 0;
-    far += p.far;
-  }
-  A.far_frac = nnz > 0 ? (double)far / (double)nnz : 0.0;
-  const double t1 = now();
-  pb_free(A.pb);
-  ell_free(A);
-  if (fixed_k > 64) fixed_k = 0;
-  LZ_TRY(dev_alloc(h, A.rowptr, (size_t)rows + 1));
-  LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
-  LZ_TRY(dev_alloc(h, A.vals, (size_t)nnz + 2));
-  LZ_HIP(h, hipMemsetAsync(A.colidx + nnz, 0, 2 * sizeof(int32_t), h->stream));  // (the kernels read pairs: two pad entries)
-  LZ_HIP(h, hipMemsetAsync(A.vals + nnz, 0, 2 * sizeof(double), h->stream));
-  LZ_TRY(upload(h, A.rowptr, rowptr, ((size_t)rows + 1) * sizeof(int32_t)));
-  if (nnz > 0) {
-    LZ_TRY(upload(h, A.colidx, colidx, (size_t)nnz * sizeof(int32_t)));
-    LZ_TRY(upload(h, A.vals, vals, (size_t)nnz * sizeof(double)));
-  }
-  const double t2 = now();
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  if (dbg)
-    fprintf(stderr, "[%s] validation sweep %.3f ms, device alloc %.3f ms, H2D of %.1f MB %.3f ms\n", who, t1 - t0, t2 - t1,
-            (12.0 * nnz + 4.0 * rows) / 1e6, now() - t2);
-  *fixed_k_out = fixed_k;
-  *max_nnz_out = max_nnz;
-  A.host_colidx = colidx;  // for pb_build (fill_csr_meta, same API call): diagonal split, fp32-exact value check
-  A.host_vals = vals;
-  return LZ_OK;
-}
-
-}  // namespace
+using namespace lz::api;
 
 // ======================================================================= C ABI
 extern "C" {
@@ -1515,277 +486,13 @@ int lz_comm_init_host(lz_handle h, int world, int rank, lz_host_allreduce_fn ar,
   return LZ_OK;
 }
 
-// ---- matrix ----------------------------------------------------------------
-int lz_set_csr(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext, int64_t nnz,
-               const int32_t* rowptr, const int32_t* colidx, const double* vals) {
-  if (!h) return LZ_ERR_ARG;
-  if (M_global <= 0 || rows_local <= 0 || row0 < 0 || row0 + rows_local > M_global || nnz < 0 || !rowptr ||
-      (nnz > 0 && (!colidx || !vals)))
-    return fail(h, LZ_ERR_ARG, "lz_set_csr: bad sizes or NULL arrays");
-  if (rows_local >= (int64_t)1 << 31 || nnz >= (int64_t)1 << 31 || ncols_ext >= (int64_t)1 << 31)
-    return fail(h, LZ_ERR_ARG, "lz_set_csr: sizes exceed int32 CSR indexing");
-  if (ncols_ext < rows_local) return fail(h, LZ_ERR_ARG, "lz_set_csr: ncols_ext < rows_local");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  h->kind = 0;
-  LZ_TRY(dev_free(h, h->d_dense));
-  LZ_TRY(dev_free(h, h->d_V));  // a new matrix invalidates the basis
-  h->n = 0;
-  int fixed_k = 0, max_nnz = 0;
-  LZ_TRY(upload_csr(h, h->csr, "lz_set_csr", rows_local, ncols_ext, nnz, rowptr, colidx, vals, &fixed_k, &max_nnz));
-  return finish_csr(h, rowptr, M_global, row0, rows_local, ncols_ext, nnz, fixed_k, max_nnz);
-}
-
-int lz_build_stencil3d_block(lz_handle h, int Nx, int Ny, int Nz, int points, double T_factor, const double* weights4,
-                             int potential_kind, const double* potential, int negate_T, int64_t row0, int64_t rows_local,
-                             int nranges, const int64_t* ghost_start, const int64_t* ghost_len) {
-  if (!h) return LZ_ERR_ARG;
-  if (Nx < 3 || Ny < 3 || Nz < 3 || (points != 7 && points != 27) || !weights4)
-    return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: need Nx, Ny, Nz >= 3, points in {7, 27}, 4 weights");
-  const int64_t M = (int64_t)Nx * Ny * Nz;
-  if (row0 < 0 || rows_local <= 0 || row0 + rows_local > M) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: bad row block");
-  if (potential_kind < 0 || potential_kind > 2 || (potential_kind != 0 && !potential))
-    return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: potential_kind in {0, 1, 2}; kinds 1 and 2 need the array / the 8 parameters");
-  if (nranges < 0 || nranges > 16 || (nranges > 0 && (!ghost_start || !ghost_len)))
-    return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: at most 16 ghost ranges");
-  const bool whole = rows_local == M;
-  if (!whole && h->world == 1) return fail(h, LZ_ERR_STATE, "lz_build_stencil3d_block: a row block needs a multi-rank handle (lz_comm_init_*)");
-  const int64_t nnz = rows_local * points;
-  if (nnz >= (int64_t)1 << 31 || M >= (int64_t)1 << 31) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: sizes exceed int32 CSR indexing");
-  StencilArgs a;
-  memset(&a, 0, sizeof a);
-  a.Nx = Nx;
-  a.Ny = Ny;
-  a.Nz = Nz;
-  a.negate = negate_T;
-  a.pot_kind = potential_kind;
-  a.renumber = whole ? 0 : 1;
-  a.nranges = nranges;
-  a.row0 = row0;
-  a.rows_local = rows_local;
-  a.tf = T_factor;
-  for (int q = 0; q < 4; ++q) a.w[q] = weights4[q];
-  if (potential_kind == 2)
-    for (int q = 0; q < 8; ++q) a.par[q] = potential[q];
-  const int64_t rows_pad = round_up(rows_local, kPadDoubles);
-  int64_t ext = rows_pad, nghost = 0;
-  for (int q = 0; q < nranges; ++q) {
-    if (ghost_len[q] <= 0 || ghost_start[q] < 0 || ghost_start[q] + ghost_len[q] > M ||
-        (ghost_start[q] < row0 + rows_local && ghost_start[q] + ghost_len[q] > row0))
-      return fail(h, LZ_ERR_ARG, "lz_build_stencil3d_block: ghost range outside the grid or overlapping the owned rows");
-    a.gstart[q] = ghost_start[q];
-    a.glen[q] = ghost_len[q];
-    a.gext[q] = ext;
-    ext += ghost_len[q];
-    nghost += ghost_len[q];
-  }
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  h->kind = 0;
-  LZ_TRY(dev_free(h, h->d_dense));
-  LZ_TRY(dev_free(h, h->d_V));
-  h->n = 0;
-  CsrDev& A = h->csr;
-  pb_free(A.pb);
-  LZ_TRY(dev_alloc(h, A.rowptr, (size_t)rows_local + 1));
-  LZ_TRY(dev_alloc(h, A.colidx, (size_t)nnz + 2));
-  LZ_TRY(dev_alloc(h, A.vals, (size_t)nnz + 2));
-  LZ_HIP(h, hipMemsetAsync(A.colidx + nnz, 0, 2 * sizeof(int32_t), h->stream));
-  LZ_HIP(h, hipMemsetAsync(A.vals + nnz, 0, 2 * sizeof(double), h->stream));
-  double* dpot = nullptr;
-  if (potential_kind == 1) {
-    LZ_TRY(dev_alloc(h, dpot, (size_t)rows_local));
-    LZ_HIP(h, hipMemcpyAsync(dpot, potential, (size_t)rows_local * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  }
-  launch_build_stencil3d(a, points, dpot, A.rowptr, A.colidx, A.vals, h->stream);
-  int rc = check_launch(h, "build_stencil3d");
-  hipError_t e = hipStreamSynchronize(h->stream);
-  if (dpot) hipFree(dpot);
-  if (rc != LZ_OK) return rc;
-  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_build_stencil3d_block: ") + hipGetErrorString(e));
-  std::vector<int32_t> rowptr((size_t)rows_local + 1);
-  for (int64_t i = 0; i <= rows_local; ++i) rowptr[(size_t)i] = (int32_t)(i * points);
-  A.far_frac = 0.0;
-  return finish_csr(h, rowptr.data(), M, row0, rows_local, whole ? M : rows_pad + nghost, nnz, points, points);
-}
-
-int lz_build_stencil3d(lz_handle h, int N, int points, double T_factor, const double* weights4, const double* potential,
-                       int negate_T) {
-  if (!h) return LZ_ERR_ARG;
-  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_build_stencil3d: whole matrix on one rank; use lz_build_stencil3d_block for a row partition");
-  if (N < 3) return fail(h, LZ_ERR_ARG, "lz_build_stencil3d: need N >= 3, points in {7, 27}, 4 weights");
-  return lz_build_stencil3d_block(h, N, N, N, points, T_factor, weights4, potential ? 1 : 0, potential, negate_T, 0, (int64_t)N * N * N, 0,
-                                  nullptr, nullptr);
-}
-
-int lz_csr_info(lz_handle h, int64_t* rows, int64_t* nnz) {
-  if (!h || !rows || !nnz) return LZ_ERR_ARG;
-  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_csr_info: no CSR matrix set");
-  *rows = h->csr.rows;
-  *nnz = h->csr.nnz;
-  return LZ_OK;
-}
-
-int lz_spmv_plan(lz_handle h, int* plan) {
-  if (!h || !plan) return LZ_ERR_ARG;
-  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "lz_spmv_plan: no matrix set");
-  if (h->kind == 2) {
-    *plan = 4;
-    return LZ_OK;
-  }
-  const CsrDev& A = h->csr;
-  if (h->flags & LZ_FLAG_SPMV_SCALAR) *plan = 0;
-  else if (A.pb && !(h->flags & LZ_FLAG_SPMV_STREAM)) *plan = 3;
-  else if (!(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7)) *plan = 2;
-  else *plan = 1;
-  return LZ_OK;
-}
-
-int lz_get_csr(lz_handle h, int32_t* rowptr, int32_t* colidx, double* vals) {
-  if (!h || !rowptr || !colidx || !vals) return LZ_ERR_ARG;
-  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_get_csr: no CSR matrix set");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  const CsrDev& A = h->csr;
-  LZ_HIP(h, hipMemcpy(rowptr, A.rowptr, ((size_t)A.rows + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
-  LZ_HIP(h, hipMemcpy(colidx, A.colidx, (size_t)A.nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
-  LZ_HIP(h, hipMemcpy(vals, A.vals, (size_t)A.nnz * sizeof(double), hipMemcpyDeviceToHost));
-  return LZ_OK;
-}
-
-int lz_set_dense_block(lz_handle h, int64_t M_global, int64_t row0, int64_t rows_local, int64_t ncols_ext, const double* A) {
-  if (!h) return LZ_ERR_ARG;
-  if (M_global <= 0 || rows_local <= 0 || row0 < 0 || row0 + rows_local > M_global || ncols_ext < M_global || !A)
-    return fail(h, LZ_ERR_ARG, "lz_set_dense_block: bad sizes or NULL matrix");
-  if (h->world == 1 && (rows_local != M_global || ncols_ext != M_global))
-    return fail(h, LZ_ERR_ARG, "lz_set_dense_block: a single rank owns the whole square matrix");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  h->kind = 0;
-  LZ_TRY(dev_free(h, h->d_V));
-  h->n = 0;
-  const int64_t lda = (ncols_ext + 1) & ~(int64_t)1;
-  LZ_TRY(dev_alloc(h, h->d_dense, (size_t)rows_local * lda + 2));
-  if (lda != ncols_ext) LZ_HIP(h, hipMemsetAsync(h->d_dense, 0, ((size_t)rows_local * lda + 2) * sizeof(double), h->stream));
-  LZ_TRY(upload2d(h, h->d_dense, (size_t)lda * sizeof(double), A, (size_t)ncols_ext * sizeof(double), (size_t)ncols_ext * sizeof(double),
-                  (size_t)rows_local));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  h->dense_lda = lda;
-  h->Mg = M_global;
-  h->row0 = row0;
-  h->rows = rows_local;
-  h->ncols_ext = ncols_ext;
-  h->rows_pad = round_up(rows_local, kPadDoubles);
-  h->ldv = skew_stride(h, h->rows_pad);
-  h->xmode = 0;
-  h->kind = 2;
-  h->T_declared = false;
-  h->bi_n = 0;
-  return LZ_OK;
-}
-
-int lz_set_dense(lz_handle h, int64_t M, const double* A) {
-  if (!h) return LZ_ERR_ARG;
-  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_set_dense: one rank, whole matrix; use lz_set_dense_block + lz_set_allgather for a row partition");
-  return lz_set_dense_block(h, M, 0, M, M, A);
-}
-
-int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* send_counts, const int32_t* send_idx,
-                const int64_t* recv_counts) {
-  if (!h) return LZ_ERR_ARG;
-  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_set_halo: call lz_set_csr first");
-  if (npeers < 0 || (npeers > 0 && (!peers || !send_counts || !recv_counts))) return fail(h, LZ_ERR_ARG, "lz_set_halo: NULL arrays");
-  h->peers.assign(peers, peers + npeers);
-  h->scount.assign(send_counts, send_counts + npeers);
-  h->rcount.assign(recv_counts, recv_counts + npeers);
-  h->soff.assign(npeers, 0);
-  h->roff.assign(npeers, 0);
-  int64_t ts = 0, tr = 0;
-  for (int p = 0; p < npeers; ++p) {
-    const bool self_ok = h->tune[6] != 0;  // test knob: a rank may exchange with itself (1-rank RCCL send/recv test)
-    if (peers[p] < 0 || peers[p] >= h->world || (peers[p] == h->rank && !self_ok) || send_counts[p] < 0 || recv_counts[p] < 0)
-      return fail(h, LZ_ERR_ARG, "lz_set_halo: bad peer or count");
-    h->soff[p] = ts;
-    h->roff[p] = tr;
-    ts += send_counts[p];
-    tr += recv_counts[p];
-  }
-  if (h->rows_pad + tr != h->ncols_ext)
-    return fail(h, LZ_ERR_ARG, "lz_set_halo: ncols_ext must equal lz_padded_rows(rows_local) + total receive count");
-  for (int64_t k = 0; k < ts; ++k)
-    if (!send_idx || send_idx[k] < 0 || send_idx[k] >= h->rows) return fail(h, LZ_ERR_ARG, "lz_set_halo: send index out of range");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_TRY(dev_alloc(h, h->d_send_idx, (size_t)ts));
-  LZ_TRY(dev_alloc(h, h->d_sendbuf, (size_t)ts));
-  if (ts > 0) LZ_HIP(h, hipMemcpy(h->d_send_idx, send_idx, (size_t)ts * sizeof(int32_t), hipMemcpyHostToDevice));
-  h->sstart.assign(npeers, -1);
-  h->all_contig = npeers > 0;
-  for (int p = 0; p < npeers; ++p) {
-    bool contig = true;
-    for (int64_t k = 1; k < send_counts[p]; ++k)
-      if (send_idx[h->soff[p] + k] != send_idx[h->soff[p] + k - 1] + 1) {
-        contig = false;
-        break;
-      }
-    if (contig && send_counts[p] > 0) h->sstart[p] = send_idx[h->soff[p]];
-    if (!contig) h->all_contig = false;
-  }
-  h->bnd_ranges.clear();
-  h->int_ranges.clear();
-  if (h->all_contig) {
-    std::vector<std::pair<int64_t, int64_t>> rg;
-    for (int p = 0; p < npeers; ++p)
-      if (send_counts[p] > 0) rg.push_back({h->sstart[p] / 2, (h->sstart[p] + send_counts[p] + 1) / 2});  // double2 positions
-    std::sort(rg.begin(), rg.end());
-    for (auto& r : rg) {
-      if (!h->bnd_ranges.empty() && r.first <= h->bnd_ranges.back().second)
-        h->bnd_ranges.back().second = std::max(h->bnd_ranges.back().second, r.second);
-      else
-        h->bnd_ranges.push_back(r);
-    }
-    int64_t cur = 0;
-    const int64_t n2 = h->rows_pad / 2;
-    for (auto& r : h->bnd_ranges) {
-      if (r.first > cur) h->int_ranges.push_back({cur, r.first});
-      cur = r.second;
-    }
-    if (cur < n2) h->int_ranges.push_back({cur, n2});
-    if (!h->cstream) {
-      LZ_HIP(h, hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
-      LZ_HIP(h, hipEventCreateWithFlags(&h->e_bnd, hipEventDisableTiming));
-      LZ_HIP(h, hipEventCreateWithFlags(&h->e_halo, hipEventDisableTiming));
-    }
-  }
-  h->total_send = ts;
-  h->total_recv = tr;
-  h->ldv = skew_stride(h, h->rows_pad + round_up(tr, kPadDoubles));
-  h->xmode = 1;
-  LZ_TRY(dev_free(h, h->d_V));
-  h->n = 0;
-  return LZ_OK;
-}
-
-int lz_set_allgather(lz_handle h, int64_t chunk) {
-  if (!h) return LZ_ERR_ARG;
-  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "lz_set_allgather: call lz_set_csr / lz_set_dense_block first");
-  if (chunk < h->rows_pad || chunk % kPadDoubles != 0 || chunk * h->world != h->ncols_ext)
-    return fail(h, LZ_ERR_ARG, "lz_set_allgather: chunk must be a multiple of 32, >= padded rows, and world*chunk == ncols_ext");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_TRY(dev_alloc(h, h->d_xfull, (size_t)(chunk * h->world)));
-  LZ_HIP(h, hipMemset(h->d_xfull, 0, (size_t)(chunk * h->world) * sizeof(double)));
-  h->ag_chunk = chunk;
-  h->ldv = skew_stride(h, chunk);
-  h->xmode = 2;
-  LZ_TRY(dev_free(h, h->d_V));
-  h->n = 0;
-  return LZ_OK;
-}
-
 // ---- basis -------------------------------------------------------------------
 // zero_rows: how many leading basis rows to clear.  The step API hands out an all-zero basis (the reference's
 // np.zeros((n, M)), Lanczos.py:104); lz_run only needs row 0 cleared (padding + ghost tail around the uploaded v0):
 // every other row is fully written before it is first read, and at j = 0 the beta * V[-1] term is skipped outright,
 // so the 8nM-byte memset (3 ms of the 553 ms headline solve) is not paid per run.
-static int basis_alloc(lz_handle h, int n, int zero_rows) {
+}  // extern "C"
+int lz::api::basis_alloc(lz_handle h, int n, int zero_rows) {
   if (!h) return LZ_ERR_ARG;
   if (h->kind == 0) return fail(h, LZ_ERR_STATE, "no matrix set (lz_set_csr / lz_set_dense)");
   if (n < 1) return fail(h, LZ_ERR_ARG, "n must be >= 1");
@@ -1848,6 +555,8 @@ static int basis_alloc(lz_handle h, int n, int zero_rows) {
   LZ_HIP(h, hipStreamSynchronize(h->stream));
   return LZ_OK;
 }
+
+extern "C" {
 
 int lz_basis_alloc(lz_handle h, int n) { return basis_alloc(h, n, n); }
 
@@ -1927,830 +636,6 @@ int lz_step_three_term(lz_handle h, int j, int jm1, double alpha, double beta, d
   LZ_TRY(step_three_term(h, j, jm1, h->d_c + h->n, h->d_beta + h->n));
   if (norm2_out) LZ_HIP(h, hipMemcpyAsync(norm2_out, h->d_nrm2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
-  return LZ_OK;
-}
-
-int lz_spmv_host(lz_handle h, const double* x, double* y) {
-  if (!h || !x || !y) return LZ_ERR_ARG;
-  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "no matrix set");
-  if (h->world > 1) return fail(h, LZ_ERR_STATE, "lz_spmv_host is single-rank only");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  const size_t nx = (size_t)round_up(h->ncols_ext, kPadDoubles) + 2 * (size_t)h->rows_pad;
-  LZ_TRY(dev_alloc(h, h->d_xtmp, nx));
-  double* dx = h->d_xtmp;
-  double* dy = h->d_xtmp + round_up(h->ncols_ext, kPadDoubles);
-  LZ_TRY(ensure_part(h, std::max<size_t>((size_t)h->csr.n_rowblk + 64, (size_t)(h->rows / 4 + 64))));  // >= the two-phase kernel's row blocks
-  LZ_HIP(h, hipMemcpyAsync(dx, x, (size_t)h->ncols_ext * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (h->kind == 1)
-    launch_spmv_csr(h->csr, dx, dy, dx, h->d_part, h->flags, h->stream);
-  else
-    launch_gemv_dense(h->d_dense, h->rows, h->ncols_ext, h->dense_lda, dx, dx, dy, h->d_part, h->stream);
-  LZ_TRY(check_launch(h, "spmv"));
-  LZ_HIP(h, hipMemcpyAsync(y, dy, (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  return LZ_OK;
-}
-
-// ---- early allocation of the big buffers ---------------------------------------------------------------------------------
-static size_t y_doubles(int64_t rows, int n) { return (size_t)(round_up(rows, 16) + 16) * (size_t)n + 64; }
-
-int lz_reserve(lz_handle h, int64_t rows_local, int n, int with_ritz) {
-  if (!h) return LZ_ERR_ARG;
-  if (rows_local <= 0 || n < 1) return fail(nullptr, LZ_ERR_ARG, "lz_reserve: bad sizes");
-  if (hipSetDevice(h->dev) != hipSuccess) return LZ_ERR_HIP;  // (h->err belongs to the thread that drives the handle: not written here)
-  const int64_t rows_pad = round_up(rows_local, kPadDoubles);
-  const size_t vsz = (size_t)n * (size_t)skew_stride(h, rows_pad);
-  const size_t ysz = y_doubles(rows_local, n);
-  std::lock_guard<std::mutex> lk(h->res_mu);
-  size_t free_b = 0, total_b = 0;
-  if (!(h->res_V && h->res_V_count >= vsz)) {
-    if (h->res_V) hipFree(h->res_V);
-    h->res_V = nullptr;
-    h->res_V_count = 0;
-    void* p = nullptr;
-    // leave room for the matrix, its layouts and the work vectors: reserve only what leaves a quarter of the device free
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || vsz * sizeof(double) + total_b / 4 > free_b) return LZ_OK;
-    if (hipMalloc(&p, vsz * sizeof(double)) != hipSuccess) {
-      (void)hipGetLastError();
-      return LZ_OK;  // not an error: basis_alloc allocates (and reports) itself
-    }
-    h->res_V = static_cast<double*>(p);
-    h->res_V_count = vsz;
-  }
-  if (with_ritz && !(h->res_Y && h->res_Y_count >= ysz)) {
-    if (h->res_Y) hipFree(h->res_Y);
-    h->res_Y = nullptr;
-    h->res_Y_count = 0;
-    void* p = nullptr;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || ysz * sizeof(double) + total_b / 4 > free_b) return LZ_OK;
-    if (hipMalloc(&p, ysz * sizeof(double)) != hipSuccess) {
-      (void)hipGetLastError();
-      return LZ_OK;
-    }
-    h->res_Y = static_cast<double*>(p);
-    h->res_Y_count = ysz;
-  }
-  return LZ_OK;
-}
-
-// ---- the run -----------------------------------------------------------------------
-int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double* beta_out) {
-  if (!h) return LZ_ERR_ARG;
-  if (!v0_local || !alpha_out || !beta_out) return fail(h, LZ_ERR_ARG, "lz_run: NULL buffer");
-  if (n < 2) return fail(h, LZ_ERR_ARG, "lz_run: n must be >= 2 (the reference's beta array has n-1 entries)");
-  if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run: n cannot be larger than M");
-  const bool dbg = getenv("LZ_DEBUG_TIMING") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = now();
-  LZ_TRY(basis_alloc(h, n, 1));
-  h->halo_inflight_j = -1;
-  h->y_n = 0;  // the Ritz vectors of an earlier run are not this run's: fetches answer LZ_ERR_STATE until lz_ritz_vectors is called again
-  const double t1 = now();
-  LZ_TRY(upload(h, h->d_V, v0_local, (size_t)h->rows * sizeof(double)));
-  const double t2 = now();
-  LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
-  h->host_syncs = 0;
-  const Loop loop = choose_loop(h, n);
-  const bool one_reduce = loop == LOOP_ONE_REDUCE;
-  int sweeps = n;
-  h->last_engine = (int)loop;
-  switch (loop) {
-#ifdef LZ_KBENCH
-    case LOOP_SMALL_ENGINE:
-    case LOOP_SMALL_STEP: {
-      bool ran = false;
-      LZ_TRY(run_small_engine(h, n, v0_local, loop == LOOP_SMALL_STEP, &ran));
-      if (!ran) {  // the engine refused (placement / barrier timeout): nothing is lost, the plain loop repeats the run
-        h->last_engine = LOOP_SIX;
-        LZ_TRY(run_loop_six(h, n, &sweeps));
-      }
-      break;
-    }
-#endif
-    case LOOP_FUSED_SMALL: LZ_TRY(run_loop_fused_small(h, n)); break;
-    case LOOP_THREE_TERM_FUSED: LZ_TRY(run_loop_three_term_fused(h, n)); break;
-    case LOOP_ONE_REDUCE: LZ_TRY(run_loop_onereduce(h, n)); break;
-    case LOOP_PARTIAL_DEVICE: LZ_TRY(run_loop_partial_device(h, n)); break;
-    default: LZ_TRY(run_loop_six(h, n, &sweeps)); break;
-  }
-  h->last_sweeps = sweeps;
-  h->r_state = (h->last_engine == LOOP_SIX || h->last_engine == LOOP_PARTIAL_DEVICE) ? 1
-               : (h->last_engine == LOOP_FUSED_SMALL || h->last_engine == LOOP_THREE_TERM_FUSED) ? 2 : 0;
-  h->prof_iter = true;
-  LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
-  const double t3 = now();
-  h->run_timed = true;
-  LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  double onered_bad = 0.0;
-  if (one_reduce) LZ_HIP(h, hipMemcpyAsync(&onered_bad, h->d_nrm2 + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  std::vector<int> sweep_log;
-  if (loop == LOOP_PARTIAL_DEVICE) {
-    sweep_log.resize(omega_state_ints(n));
-    LZ_HIP(h, hipMemcpyAsync(sweep_log.data(), h->d_omi, sweep_log.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  }
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  if (loop == LOOP_PARTIAL_DEVICE) account_partial_device(h, n, sweep_log, &h->last_sweeps);
-  if (one_reduce && onered_bad != 0.0) {
-    // cancellation guard of the one-reduce loop (k_onereduce_prepare): |r|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u lost too
-    // many digits at some step (|alpha| >> beta).  Every rank sees the same reduced sums, so every rank takes this branch:
-    // the solve is repeated on the default loop (two all-reduces per iteration), whose coefficients hold the bar.
-    h->run_timed = false;
-    const int keep = h->flags;
-    h->flags &= ~LZ_FLAG_ONE_REDUCE;
-    const int rc = lz_run(h, n, v0_local, alpha_out, beta_out);
-    h->flags = keep;
-    h->last_engine = LOOP_ONE_REDUCE_REPEATED;
-    return rc;
-  }
-  if (dbg)
-    fprintf(stderr, "[lz_run] alloc+memset %.3f ms, v0 upload %.3f ms, enqueue loop %.3f ms, drain+D2H %.3f ms\n", t1 - t0, t2 - t1,
-            t3 - t2, now() - t3);
-  {
-    float ms = 0.f;
-    LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
-    h->acc.total_ms += ms;
-    h->run_timed = false;
-  }
-  return breakdown_status(h, n, alpha_out, beta_out);
-}
-
-/* ---- checkpoint / resume ("Optional: dump (alpha, beta, j, V[:j])") ---------------------------------- */
-int lz_get_residual(lz_handle h, double* r_local) {
-  if (!h || !r_local) return LZ_ERR_ARG;
-  LZ_TRY(require_basis(h, 0));
-  LZ_HIP(h, hipSetDevice(h->dev));
-  const int n = h->n;
-  if (h->r_state == 2) {
-    // the three- / five-launch loops leave y = A v_{n-1} behind: their three-term recurrence rides in the NEXT step's pass 1.
-    // Form r = (y - alpha_{n-1} v_{n-1}) - beta_{n-2} v_{n-2} now, with the same kernel and expression (Lanczos.py:119).
-    Scope sc(h, LZ_K_THREE, 32.0 * (double)h->rows, 6.0 * (double)h->rows);
-    launch_three_term(h->d_r, h->d_V + (int64_t)(n - 1) * h->ldv, n >= 2 ? h->d_V + (int64_t)(n - 2) * h->ldv : nullptr, h->d_alpha + (n - 1),
-                      h->d_beta + (n >= 2 ? n - 2 : 0), h->rows_pad, h->d_part, h->stream);
-    LZ_TRY(check_launch(h, "three_term(residual)"));
-    h->r_state = 1;
-  }
-  if (h->r_state != 1)
-    return fail(h, LZ_ERR_STATE, "lz_get_residual: the last run left no residual (run lz_run first; not after the one-reduce loop or lz_run_two_sided)");
-  LZ_HIP(h, hipMemcpyAsync(r_local, h->d_r, (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  return LZ_OK;
-}
-
-int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_in, const double* r_local, const double* alpha_in,
-                  const double* beta_in, double* alpha_out, double* beta_out) {
-  if (!h) return LZ_ERR_ARG;
-  if (!V_rows || !r_local || !alpha_in || !beta_in || !alpha_out || !beta_out) return fail(h, LZ_ERR_ARG, "lz_run_resume: NULL buffer");
-  if (j0 < 1 || n <= j0) return fail(h, LZ_ERR_ARG, "lz_run_resume: need 1 <= j0 < n (j0 completed steps, n in total)");
-  if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run_resume: n cannot be larger than M");
-  if (ldv_in < h->rows) return fail(h, LZ_ERR_ARG, "lz_run_resume: ldv_in < rows_local");
-  if (h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE))
-    return fail(h, LZ_ERR_STATE, "lz_run_resume: not with partial re-orthogonalisation (its omega-recurrence lives on the host) or the one-reduce loop");
-  LZ_TRY(basis_alloc(h, n, 1));
-  h->halo_inflight_j = -1;
-  h->y_n = 0;
-  LZ_TRY(upload2d(h, h->d_V, (size_t)h->ldv * sizeof(double), V_rows, (size_t)ldv_in * sizeof(double), (size_t)h->rows * sizeof(double), (size_t)j0));
-  LZ_TRY(upload(h, h->d_r, r_local, (size_t)h->rows * sizeof(double)));
-  LZ_HIP(h, hipMemcpyAsync(h->d_alpha, alpha_in, (size_t)j0 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (j0 > 1) LZ_HIP(h, hipMemcpyAsync(h->d_beta, beta_in, (size_t)(j0 - 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
-  int sweeps = n - j0;
-  h->last_engine = LOOP_SIX;  // every loop structure gives the same bits (tests/test_gpu_small.py): the plain one takes a start step
-  LZ_TRY(run_loop_six(h, n, &sweeps, j0));
-  h->last_sweeps = sweeps;
-  h->r_state = 1;
-  h->prof_iter = true;
-  LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
-  LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  float ms = 0.f;
-  LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
-  h->acc.total_ms += ms;
-  return breakdown_status(h, n, alpha_out, beta_out);
-}
-
-// ---- two-sided (bi-orthogonal) Lanczos ------------------------------------------------------------------------------
-}  // extern "C"
-
-namespace {
-
-double* bi_base(lz_handle h, int which) {  // 0 = Q (the published basis), 1 = P, 2 = Qb, 3 = Pb
-  return which == 0 ? h->d_V : h->d_B3 + (size_t)(which - 1) * (size_t)h->n * (size_t)h->ldv;
-}
-double* bi_row(lz_handle h, int which, int j) { return bi_base(h, which) + (int64_t)j * h->ldv; }
-// d_bi[7] doubles as the ticket counter of the single-launch A/B arm (tune[11] == 2: the last block folds the partials
-// behind a __threadfence()).  Measured (tools/two_sided_probe.py, profiles/r01/ab_two_sided_links.json): the agent-scope
-// release has to write back the L2 lines the kernel just dirtied, which costs far more than the launch it saves - 157
-// vs 41 ms at M = 2.6e5, 250 vs 98 ms at M = 1e6, 178 vs 75 ms at M = 1e7, a tie at M = 9e4.  Default: two launches.  (A third arm, the fold deferred into the
-// consumer's prologue, tune[11] == 3, is no faster either: see bi_reorth.)
-#ifdef LZ_KBENCH
-unsigned* bi_ticket(lz_handle h) { return h->tune[11] == 2 ? reinterpret_cast<unsigned*>(h->d_bi + 7) : nullptr; }
-bool bi_defer(lz_handle h) { return h->tune[11] == 3; }
-#else  // both arms are retired from the product library (lz_set_tuning refuses knob 11 >= 2)
-unsigned* bi_ticket(lz_handle) { return nullptr; }
-bool bi_defer(lz_handle) { return false; }
-#endif
-
-int bi_alloc(lz_handle h, int n, int zero_rows) {
-  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "two-sided Lanczos needs a CSR matrix (lz_set_csr)");
-  if (h->world > 1) return fail(h, LZ_ERR_STATE, "two-sided Lanczos is single-rank only");
-  if (h->rows != h->ncols_ext || h->rows != h->Mg) return fail(h, LZ_ERR_STATE, "two-sided Lanczos needs the whole square matrix on this rank");
-  LZ_TRY(basis_alloc(h, n, zero_rows));
-  const size_t one = (size_t)n * (size_t)h->ldv;
-  if (!h->d_B3 || h->bi_n != n) {
-    LZ_TRY(dev_alloc(h, h->d_B3, 3 * one));
-    LZ_TRY(dev_alloc(h, h->d_s, (size_t)h->ldv));
-    LZ_TRY(dev_alloc(h, h->d_gamma, (size_t)n + 1));
-    LZ_TRY(dev_alloc(h, h->d_bi, 8));
-    h->bi_n = n;
-  }
-  LZ_TRY(ensure_part(h, (size_t)2 * bi_partials_needed()));  // two partial buffers: a link whose fold is deferred leaves its partials for its consumer
-  const size_t zr = (size_t)std::min(zero_rows, n) * (size_t)h->ldv * sizeof(double);
-  for (int w = 1; w < 4; ++w) LZ_HIP(h, hipMemsetAsync(bi_base(h, w), 0, zr, h->stream));
-  LZ_HIP(h, hipMemsetAsync(h->d_s, 0, (size_t)h->ldv * sizeof(double), h->stream));
-  LZ_HIP(h, hipMemsetAsync(h->d_gamma, 0, ((size_t)n + 1) * sizeof(double), h->stream));
-  LZ_HIP(h, hipMemsetAsync(h->d_bi, 0, 8 * sizeof(double), h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  return LZ_OK;
-}
-
-// IrrLanczos.py:408-441 on row jj (>= 1).  from_rs: the pair is formed here as (r / beta, s / gamma) with the factors the
-// two-term kernel left in f (driver loop :136-137); otherwise rows jj of Q and P are taken as stored (step API).
-int bi_reorth(lz_handle h, int jj, bool from_rs) {
-  const int64_t len = h->rows_pad;
-  double* S = h->d_bi;
-  double* f = h->d_bi + 4;
-  unsigned* tk = bi_ticket(h);
-  double *q = bi_row(h, 0, jj), *p = bi_row(h, 1, jj), *qb = bi_row(h, 2, jj), *pb = bi_row(h, 3, jj);
-  const double M = (double)h->rows;
-  Scope sc(h, LZ_K_QTW, (2.0 * jj * 64.0 + 5.0 * 32.0) * M, (2.0 * jj * 12.0) * M);
-  // A/B arm (tune[11] == 3): a link's four sums are not folded by a launch of their own - the link leaves its block
-  // partials in one of two buffers and the NEXT link (which applies the axpy they decide) folds them in its prologue, in
-  // k_bi_final's order: one launch per link instead of two, same bits.  Measured (tests/test_gpu_two_sided.py, device
-  // time): 0.81-0.92x - a dependent launch costs ~4 us here and the emulated fold (16 shuffle trees per block) as much,
-  // so the separate fold kernel stays the default.
-  const bool defer = bi_defer(h) && !tk;
-  double* pbuf[2] = {h->d_part, h->d_part + bi_partials_needed()};
-  int cur = 0;  // buffer the next link writes its partials to
-  const double* pend = nullptr;  // where the previous link's deferred partials are
-  auto link = [&](int first, int pnd, int dots, double* x, double* y, const double* xs, const double* ys, const double* ff, const double* ap,
-                  const double* bp, const double* a, const double* b, int epi) {
-    launch_bi(first, pnd, dots, x, y, xs, ys, ff, ap, bp, S, a, b, len, pbuf[cur], epi, S, f, nullptr, nullptr, tk, h->stream, pnd ? pend : nullptr,
-              defer);
-    pend = (defer && dots == 0) ? pbuf[cur] : nullptr;
-    cur ^= 1;
-  };
-  if (jj == 0) {
-    // j = 0 (the static method's own call shape; the driver starts at j = 1): both projection loops are empty - rescale the pair
-    // to q.p = +-1 (:418-420) and seed the two orthonormal bases with it (:423-424, 437-438)
-    link(0, 0, 1, q, p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
-    link(1, 0, 2, q, p, q, p, f, nullptr, nullptr, nullptr, nullptr, 2);
-    link(1, 0, 2, qb, pb, q, p, f, nullptr, nullptr, nullptr, nullptr, 2);
-    link(1, 0, 3, qb, pb, qb, pb, f, nullptr, nullptr, nullptr, nullptr, 2);
-    return check_launch(h, "bireorthogonalize(j = 0)");
-  }
-  // project q on the orthonormalised p's and p on the orthonormalised q's, one vector at a time (:409-416)
-  for (int i = 0; i < jj; ++i) {
-    const double *a = bi_row(h, 3, i), *b = bi_row(h, 2, i);
-    if (i == 0)
-      link(from_rs ? 1 : 0, 0, 0, q, p, h->d_r, h->d_s, f, nullptr, nullptr, a, b, 0);
-    else
-      link(0, 1, 0, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, i - 1), bi_row(h, 2, i - 1), a, b, 0);
-  }
-  // last axpy + q.p  ->  f = {sqrt|q.p|, sqrt|q.p|, sign(q.p)}; rescale so that q.p = +-1 (:418-420) + the two norms
-  link(0, 1, 1, q, p, nullptr, nullptr, nullptr, bi_row(h, 3, jj - 1), bi_row(h, 2, jj - 1), nullptr, nullptr, 1);
-  link(1, 0, 2, q, p, q, p, f, nullptr, nullptr, nullptr, nullptr, 2);
-  // q_basis[jj] = q / |q|, p_basis[jj] = p / |p| (:423-424), made orthogonal to the earlier basis vectors (:427-434)
-  for (int i = 0; i < jj; ++i) {
-    const double *a = bi_row(h, 2, i), *b = bi_row(h, 3, i);
-    if (i == 0)
-      link(1, 0, 0, qb, pb, q, p, f, nullptr, nullptr, a, b, 0);
-    else
-      link(0, 1, 0, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, i - 1), bi_row(h, 3, i - 1), a, b, 0);
-  }
-  link(0, 1, 2, qb, pb, nullptr, nullptr, nullptr, bi_row(h, 2, jj - 1), bi_row(h, 3, jj - 1), nullptr, nullptr, 2);
-  link(1, 0, 3, qb, pb, qb, pb, f, nullptr, nullptr, nullptr, nullptr, 2);  // :437-438
-  return check_launch(h, "bireorthogonalize");
-}
-
-}  // namespace
-
-extern "C" {
-
-int lz_set_csr_transpose(lz_handle h, int64_t nnz, const int32_t* rowptr, const int32_t* colidx, const double* vals) {
-  if (!h) return LZ_ERR_ARG;
-  if (h->kind != 1) return fail(h, LZ_ERR_STATE, "lz_set_csr_transpose: call lz_set_csr first");
-  if (h->world > 1 || h->rows != h->Mg || h->ncols_ext != h->rows)
-    return fail(h, LZ_ERR_STATE, "lz_set_csr_transpose: needs the whole square matrix on one rank");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  if (!rowptr) {
-    h->has_T = false;
-    h->T_declared = true;
-    return LZ_OK;
-  }
-  if (nnz < 0 || nnz >= (int64_t)1 << 31 || (nnz > 0 && (!colidx || !vals))) return fail(h, LZ_ERR_ARG, "lz_set_csr_transpose: bad nnz or NULL arrays");
-  int fixed_k = 0, max_nnz = 0;
-  h->has_T = false;
-  h->T_declared = false;
-  LZ_TRY(upload_csr(h, h->csrT, "lz_set_csr_transpose", h->rows, h->rows, nnz, rowptr, colidx, vals, &fixed_k, &max_nnz));
-  LZ_TRY(fill_csr_meta(h, h->csrT, rowptr, h->rows, h->rows, nnz, fixed_k, max_nnz));
-  h->has_T = true;
-  h->T_declared = true;
-  return LZ_OK;
-}
-
-int lz_bi_alloc(lz_handle h, int n) {
-  if (!h) return LZ_ERR_ARG;
-  if (n < 1) return fail(h, LZ_ERR_ARG, "n must be >= 1");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  return bi_alloc(h, n, n);
-}
-
-static int bi_check_row(lz_handle h, int which, int j) {
-  if (!h->d_V || !h->d_B3 || h->bi_n != h->n) return fail(h, LZ_ERR_STATE, "no two-sided bases allocated (lz_bi_alloc / lz_run_two_sided)");
-  if (which < 0 || which > 3 || j < 0 || j >= h->n) return fail(h, LZ_ERR_ARG, "basis selector or row index out of range");
-  return LZ_OK;
-}
-
-int lz_bi_set_row(lz_handle h, int which, int j, const double* row) {
-  if (!h || !row) return LZ_ERR_ARG;
-  LZ_TRY(bi_check_row(h, which, j));
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipMemcpyAsync(bi_row(h, which, j), row, (size_t)h->rows * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  return LZ_OK;
-}
-
-int lz_bi_get_row(lz_handle h, int which, int j, double* row) {
-  if (!h || !row) return LZ_ERR_ARG;
-  LZ_TRY(bi_check_row(h, which, j));
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, hipMemcpyAsync(row, bi_row(h, which, j), (size_t)h->rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  return LZ_OK;
-}
-
-int lz_step_bireorth(lz_handle h, int j) {
-  if (!h) return LZ_ERR_ARG;
-  LZ_TRY(bi_check_row(h, 0, j));
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_TRY(bi_reorth(h, j, false));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  return LZ_OK;
-}
-
-int lz_step_bireorth_mem_safe(lz_handle h, int j) {
-  if (!h) return LZ_ERR_ARG;
-  LZ_TRY(bi_check_row(h, 0, j));
-  LZ_HIP(h, hipSetDevice(h->dev));
-  // IrrLanczos.py:399-403 then :405-409: V1[j] against the rows of V2, then V2[j] against the rows of V1 (its row j already
-  // updated).  The n coefficients of a half live in d_gamma (n + 1 doubles, idle in the step API).
-  launch_bi_mem_safe(bi_row(h, 0, j), bi_base(h, 1), h->ldv, h->n, j, h->rows_pad, h->d_gamma, h->stream);
-  launch_bi_mem_safe(bi_row(h, 1, j), bi_base(h, 0), h->ldv, h->n, j, h->rows_pad, h->d_gamma, h->stream);
-  LZ_TRY(check_launch(h, "bireorthogonalize (mem_safe)"));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  return LZ_OK;
-}
-
-int lz_run_two_sided(lz_handle h, int n, const double* q0, const double* p0, double* alpha_out, double* beta_out, double* gamma_out) {
-  if (!h) return LZ_ERR_ARG;
-  if (!q0 || !p0 || !alpha_out || !beta_out || !gamma_out) return fail(h, LZ_ERR_ARG, "lz_run_two_sided: NULL buffer");
-  if (n < 2) return fail(h, LZ_ERR_ARG, "lz_run_two_sided: n must be >= 2 (H_eff[0,1] and beta[-1] exist only then)");
-  if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run_two_sided: n cannot be larger than M");
-  if (h->kind == 1 && !h->T_declared)
-    return fail(h, LZ_ERR_STATE, "lz_run_two_sided: call lz_set_csr_transpose first (NULL arrays if H is symmetric)");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_TRY(bi_alloc(h, n, 1));
-  h->y_n = 0;
-  const int64_t len = h->rows_pad;
-  const size_t rowb = (size_t)h->rows * sizeof(double);
-  double* S = h->d_bi;
-  double* f = h->d_bi + 4;
-  unsigned* tk = bi_ticket(h);
-  LZ_HIP(h, hipMemcpyAsync(bi_row(h, 0, 0), q0, rowb, hipMemcpyHostToDevice, h->stream));
-  LZ_HIP(h, hipMemcpyAsync(bi_row(h, 1, 0), p0, rowb, hipMemcpyHostToDevice, h->stream));
-  LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
-  // q_basis[0] = q0 / |q0|, p_basis[0] = p0 / |p0|  (IrrLanczos.py:113-118)
-  launch_bi(0, 0, 2, bi_row(h, 0, 0), bi_row(h, 1, 0), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, len, h->d_part, 2, S,
-            f, nullptr, nullptr, tk, h->stream);
-  launch_bi(1, 0, 3, bi_row(h, 2, 0), bi_row(h, 3, 0), bi_row(h, 0, 0), bi_row(h, 1, 0), f, nullptr, nullptr, nullptr, nullptr, nullptr, len,
-            h->d_part, 2, S, f, nullptr, nullptr, tk, h->stream);
-  LZ_TRY(check_launch(h, "two-sided start"));
-  const CsrDev& AT = h->has_T ? h->csrT : h->csr;
-  const double M = (double)h->rows;
-  for (int j = 0; j + 1 < n; ++j) {
-    double *qj = bi_row(h, 0, j), *pj = bi_row(h, 1, j);
-    {
-      Scope sc(h, LZ_K_SPMV, 2.0 * spmv_bytes(h), 2.0 * spmv_flops(h));
-      launch_spmv_csr(h->csr, qj, h->d_r, qj, h->d_part, h->flags, h->stream);  // r = H q_j   (:124)
-      launch_spmv_csr(AT, pj, h->d_s, pj, h->d_part, h->flags, h->stream);      // s = HT p_j  (:125)
-      LZ_TRY(check_launch(h, "two-sided spmv"));
-    }
-    {
-      Scope sc(h, LZ_K_THREE, (j > 0 ? 112.0 : 64.0) * M, 12.0 * M);
-      // r -= gamma[j-1] q[j-1]; s -= beta[j-1] p[j-1] (at j = 0 both are the reference's zero rows: skipped);
-      // alpha[j] = (p_j . r + q_j . s) / 2  (:128-132)
-      if (j > 0)
-        launch_bi_two_term(1, 0, h->d_r, h->d_s, bi_row(h, 0, j - 1), bi_row(h, 1, j - 1), h->d_gamma + (j - 1), h->d_beta + (j - 1), pj, qj, len,
-                           h->d_part, f, h->d_alpha + j, nullptr, tk, h->stream);
-      else
-        launch_bi_two_term(0, 0, h->d_r, h->d_s, nullptr, nullptr, nullptr, nullptr, pj, qj, len, h->d_part, f, h->d_alpha + j, nullptr, tk, h->stream);
-      // r -= alpha q_j; s -= alpha p_j; w = r . s; beta[j] = sqrt|w|; gamma[j] = w / beta[j]  (:134-141)
-      launch_bi_two_term(1, 1, h->d_r, h->d_s, qj, pj, h->d_alpha + j, h->d_alpha + j, nullptr, nullptr, len, h->d_part, f, h->d_beta + j,
-                         h->d_gamma + j, tk, h->stream);
-      LZ_TRY(check_launch(h, "two-sided recurrence"));
-    }
-    LZ_TRY(bi_reorth(h, j + 1, true));  // q[j+1] = r / beta, p[j+1] = s / gamma, then bireorthogonalize (:142-161)
-  }
-  // alpha[n-1] = q[n-1] . r with the LAST iteration's residual (:163)
-  launch_bi_two_term(0, 2, h->d_r, nullptr, nullptr, nullptr, nullptr, nullptr, bi_row(h, 0, n - 1), nullptr, len, h->d_part, f, h->d_alpha + (n - 1),
-                     nullptr, tk, h->stream);
-  LZ_TRY(check_launch(h, "two-sided last alpha"));
-  LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
-  LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipMemcpyAsync(gamma_out, h->d_gamma, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  float ms = 0.f;
-  LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
-  h->acc.total_ms += ms;
-  h->last_sweeps = n - 1;
-  return LZ_OK;
-}
-
-int lz_get_basis(lz_handle h, double* V_out, int64_t ld) {
-  if (!h || !V_out) return LZ_ERR_ARG;
-  LZ_TRY(require_basis(h, 0));
-  if (ld < h->rows) return fail(h, LZ_ERR_ARG, "lz_get_basis: ld < rows_local");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, V_out, (size_t)ld * sizeof(double), h->d_V, (size_t)h->ldv * sizeof(double),
-                     (size_t)h->rows * sizeof(double), (size_t)h->n));
-  return LZ_OK;
-}
-
-int lz_get_basis_block(lz_handle h, int64_t row0, int64_t nrows, double* V_out, int64_t ld) {
-  if (!h || !V_out) return LZ_ERR_ARG;
-  LZ_TRY(require_basis(h, 0));
-  if (row0 < 0 || nrows < 1 || row0 + nrows > h->rows || ld < nrows) return fail(h, LZ_ERR_ARG, "lz_get_basis_block: bad row range or ld < nrows");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, V_out, (size_t)ld * sizeof(double), h->d_V + row0, (size_t)h->ldv * sizeof(double),
-                     (size_t)nrows * sizeof(double), (size_t)h->n));
-  return LZ_OK;
-}
-
-}  // extern "C"
-
-namespace {
-
-// ---- Ritz back-transform: resident or chunked -----------------------------------------------------------------------
-// rows [r0, r0 + nr) of Y = V^T-layout x S into `dst` (row-major, leading dimension n).  r0 is a multiple of 16 (the
-// S-stationary kernel moves whole 16-row tiles of V with 16-byte LDS-DMA pieces); dst needs round_up(nr, 16) + 16 rows.
-int ritz_rows_into(lz_handle h, int64_t r0, int64_t nr, double* dst) {
-  const int n = h->y_n;
-  Scope sc(h, LZ_K_RITZ, 16.0 * n * (double)nr + 8.0 * n * n, 2.0 * (double)nr * n * n);
-  LZ_HIP(h, launch_ritz_gemm(h->d_V + r0, h->ldv, nr, n, h->d_S, h->s_npad, dst, n, h->stream, h->tune[9],
-                             reinterpret_cast<unsigned long long*>(h->d_rclk)));
-  return check_launch(h, "ritz_gemm");
-}
-
-// columns [c0, c0 + nc) of Y for ALL rows into `dst` (rows x ldy): the chunked mode's way to hand whole Ritz vectors to
-// the quality sums (A y_i needs every row of y_i) without ever holding all n of them
-int ritz_cols_into(lz_handle h, int c0, int nc, double* dst, int64_t ldy) {
-  const int n = h->y_n;
-  Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)h->y_rows + 8.0 * nc * (double)h->y_rows, 2.0 * (double)h->y_rows * n * nc);
-  launch_ritz_gemm_cols(h->d_V, h->ldv, h->y_rows, n, h->d_S + c0, h->s_npad, nc, dst, ldy, h->stream);
-  return check_launch(h, "ritz_gemm(columns)");
-}
-
-}  // namespace
-
-extern "C" {
-
-int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
-  if (!h || !S) return LZ_ERR_ARG;
-  LZ_TRY(require_basis(h, 0));
-  LZ_HIP(h, hipSetDevice(h->dev));
-  const int n = h->n;
-  const int npad = (int)round_up(n, 16);
-  std::vector<double> Sp((size_t)npad * npad, 0.0);
-  for (int k = 0; k < n; ++k) memcpy(&Sp[(size_t)k * npad], S + (size_t)k * n, (size_t)n * sizeof(double));
-  if (!h->d_S || h->s_npad != npad) {
-    LZ_TRY(dev_alloc(h, h->d_S, Sp.size() + 64));
-    h->s_npad = npad;
-  }
-  if (!h->d_rclk) LZ_TRY(dev_alloc(h, h->d_rclk, 8 + 256));
-  LZ_HIP(h, hipMemsetAsync(h->d_rclk, 0, (8 + 256) * sizeof(uint64_t), h->stream));
-  LZ_HIP(h, hipMemsetAsync(h->d_rclk + 4, 0xFF, sizeof(uint64_t), h->stream));  // [4], [6]: min over waves of their entry tick
-  LZ_HIP(h, hipMemsetAsync(h->d_rclk + 6, 0xFF, sizeof(uint64_t), h->stream));
-  LZ_HIP(h, hipMemcpyAsync(h->d_S, Sp.data(), Sp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));  // Sp is a local
-  // Resident when all of Y fits beside the basis (with 1 GiB to spare for the Gram partials and the runtime), else chunked.
-  // tune[16] > 0 forces the chunked mode with that many rows per chunk (tests).
-  const size_t full = y_doubles(h->rows, n);
-  bool chunked = h->tune[16] > 0;
-  size_t free_b = 0, total_b = 0;
-  {
-    std::lock_guard<std::mutex> lk(h->res_mu);
-    if (h->res_Y && !chunked && h->res_Y_count >= full && !(h->d_Y && !h->y_chunked && h->y_cap >= (int64_t)full)) {
-      hipFree(h->d_Y);  // (a smaller or chunked buffer of an earlier call)
-      h->d_Y = h->res_Y;
-      h->y_cap = (int64_t)h->res_Y_count;
-      h->y_chunked = false;
-      h->res_Y = nullptr;
-      h->res_Y_count = 0;
-    }
-  }
-  if (!chunked && !(h->d_Y && !h->y_chunked && h->y_cap >= (int64_t)full)) {
-    LZ_TRY(dev_free(h, h->d_Y));
-    h->y_cap = 0;
-    LZ_HIP(h, hipMemGetInfo(&free_b, &total_b));
-    // what has to stay free beside Y: lz_ritz_gram's scratch (K-slice partials + G; 0.25 GB at n = 200, 4 GB at n = 1000 on the
-    // split-K path) plus 512 MB for the runtime and the quality sums
-    const size_t gram_need = (std::max<size_t>(gram_scratch_doubles(n) / ((size_t)n * n), 512) + 2) * (size_t)n * n * sizeof(double);
-    chunked = full * sizeof(double) + gram_need + ((size_t)512 << 20) > free_b;
-  }
-  h->y_rows = h->rows;
-  h->y_n = n;
-  if (!chunked) {
-    if (!h->d_Y || h->y_cap < (int64_t)full) {
-      LZ_TRY(dev_alloc(h, h->d_Y, full));
-      h->y_cap = (int64_t)full;
-    }
-    h->y_chunked = false;
-    h->y_chunk = h->rows;
-    LZ_TRY(ritz_rows_into(h, 0, h->rows, h->d_Y));
-    if (Y_out) {
-      const size_t bytes = (size_t)h->rows * n * sizeof(double);
-      LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, Y_out, bytes, h->d_Y, bytes, bytes, 1));
-    } else {
-      LZ_HIP(h, hipStreamSynchronize(h->stream));
-    }
-    return LZ_OK;
-  }
-  // chunked: a bounded buffer (at most 4 GiB, at most a quarter of what is free), whole 16-row tiles
-  int64_t chunk = h->tune[16] > 0 ? h->tune[16] : 0;
-  if (chunk == 0) {
-    LZ_TRY(dev_free(h, h->d_Y));
-    h->y_cap = 0;
-    LZ_HIP(h, hipMemGetInfo(&free_b, &total_b));
-    const size_t budget = std::min<size_t>((size_t)4 << 30, free_b / 4);
-    chunk = (int64_t)(budget / ((size_t)n * sizeof(double)));
-    if (chunk < 4096) return fail(h, LZ_ERR_NOMEM, "lz_ritz_vectors: no device memory left for even a 4096-row chunk of Ritz vectors");
-  }
-  chunk = std::min<int64_t>(round_up(chunk, 16), round_up(h->rows, 16));
-  const size_t need = y_doubles(chunk, n);
-  if (!h->d_Y || h->y_cap < (int64_t)need) {
-    LZ_TRY(dev_alloc(h, h->d_Y, need));
-    h->y_cap = (int64_t)need;
-  }
-  h->y_chunked = true;
-  h->y_chunk = chunk;
-  if (Y_out) return lz_get_ritz_rows(h, 0, h->rows, Y_out);
-  return LZ_OK;
-}
-
-int lz_get_ritz_rows(lz_handle h, int64_t row0, int64_t nrows, double* Y_out) {
-  if (!h || !Y_out) return LZ_ERR_ARG;
-  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_get_ritz_rows: call lz_ritz_vectors first");
-  if (row0 < 0 || nrows < 0 || row0 + nrows > h->y_rows) return fail(h, LZ_ERR_ARG, "lz_get_ritz_rows: row range outside [0, rows_local)");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  const int n = h->y_n;
-  if (!h->y_chunked) {
-    const size_t bytes = (size_t)nrows * n * sizeof(double);
-    LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, Y_out, bytes, h->d_Y + (size_t)row0 * n, bytes, bytes, nrows > 0 ? 1 : 0));
-    return LZ_OK;
-  }
-  if (!h->d_V || h->n != n || h->rows != h->y_rows) return fail(h, LZ_ERR_STATE, "lz_get_ritz_rows: the basis of the run is gone");
-  for (int64_t r = row0 & ~(int64_t)15; r < row0 + nrows; r += h->y_chunk) {
-    // only the 16-row tiles that cover the requested window are re-formed (a 32-row window of C4 used to cost a 4 GiB chunk)
-    const int64_t nr = std::min<int64_t>(std::min<int64_t>(h->y_chunk, round_up(row0 + nrows - r, 16)), h->y_rows - r);
-    LZ_TRY(ritz_rows_into(h, r, nr, h->d_Y));
-    const int64_t a = std::max(r, row0), b = std::min(r + nr, row0 + nrows);
-    const size_t bytes = (size_t)(b - a) * n * sizeof(double);
-    LZ_HIP(h, xfer_d2h(h->dev, h->stream, h->xfer, Y_out + (size_t)(a - row0) * n, bytes, h->d_Y + (size_t)(a - r) * n, bytes, bytes, 1));
-  }
-  return LZ_OK;
-}
-
-int lz_get_ritz_vectors(lz_handle h, double* Y_out) {
-  if (!h || !Y_out) return LZ_ERR_ARG;
-  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_get_ritz_vectors: call lz_ritz_vectors first");
-  return lz_get_ritz_rows(h, 0, h->y_rows, Y_out);
-}
-
-int lz_ritz_info(lz_handle h, int64_t* chunk_rows, double* clock4) {
-  if (!h) return LZ_ERR_ARG;
-  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_ritz_info: call lz_ritz_vectors first");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  if (chunk_rows) *chunk_rows = h->y_chunked ? h->y_chunk : 0;
-  if (clock4) {
-    uint64_t c[8] = {0};
-    if (h->d_rclk) {
-      LZ_HIP(h, hipMemcpyAsync(c, h->d_rclk, sizeof c, hipMemcpyDeviceToHost, h->stream));
-      LZ_HIP(h, hipStreamSynchronize(h->stream));
-    }
-    // [0] shader cycles, [1] ticks of the constant 100 MHz counter, [2] 16-row tiles, [3] MFMAs per tile and SIMD (x 64 = issue floor)
-    clock4[0] = c[1] ? 100.0 * (double)c[0] / (double)c[1] : 0.0;  // shader clock in MHz while the kernel ran
-    clock4[1] = c[2] ? (double)c[0] / (double)c[2] : 0.0;          // shader cycles per 16-row tile
-    // S-in-LDS kernels: the waves of a SIMD are not in lockstep (the oldest wins the issue arbitration and finishes early), so
-    // the honest figure is workgroup 0's whole span (first wave in .. last wave out, S staging included) at the measured clock
-    if (c[7] > c[6] && c[6] != 0 && c[6] != ~0ull && c[2]) clock4[1] = (double)(c[7] - c[6]) * clock4[0] / 100.0 / (double)c[2];
-    clock4[2] = (double)c[3] / 4.0 * 64.0;                         // MFMA issue floor per tile: (MFMAs per tile / 4 SIMDs) x 64 cycles; c[3] holds 4x the per-SIMD count
-    clock4[3] = (double)c[2];
-    if (getenv("LZ_DEBUG_TIMING") && c[5] > c[4] && c[4] != ~0ull) {
-      fprintf(stderr, "[lz_ritz_info] kernel-internal span (first wave in .. last wave out) %.1f us; wave 0's tile loop %.1f us\n",
-              (double)(c[5] - c[4]) * 0.01, (double)c[1] * 0.01);
-      std::vector<uint64_t> wg(256);
-      if (hipMemcpy(wg.data(), h->d_rclk + 8, 256 * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
-        fprintf(stderr, "[lz_ritz_info] workgroup exit times (us after the first wave in), by workgroup id:");
-        for (int i = 0; i < 256; ++i) {
-          if (i % 16 == 0) fprintf(stderr, "\n   ");
-          fprintf(stderr, " %6.1f", wg[i] > c[4] ? (double)(wg[i] - c[4]) * 0.01 : -1.0);
-        }
-        fprintf(stderr, "\n");
-      }
-    }
-  }
-  return LZ_OK;
-}
-
-int lz_ritz_gram(lz_handle h, double* gram_out) {
-  if (!h || !gram_out) return LZ_ERR_ARG;
-  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_ritz_gram: call lz_ritz_vectors first");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  const int n = h->y_n;
-  const int nz_max = 512;
-  const int64_t nchunks = h->y_chunked ? (h->y_rows + h->y_chunk - 1) / h->y_chunk : 1;
-  if (h->y_chunked && (!h->d_V || h->n != n || h->rows != h->y_rows)) return fail(h, LZ_ERR_STATE, "lz_ritz_gram: the basis of the run is gone");
-  // scratch: the K-slice partials of one chunk (the symmetric kernel's or the split-K TN GEMM's), one n x n slice per chunk
-  // (added in chunk order at the end), G.  Kept in the handle: a 160-250 MB hipMalloc + hipFree per call cost milliseconds.
-  const size_t slices = std::max<size_t>(gram_scratch_doubles(n) / ((size_t)n * n), (size_t)nz_max);
-  const size_t need = (slices + (size_t)nchunks + 1) * (size_t)n * n;
-  if (h->gram_cap < need) {
-    LZ_TRY(dev_alloc(h, h->d_gram, need));
-    h->gram_cap = need;
-  }
-  if (!h->d_gclk) {
-    LZ_TRY(dev_alloc(h, h->d_gclk, 4));
-  }
-  LZ_HIP(h, hipMemsetAsync(h->d_gclk, 0, 4 * sizeof(uint64_t), h->stream));
-  double* part = h->d_gram;
-  double* cpart = part + slices * n * n;
-  double* dG = cpart + (size_t)nchunks * n * n;
-  int rc = LZ_OK;
-  h->gram_sym_last = false;
-  for (int64_t q = 0; q < nchunks && rc == LZ_OK; ++q) {
-    const int64_t r = q * h->y_chunk, nr = std::min<int64_t>(h->y_chunk, h->y_rows - r);
-    if (h->y_chunked) rc = ritz_rows_into(h, r, nr, h->d_Y);
-    if (rc != LZ_OK) break;
-    // flops on the books: the symmetric half, n (n + 1) per row (the full product is 2 n^2; the kernel computes the upper tiles)
-    Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)nr, (double)nr * n * (n + 1.0));
-    if (h->tune[19] != 1 && launch_gram_sym(h->d_Y, n, nr, n, part, cpart + (size_t)q * n * n, h->stream, reinterpret_cast<unsigned long long*>(h->d_gclk))) {
-      h->gram_sym_last = true;
-    } else {
-      const int nz = launch_gram(h->d_Y, n, nr, n, part, nz_max, h->stream);
-      launch_sum_slices(part, nz, (int64_t)n * n, cpart + (size_t)q * n * n, h->stream);
-    }
-    rc = check_launch(h, "gram");
-  }
-  if (rc == LZ_OK) {
-    launch_sum_slices(cpart, (int)nchunks, (int64_t)n * n, dG, h->stream);
-    rc = check_launch(h, "gram(sum)");
-  }
-  if (rc == LZ_OK) rc = comm_allreduce(h, dG, (int64_t)n * n);
-  hipError_t e = hipSuccess;
-  if (rc == LZ_OK) e = hipMemcpyAsync(gram_out, dG, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-  if (rc != LZ_OK) return rc;
-  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_gram: ") + hipGetErrorString(e));
-  return LZ_OK;
-}
-
-int lz_gram_info(lz_handle h, double* info4) {
-  if (!h || !info4) return LZ_ERR_ARG;
-  info4[0] = info4[1] = info4[2] = info4[3] = 0.0;
-  if (!h->d_gclk || !h->gram_sym_last) return LZ_OK;
-  LZ_HIP(h, hipSetDevice(h->dev));
-  uint64_t c[4] = {0};
-  LZ_HIP(h, hipMemcpyAsync(c, h->d_gclk, sizeof c, hipMemcpyDeviceToHost, h->stream));
-  LZ_HIP(h, hipStreamSynchronize(h->stream));
-  info4[0] = c[1] ? 100.0 * (double)c[0] / (double)c[1] : 0.0;  // shader clock in MHz while workgroup 0 ran
-  info4[1] = c[2] ? (double)c[0] / (double)c[2] : 0.0;          // shader cycles per k-step (4 rows of Y) of its wave 0
-  info4[2] = 64.0 * (double)c[3];                               // MFMA issue floor of that: MFMAs per k-step and SIMD x 64 cycles
-  info4[3] = (double)c[2];
-  return LZ_OK;
-}
-
-int lz_ritz_quality(lz_handle h, double* out) {
-  if (!h || !out) return LZ_ERR_ARG;
-  if (!h->d_Y || h->y_n < 1) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: call lz_ritz_vectors first");
-  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: no matrix set");
-  LZ_HIP(h, hipSetDevice(h->dev));
-  const int n = h->y_n;
-  // Chunked mode: whole Ritz vectors are formed a batch of columns at a time (Yb = V^T-layout x S[:, c0:c0+nb], all rows)
-  // and handed to the same kernels with ldy = nb.
-  double* Yb = nullptr;
-  int nb = n;
-  int64_t ldy = n;
-  if (h->y_chunked) {
-    if (!h->d_V || h->n != n || h->rows != h->y_rows) return fail(h, LZ_ERR_STATE, "lz_ritz_quality: the basis of the run is gone");
-    size_t free_b = 0, total_b = 0;
-    LZ_HIP(h, hipMemGetInfo(&free_b, &total_b));
-    const size_t per_col = (size_t)(round_up(h->y_rows, 16) + 16) * sizeof(double);
-    int64_t fit = (int64_t)((free_b > ((size_t)1 << 30) ? free_b - ((size_t)1 << 30) : 0) / 2 / per_col);
-    if (h->tune[16] > 0) fit = 16;  // test knob: the smallest batch
-    nb = (int)std::min<int64_t>(round_up(n, 16), fit / 16 * 16);
-    if (nb < 16) return fail(h, LZ_ERR_NOMEM, "lz_ritz_quality: no device memory left for a 16-column batch of Ritz vectors");
-    ldy = nb;
-    LZ_TRY(dev_alloc(h, Yb, (size_t)(round_up(h->y_rows, 16) + 16) * nb + 64));
-  }
-  std::vector<double> sums(2 * (size_t)n);
-  int rc = LZ_OK;
-  hipError_t e = hipSuccess;
-  if (h->world > 1 || h->tune[6] || h->kind == 2) {
-    // Row-block partition (and dense matrices on any number of ranks: the fused kernel below walks CSR rows): z = A y_i needs
-    // the neighbours' entries of y_i, so every Ritz vector takes the path a Lanczos
-    // vector takes - copied into basis row 0 (saved and restored), exchanged (halo or all-gather), multiplied by the
-    // SpMV kernel, whose epilogue already delivers y_i . z; ||z||^2 from the three-term kernel with zero coefficients.
-    // One all-reduce of the 2 n sums at the end.
-    if (!h->d_V || h->n < 1 || h->y_rows != h->rows) rc = fail(h, LZ_ERR_STATE, "lz_ritz_quality: the basis of the run is gone");
-    if (rc == LZ_OK && (size_t)2 * n > (size_t)2 * qtw_ldp(h->n + 2) + 8) rc = fail(h, LZ_ERR_STATE, "lz_ritz_quality: coefficient buffer too small");
-    if (rc != LZ_OK) {
-      hipFree(Yb);
-      return rc;
-    }
-    double* v0 = h->d_V;
-    double* save = nullptr;  // basis row 0 is borrowed; in chunked mode the batches are formed from the INTACT basis first
-    e = hipMemcpyAsync(h->d_r2, v0, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
-    (void)save;
-    if (e == hipSuccess) e = hipMemsetAsync(h->d_nrm2, 0, 2 * sizeof(double), h->stream);
-    h->halo_inflight_j = -1;
-    for (int c0 = 0; c0 < n && rc == LZ_OK && e == hipSuccess; c0 += nb) {
-      const int nc = std::min(nb, n - c0);
-      const double* Ysrc = h->d_Y;
-      if (h->y_chunked) {
-        e = hipMemcpyAsync(v0, h->d_r2, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream);  // the batch GEMM reads basis row 0
-        if (e != hipSuccess) break;
-        rc = ritz_cols_into(h, c0, nc, Yb, ldy);
-        Ysrc = Yb;
-      }
-      for (int i = 0; i < nc && rc == LZ_OK; ++i) {
-        launch_extract_column(Ysrc, ldy, h->y_chunked ? i : c0 + i, h->rows, h->rows_pad, v0, h->stream);
-        rc = step_spmv(h, 0, h->d_c + c0 + i, false);
-        if (rc != LZ_OK) break;
-        const int np = launch_three_term(h->d_r, v0, nullptr, h->d_nrm2, h->d_nrm2, h->rows_pad, h->d_part, h->stream);
-        launch_final_sum(h->d_part, np, h->d_c + n + c0 + i, h->stream);
-        rc = check_launch(h, "ritz_quality(row-block)");
-      }
-    }
-    hipError_t e2 = hipMemcpyAsync(v0, h->d_r2, (size_t)h->ldv * sizeof(double), hipMemcpyDeviceToDevice, h->stream);  // basis row 0 back
-    if (e == hipSuccess) e = e2;
-    if (rc == LZ_OK) rc = comm_allreduce(h, h->d_c, 2 * n);
-    if (rc == LZ_OK && e == hipSuccess) e = hipMemcpyAsync(sums.data(), h->d_c, sums.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(Yb);
-    if (rc != LZ_OK) return rc;
-    if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
-    for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];
-    return LZ_OK;
-  }
-  const size_t nblk = (size_t)((h->rows + 2047) / 2048);
-  double* part = nullptr;
-  rc = dev_alloc(h, part, (nblk + 1) * 2 * (size_t)nb);
-  if (rc != LZ_OK) {
-    hipFree(Yb);
-    return rc;
-  }
-  double* dSums = part + nblk * 2 * (size_t)nb;
-  for (int c0 = 0; c0 < n && rc == LZ_OK && e == hipSuccess; c0 += nb) {
-    const int nc = std::min(nb, n - c0);
-    const double* Ysrc = h->d_Y;
-    if (h->y_chunked) {
-      rc = ritz_cols_into(h, c0, nc, Yb, ldy);
-      Ysrc = Yb;
-      if (rc != LZ_OK) break;
-    }
-    {
-      Scope sc(h, LZ_K_RITZ, 12.0 * h->csr.nnz + 8.0 * nc * (double)h->rows, 2.0 * (double)h->csr.nnz * nc);
-      const int nblocks = launch_ritz_quality(h->csr, Ysrc, ldy, nc, part, h->stream);
-      launch_sum_slices(part, nblocks, 2 * (int64_t)nc, dSums, h->stream);
-      rc = check_launch(h, "ritz_quality");
-    }
-    std::vector<double> two(2 * (size_t)nc);
-    if (rc == LZ_OK) e = hipMemcpyAsync(two.data(), dSums, two.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    for (int i = 0; i < nc; ++i) {
-      sums[(size_t)c0 + i] = two[(size_t)i];
-      sums[(size_t)n + c0 + i] = two[(size_t)nc + i];
-    }
-  }
-  hipFree(part);
-  hipFree(Yb);
-  if (rc != LZ_OK) return rc;
-  if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
-  for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];
   return LZ_OK;
 }
 

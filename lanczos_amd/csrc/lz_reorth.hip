@@ -23,46 +23,21 @@ namespace lz {
 constexpr int kFinalThreads = 1024;
 // sum(part[0..n)) by one block of 1024 threads: four strided accumulators per thread (a full group of four while
 // i + 3 * 1024 < n, the remainder into the first), wave shuffle tree, 16 wave sums added in order.  The grouping is part of
-// the contract (final_sum_emulated in lz_device.h replays it).  Up to 24 576 partials (the headline's SpMV leaves 19 532)
-// every load of a thread is issued before its first add: the partials were written by another kernel on other XCDs, each
-// load is a round trip to the memory side, and the plain loop paid eight of them one after the other (4.7 us for this
-// kernel, now one or two) - same adds in the same order, same bits.  The result is valid in thread 0.
+// the contract (final_sum_emulated in lz_device.h replays it).  The result is valid in thread 0.
+// (Round 4 tried issuing all of a thread's loads - up to 24 - before its first add, on the theory that the ~4.7 us this
+// one-block kernel takes are eight dependent round trips to the memory side: measured 4.85 us instead of 4.69, k_omega 6.0
+// instead of 5.0 (profiles/r04/partial_loop_kernel_stats*.csv) - a one-block kernel this short pays for its instruction
+// fetch, not for its loads; the plain loop is the smaller code and stays.)
 __device__ __forceinline__ double final_sum_1024(const double* __restrict__ part, int n, double* sm) {
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-  constexpr int GMAX = 6;
-  if (n <= GMAX * 4 * kFinalThreads) {
-    double v[GMAX * 4];
-#pragma unroll
-    for (int q = 0; q < GMAX * 4; ++q) {
-      const int idx = threadIdx.x + q * kFinalThreads;
-      v[q] = idx < n ? part[idx] : 0.0;
-    }
-    bool tail = false;
-#pragma unroll
-    for (int g = 0; g < GMAX; ++g) {
-      const int i = threadIdx.x + g * 4 * kFinalThreads;
-      if (!tail && i + 3 * kFinalThreads < n) {
-        a0 += v[4 * g];
-        a1 += v[4 * g + 1];
-        a2 += v[4 * g + 2];
-        a3 += v[4 * g + 3];
-      } else {  // the plain loop's remainder: everything left goes into a0, in index order
-        tail = true;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i + u * kFinalThreads < n) a0 += v[4 * g + u];
-      }
-    }
-  } else {
-    int i = threadIdx.x;
-    for (; i + 3 * kFinalThreads < n; i += 4 * kFinalThreads) {
-      a0 += part[i];
-      a1 += part[i + kFinalThreads];
-      a2 += part[i + 2 * kFinalThreads];
-      a3 += part[i + 3 * kFinalThreads];
-    }
-    for (; i < n; i += kFinalThreads) a0 += part[i];
+  int i = threadIdx.x;
+  for (; i + 3 * kFinalThreads < n; i += 4 * kFinalThreads) {
+    a0 += part[i];
+    a1 += part[i + kFinalThreads];
+    a2 += part[i + 2 * kFinalThreads];
+    a3 += part[i + 3 * kFinalThreads];
   }
+  for (; i < n; i += kFinalThreads) a0 += part[i];
   const double acc = wave_sum((a0 + a1) + (a2 + a3));
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) sm[w] = acc;
@@ -86,7 +61,7 @@ __global__ __launch_bounds__(kFinalThreads) void k_final_sum(const double* __res
 // max_k |omega_{j,k}| exceeds sqrt(eps), on that vector and the next.  One block; called once per step, AFTER the three-term
 // kernel of step jn - 1 (optionally folding that kernel's ||r||^2 partials first, with k_final_sum's exact grouping), it leaves
 // the gate of step jn in ist[0].  The sweep kernels and the SpMV of step jn read the gate: lz_run never waits for the device.
-// Arithmetic: expression for expression the host loop this replaces (run_loop_six, lz_api.hip; both compiled with
+// Arithmetic: expression for expression the host loop this replaces (run_loop_six, lz_loops.hip; both compiled with
 // -ffp-contract=off, IEEE sqrt and division), every k is independent and the maximum does not depend on the order, so the
 // decisions - and with them every coefficient - are bit-identical to the host-decided run (tests/test_gpu_lanczos.py).
 // State layout: see omega_state_doubles (lz_internal.h).

@@ -218,7 +218,7 @@ static int launch_spmv_fixed(const CsrDev& A, const double* x, double* y, const 
 // k-th gathers of a wave are one contiguous run of x, and the row sum is formed in registers in CSR order (sum += a * x,
 // unfused: SciPy's bits) - no LDS staging of the products, no barrier before the alpha reduction.  All of a lane's loads
 // are issued before the first gather, all gathers before the first use.  Blocks are padded with (value 0, column 0).
-//   SC (the device-resident partial re-orthogonalisation loop, lz_api.hip): x = r / beta is formed per gathered entry
+//   SC (the device-resident partial re-orthogonalisation loop, lz_loops.hip): x = r / beta is formed per gathered entry
 //   when no sweep ran on this vector (see SpmvScale), and the block stores the rows it owns to V[j].
 template <typename T>
 __device__ __forceinline__ T ld_nt(const T* p) {

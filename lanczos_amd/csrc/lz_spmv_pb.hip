@@ -1,5 +1,5 @@
 // Column-blocked two-phase SpMV for CSR matrices WITHOUT column locality (random graphs: BASELINE config C3).
-// Selected by lz_set_csr for such matrices (lz_api.hip; lz_set_tuning(h, 14, 1) switches it off, 2 forces it); y is
+// Selected by lz_set_csr for such matrices (lz_matrix.hip; lz_set_tuning(h, 14, 1) switches it off, 2 forces it); y is
 // bit-identical to SciPy's csr_matvec (tests/test_gpu_kernels.py).
 //
 // Why.  r = A v with random columns is a gather of nnz 8-byte values out of a vector that fits no cache (C3: 8e7 gathers

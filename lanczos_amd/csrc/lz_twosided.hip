@@ -58,7 +58,7 @@ __device__ __forceinline__ void bi_epilogue(const double* tot, int K, double* S,
 // epilogue.  __threadfence() is the agent-scope release/acquire pair that makes the partials written on other XCDs
 // (separate, non-coherent L2s) visible.  Saves the second dependent launch of every link of the chain, but the release
 // writes back every L2 line the kernel dirtied, which measured 2-4x slower than the extra launch: A/B arm only (see
-// bi_ticket() in lz_api.hip); the same result kept the main path's second-stage reductions as separate kernels.
+// bi_ticket() in lz_twosided_api.hip); the same result kept the main path's second-stage reductions as separate kernels.
 template <int EPI>
 __device__ __forceinline__ void bi_last_block_final(unsigned* ticket, const double* part, int NB, int K, double* S, double* f,
                                                     double* o0, double* o1, double* sm) {

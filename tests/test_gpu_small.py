@@ -147,7 +147,7 @@ def test_device_scope_arm_is_bit_identical_too(hip, kb):
 
 
 def test_loop_selection(hip, kb):
-    """choose_loop (lz_api.hip) through lz_last_engine: the product library knows three loops + one-reduce; the retired
+    """choose_loop (lz_loops.hip) through lz_last_engine: the product library knows three loops + one-reduce; the retired
     engines answer only in the kernel-bench build, and only where they apply."""
     rag = load_golden("ragged_M700_n25")[1]  # a 700-entry row: one lane per row would be a chain of dependent loads
     assert _run(kb, rag, 25, engine_off=False)[3] == "kernels"
