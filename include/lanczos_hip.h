@@ -128,7 +128,8 @@ int lz_set_options(lz_handle h, int flags);
  *       2 ELL for every SpMV, one row per lane and trip, 3 ELL, two adjacent rows per lane (16-byte loads)
  *   19  Gram matrix of the Ritz vectors: 0 auto (accumulator-stationary symmetric kernel where it applies), 1 the split-K TN GEMM always
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
- *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta)
+ *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta),
+ *       3 device-resident with pass 1's second-stage sums as a kernel of their own (default: pass 1's last block adds them)
  * The product library returns LZ_ERR_ARG for everything that lives only in the kernel-bench build (make KBENCH=1 ->
  * liblanczos_kbench.so, loaded by tools/ and by the tests of those arms): the timing-only ablation arms (knob 1 >= 20,
  * knob 3) and the A/B arms retired in round 3 because they measured slower - the one-kernel and one-launch-per-step engines

@@ -50,7 +50,8 @@ TUNE_LOOP = 15              # loop structure (0 auto, 1 six launches per step al
 TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 forces it)
 TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto: CSR order, ELL only in the partial loop; 1 never ELL; 2 / 3 ELL always, one / two rows per lane)
 TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel, 1 split-K TN GEMM)
-TUNE_PARTIAL_LOOP = 18      # partial re-orthogonalisation loop (0 device-resident, 1 host-decided, 2 device-resident without the fused scale)
+TUNE_PARTIAL_LOOP = 18      # partial re-orthogonalisation loop (0 device-resident, 1 host-decided, 2 device-resident without the fused scale,
+                            # 3 device-resident with a separate second-stage kernel behind pass 1)
 
 KERNEL_CLASSES = ("spmv", "qtw", "update", "three_term", "final", "comm", "ritz")
 K_COUNT = len(KERNEL_CLASSES)

@@ -141,6 +141,8 @@ struct QtwFuse {
   double* alpha_out = nullptr;
   double* r_out = nullptr;        // where r goes (NOT y itself: with the row split several blocks read the same slice of y)
   const int* gate = nullptr;      // any mode: the kernel returns at once when gate[0] == 0 (device-resident partial re-orthogonalisation)
+  unsigned* ticket = nullptr;     // mode 1: the last block to finish also adds up all blocks' runs into c_out (k_final_rows_t's order)
+  double* c_out = nullptr;
 };
 // returns the error of the per-kernel LDS-limit raise (hipFuncSetAttribute), if that was needed and failed
 hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* r, const double* nrm2,

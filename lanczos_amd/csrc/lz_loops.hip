@@ -534,9 +534,10 @@ int run_loop_partial_device(lz_handle h, int n) {
   const double M = (double)h->rows;
   if (h->om_n < n) {
     LZ_TRY(dev_alloc(h, h->d_om, omega_state_doubles(n)));
-    LZ_TRY(dev_alloc(h, h->d_omi, omega_state_ints(n)));
+    LZ_TRY(dev_alloc(h, h->d_omi, omega_state_ints(n) + 1));  // (+ the ticket of pass 1's folded second stage)
     h->om_n = n;
   }
+  LZ_HIP(h, hipMemsetAsync(h->d_omi + omega_state_ints(n), 0, sizeof(int), h->stream));
   const int* gate = h->d_omi;
   const bool one_rank = h->world <= 1 && !(h->tune[6] && h->comm_kind);
   if (one_rank && h->kind == 1 && h->tune[18] != 2 && h->tune[17] != 1 && !h->csr.ell_rb && !h->csr.pb &&
@@ -582,13 +583,20 @@ int run_loop_partial_device(lz_handle h, int n) {
     {
       QtwFuse fz;
       fz.gate = gate;
+      // pass 1's last block adds the blocks' runs itself (k_final_rows_t's order: same bits): one gated launch less per step.
+      // (tune[18] == 3: the separate second-stage kernel, A/B)
+      const bool fold = h->tune[18] != 3;
+      if (fold) {
+        fz.ticket = reinterpret_cast<unsigned*>(h->d_omi + omega_state_ints(n));
+        fz.c_out = h->d_c;
+      }
       h->qplan.variant = 0;
       {
         Scope sc(h, LZ_K_QTW, 0, 0);
         LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, j + 1, j, rcur, h->d_nrm2, h->d_beta + bidx, h->qplan, h->d_part, 1, h->stream, &fz));
         LZ_TRY(check_launch(h, "qtw(gated)"));
       }
-      {
+      if (!fold) {
         Scope sc(h, LZ_K_FINAL, 0, 0);
         launch_final_rows(h->d_part, j + 1, h->qplan.P, h->d_c, h->stream, true, gate);
         LZ_TRY(check_launch(h, "final_rows(gated)"));

@@ -628,6 +628,52 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
     }
     __builtin_nontemporal_store(((k0[i] + k0[run + i]) + k0[2 * run + i]) + k0[3 * run + i], mine + i);
   }
+  // Device-resident partial re-orthogonalisation (fz.ticket != nullptr; SCALE == 1, no row split): the block that finishes LAST
+  // adds up every block's run itself - k_final_rows_t's additions in k_final_rows_t's order, so c has the same bits - which
+  // saves that kernel's launch in the 99 % of steps where this kernel returns at its first line.  The release / acquire
+  // pair around the ticket costs more than the launch it replaces (the two-sided links measured 2-4x), but only a step that
+  // really sweeps pays it.
+  if constexpr (SCALE == 1) {
+    if (fz.ticket != nullptr) {
+      __shared__ unsigned s_last;
+      __threadfence();  // this block's run is visible device-wide before its ticket is
+      __syncthreads();  // (and every wave is done with the LDS image)
+      if (threadIdx.x == 0) s_last = atomicAdd(fz.ticket, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;
+      __syncthreads();
+      if (s_last) {
+        __threadfence();  // the other blocks' runs
+        double* smf = reinterpret_cast<double*>(sw);  // [128][8] doubles of the (now free) slice image
+        constexpr int S = kFinalThreads / 8;
+        const int P = (int)gridDim.x;
+        for (int g8 = 0; g8 < (nrows + 7) / 8; ++g8) {
+#pragma unroll
+          for (int q = 0; q < kFinalThreads / kTPB; ++q) {  // a 256-thread block plays k_final_rows_t's 1024 threads
+            const int vt = threadIdx.x + q * kTPB;
+            const int rl = vt & 7, pl = vt >> 3;
+            const double* p = part + (g8 * 8 + rl);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int pid = pl;
+            for (; pid + 3 * S < P; pid += 4 * S) {
+              a0 += p[(int64_t)pid * ldp];
+              a1 += p[(int64_t)(pid + S) * ldp];
+              a2 += p[(int64_t)(pid + 2 * S) * ldp];
+              a3 += p[(int64_t)(pid + 3 * S) * ldp];
+            }
+            for (; pid < P; pid += S) a0 += p[(int64_t)pid * ldp];
+            smf[pl * 8 + rl] = (a0 + a1) + (a2 + a3);
+          }
+          __syncthreads();
+          if (threadIdx.x < 8 && g8 * 8 + (int)threadIdx.x < nrows) {
+            double t = 0.0;
+            for (int k = 0; k < S; ++k) t += smf[k * 8 + threadIdx.x];
+            fz.c_out[g8 * 8 + threadIdx.x] = t;
+          }
+          __syncthreads();
+        }
+        if (threadIdx.x == 0) fz.ticket[0] = 0u;  // ready for the next sweep
+      }
+    }
+  }
 }
 
 // LDS bytes left for ONE slice of w in the default (4x4x4 MFMA) kernel: a block stages ncol slices and parks ncol sets of four
@@ -692,7 +738,8 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
   if (plan.family == 2) {
     const int ncol = SCALE == 3 ? 2 : 1;
     const int ldp = qtw_ldp(SCALE == 3 ? nrows + 2 : nrows);
-    const size_t lds4 = ncol * (lds + (size_t)(kTPB / 64) * ldp * sizeof(double));  // slice(s) of w + the four waves' coefficient runs
+    size_t lds4 = ncol * (lds + (size_t)(kTPB / 64) * ldp * sizeof(double));  // slice(s) of w + the four waves' coefficient runs
+    if (fz.ticket) lds4 = std::max<size_t>(lds4, (size_t)kFinalThreads * sizeof(double));  // the folded second stage's [128][8] image
     // row split for short vectors (see the kernel): only where the slices alone leave most of the chip idle, and only in
     // the modes whose staging stores nothing that other blocks of the same slice would race on
     dim3 grid2 = grid;

@@ -364,7 +364,7 @@ def test_partial_reorthogonalisation_opt_in(build, n):
     # (knob 18 = 2; with an ELL-ordered stencil matrix the SpMV forms v_j = r / beta itself).
     h = part._get_handle()
     assert h.last_engine() == "partial-device" and h.last_host_syncs() == 0
-    for knob in (1, 2):
+    for knob in (1, 2, 3):  # 3: device loop with the separate second-stage kernel of pass 1 (default: folded into pass 1's last block)
         other = Lanczos(H)
         other.reorth = "partial"
         other._get_handle().set_tuning(_capi.TUNE_PARTIAL_LOOP, knob)
