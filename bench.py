@@ -427,13 +427,15 @@ def main():
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.isfile(traffic_file):  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
             try:
-                measured = json.load(open(traffic_file)).get(args.workload, {})
+                traffic_all = json.load(open(traffic_file))
+                measured = traffic_all.get(args.workload, {})
+                stamp = traffic_all.get(args.workload + "_measured", "taken in round 2, kernels unchanged since")
                 for name, v in measured.items():
                     if name in per_class:
                         per_class[name]["traffic"] = v
                         # NOT a counter of this run: HBM bytes per launch from separate `rocprofv3 --pmc` passes of the same
                         # command (FETCH_SIZE / WRITE_SIZE, corrected as the guide prescribes), kept in profiles/
-                        per_class[name]["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc passes of this workload; static copy)"
+                        per_class[name]["traffic_source"] = f"profiles/hbm_traffic.json (rocprofv3 --pmc passes of this workload; static copy; {stamp})"
             except Exception:
                 pass
         line = {

@@ -31,6 +31,7 @@ out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path
 fetch, write = per_class(fdir, "FETCH_SIZE"), per_class(wdir, "WRITE_SIZE")
 data = json.load(open(out)) if os.path.isfile(out) else {}
 data[workload] = {c: round(2 * 1024 * fetch[c][0] + 1024 * write.get(c, (0, 0))[0]) for c in fetch}
+data[workload + "_measured"] = os.environ.get("LZ_TRAFFIC_STAMP", "undated")  # which round / date / tree these passes were taken on
 data[workload + "_detail"] = {c: {"read_bytes": round(2 * 1024 * fetch[c][0]), "write_bytes": round(1024 * write.get(c, (0, 0))[0]), "launches": fetch[c][1]} for c in fetch}
 json.dump(data, open(out, "w"), indent=1)
 print(json.dumps(data[workload + "_detail"], indent=1))

@@ -15,6 +15,6 @@ for k, cs in acc.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in o and o.get("GRBM_GUI_ACTIVE"):
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs
         o["mfma_util_pct"] = 100.0 * o["SQ_VALU_MFMA_BUSY_CYCLES"] / (o["GRBM_GUI_ACTIVE"] / 8.0 * 1024)
-    if "mfma" in k or "gemm" in k:
+    if "mfma" in k or "gemm" in k or "gram" in k:
         out[k] = o
 print(json.dumps(out, indent=1))
