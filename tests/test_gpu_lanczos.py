@@ -382,6 +382,35 @@ def test_partial_reorthogonalisation_opt_in(build, n):
     assert np.abs(R[:, :-1]).max() < 1e-6 * max(scale, 1.0)
 
 
+def test_repeated_default_start_vector_is_cached_and_the_global_rng_ends_where_the_reference_leaves_it():
+    """Lanczos.py:93-97 seeds the GLOBAL legacy RNG and draws M doubles on every call.  A repeated call with the same (seed, M)
+    reuses the cached normalised vector (the draw is the whole overhead of a second call at the headline size) - same results bit
+    for bit - and restores the RNG state saved right after the first draw, so the caller's next np.random draw is what it would be
+    after the reference's call."""
+    H = synthetic.laplacian_2d_5pt(60, 50).to_scipy()
+    M = H.shape[0]
+    Lanczos.verbose = False
+    s = Lanczos(H)
+    s.execute_Lanczos(20, seed=7)
+    after_first = np.random.uniform()
+    first = s.H_eff.copy()
+    np.random.seed(12345)  # the caller does something else with the global RNG in between
+    s.execute_Lanczos(20, seed=7)
+    after_second = np.random.uniform()
+    np.random.seed(7)
+    np.random.uniform(-1, 1, size=(M))
+    expected = np.random.uniform()
+    assert after_first == expected and after_second == expected
+    assert np.array_equal(s.H_eff, first)
+    s.execute_Lanczos(20, seed=8)  # another seed: a fresh draw
+    assert not np.array_equal(s.H_eff, first)
+    s.execute_Lanczos(20, seed=7, v0=np.ones(M))  # explicit v0: the RNG is seeded, nothing is drawn (Lanczos.py:93, 98-99)
+    x = np.random.uniform()
+    np.random.seed(7)
+    assert x == np.random.uniform()
+    s.close()
+
+
 def test_randomised_shapes_against_oracle():
     """30 random symmetric matrices of awkward shapes (M = 5 ... 12345 incl. non-multiples of every tile size, n up to
     M, dense / banded / ragged sparse): recurrence coefficients and Ritz values vs the CPU oracle, Y = V S."""
