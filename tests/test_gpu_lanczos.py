@@ -382,6 +382,49 @@ def test_partial_reorthogonalisation_opt_in(build, n):
     assert np.abs(R[:, :-1]).max() < 1e-6 * max(scale, 1.0)
 
 
+def test_partial_loops_agree_bit_for_bit_on_awkward_shapes(hip):
+    """The device-decided partial re-orthogonalisation loop against the host-decided one (knob 18 = 1) through the C ABI on 24
+    random shapes: stencils whose row count is no multiple of any block size (the fused r / beta over the ELL copy, ragged last
+    block), ragged CSR, dense, n from 2 to 60 - alpha, beta, basis, number of sweeps and the sweep log's count, all np.array_equal;
+    no host synchronisation in the device loop."""
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        kind = ("lap2d", "lap3d", "ragged", "dense")[trial % 4]
+        if kind == "lap2d":
+            A = synthetic.laplacian_2d_5pt(int(rng.integers(5, 90)), int(rng.integers(5, 90)))
+            M, setm = A.shape[0], lambda h, A=A: h.set_csr(A.shape[0], 0, A.rowptr, A.colidx, A.vals)
+        elif kind == "lap3d":
+            A = synthetic.laplacian_3d_7pt(int(rng.integers(3, 20)), int(rng.integers(3, 20)), int(rng.integers(3, 20)))
+            M, setm = A.shape[0], lambda h, A=A: h.set_csr(A.shape[0], 0, A.rowptr, A.colidx, A.vals)
+        elif kind == "ragged":
+            M = int(rng.integers(40, 3000))
+            R = scipy.sparse.random(M, M, density=min(0.3, 8.0 / M), random_state=rng, format="csr")
+            S = (R + R.T + scipy.sparse.diags(rng.standard_normal(M))).tocsr()
+            S.sort_indices()
+            setm = lambda h, S=S, M=M: h.set_csr(M, 0, S.indptr, S.indices, S.data)
+        else:
+            M = int(rng.integers(20, 400))
+            D = synthetic.dense_symmetric(M, seed=trial)
+            setm = lambda h, D=D: h.set_dense(D)
+        n = int(min(M, rng.integers(2, 61)))
+        v0 = rng.uniform(-1, 1, M)
+        v0 /= np.linalg.norm(v0)
+        out = []
+        for knob in (0, 1):
+            h = hip.Handle(0)
+            h.set_tuning(hip.TUNE_PARTIAL_LOOP, knob)
+            h.set_options(hip.FLAG_REORTH_PARTIAL | hip.FLAG_FUSED_NORM)
+            setm(h)
+            a, b = h.run(n, v0)
+            out.append((a, b, h.get_basis(), h.last_sweeps(), h.last_engine(), h.last_host_syncs()))
+            h.close()
+        (a0, b0, V0, s0, e0, y0), (a1, b1, V1, s1, e1, y1) = out
+        tag = f"{kind} M={M} n={n}"
+        assert e0 == "partial-device" and y0 == 0 and e1 == "kernels" and y1 >= n, tag
+        assert s0 == s1 and 1 <= s0 <= n, tag
+        assert np.array_equal(a0, a1, equal_nan=True) and np.array_equal(b0, b1, equal_nan=True) and np.array_equal(V0, V1, equal_nan=True), tag
+
+
 def test_repeated_default_start_vector_is_cached_and_the_global_rng_ends_where_the_reference_leaves_it():
     """Lanczos.py:93-97 seeds the GLOBAL legacy RNG and draws M doubles on every call.  A repeated call with the same (seed, M)
     reuses the cached normalised vector (the draw is the whole overhead of a second call at the headline size) - same results bit
