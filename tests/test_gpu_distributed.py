@@ -55,7 +55,7 @@ WORKER = textwrap.dedent('''
         if name == "graph_twophase":
             assert s.h.spmv_plan() == "two-phase"
         if name == "dense_poison":
-            s.h.set_tuning(13, 1)
+            s.h.set_tuning(_capi.TUNE_POISON_BASIS, 1)
         a, bta = s.execute_Lanczos(n)
         sweeps = s.h.last_sweeps()
         device_built_equal = None
@@ -75,12 +75,12 @@ WORKER = textwrap.dedent('''
             # the CHUNKED Ritz mode on a row-block partition (what a rank does when a second rows x n array does not fit beside its
             # basis): Y re-formed in 512-row chunks, Gram matrix accumulated per chunk and all-reduced, quality sums from column batches
             G0 = s.h.ritz_gram()
-            s.h.set_tuning(16, 512)
+            s.h.set_tuning(_capi.TUNE_RITZ_CHUNK_ROWS, 512)
             s.get_H_eigs()
             Yc, Gc, qc = s.H_eigvecs_local, s.h.ritz_gram(), s.ritz_quality()
             chunked = dict(rows=s.h.ritz_info()["chunk_rows"], dY=float(np.abs(Yc - Y).max()), dG=float(np.abs(Gc - G0).max()),
                            dq=float(np.abs(qc - qual).max()), basis_ok=bool(np.array_equal(s.V_local, V)))
-            s.h.set_tuning(16, 0)
+            s.h.set_tuning(_capi.TUNE_RITZ_CHUNK_ROWS, 0)
             s.get_H_eigs()
         # single-rank oracle on the full matrix
         full = build(0, M)
@@ -169,7 +169,7 @@ def test_rccl_single_rank_communicator():
     a0, b0 = h0.run(20, v0)
     h = _capi.Handle(0)
     h.comm_init_rccl(1, 0, h.unique_id())
-    h.set_tuning(6, 1)  # issue the collectives although world == 1
+    h.set_tuning(_capi.TUNE_FORCE_COLLECTIVES, 1)  # issue the collectives although world == 1
     h.set_csr(M, 0, A.rowptr, A.colidx, A.vals, ncols_ext=h.padded_rows(M))
     h.set_allgather(h.padded_rows(M))
     a1, b1 = h.run(20, v0)
@@ -215,7 +215,7 @@ def test_rccl_self_send_recv_halo(faces, overlap):
     col[wrap] = rows_pad + np.searchsorted(ghost_cols, A.colidx[wrap])
     h = _capi.Handle(0)
     h.comm_init_rccl(1, 0, h.unique_id())
-    h.set_tuning(6, 1)
+    h.set_tuning(_capi.TUNE_FORCE_COLLECTIVES, 1)
     if overlap:  # LZ_FLAG_OVERLAP_HALO: faces updated first, exchanged on a second stream behind the interior update
         h.set_options(_capi.FLAG_OVERLAP_HALO)
     h.set_csr(M, 0, A.rowptr, col.astype(np.int32), A.vals, ncols_ext=rows_pad + len(ghost_cols))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import scipy.sparse
 
-from lanczos_amd import synthetic
+from lanczos_amd import synthetic, _capi
 
 pytestmark = pytest.mark.gpu
 
@@ -120,7 +120,7 @@ def test_spmv_two_phase_bit_exact(hip, name):
     H = MATS[name] if name in MATS else _two_phase_matrices()[name]
     M = H.shape[0]
     h = hip.Handle(0)
-    h.set_tuning(14, 2)
+    h.set_tuning(_capi.TUNE_SPMV_PLAN, 2)
     h.set_csr(M, 0, H.indptr, H.indices, H.data)
     assert h.spmv_plan() == ("csr-stream" if name == "row_too_long" else "two-phase")
     x = np.random.default_rng(1).uniform(-1, 1, M)
@@ -176,7 +176,7 @@ def test_two_phase_spmv_in_the_run_loop(hip):
     out = []
     for knob in (1, 2):
         h = hip.Handle(0)
-        h.set_tuning(14, knob)
+        h.set_tuning(_capi.TUNE_SPMV_PLAN, knob)
         h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
         a, b = h.run(50, v0)
         out.append((a, b, h.get_basis()))
@@ -310,8 +310,8 @@ def test_two_phase_layouts_of_different_size_coexist(hip):
     y1 = A1.to_scipy() @ x1
     assert np.array_equal(h1.spmv_host(x1), y1)
     h2 = hip.Handle(0)
-    h2.set_tuning(14, 2)
-    h2.set_tuning(10, 3000)
+    h2.set_tuning(_capi.TUNE_SPMV_PLAN, 2)
+    h2.set_tuning(_capi.TUNE_PB_ENTRIES, 3000)
     h2.set_csr(A2.shape[0], 0, A2.rowptr, A2.colidx, A2.vals)
     assert h2.spmv_plan() == "two-phase"
     x2 = np.random.default_rng(2).standard_normal(A2.shape[0])
@@ -344,7 +344,7 @@ def test_two_phase_spmv_with_duplicate_diagonal_entries(hip):
     B = scipy.sparse.csr_matrix((np.concatenate(out_val), np.concatenate(out_idx), np.array(out_ptr)), shape=A.shape)
     assert B.nnz == A.nnz + 50 and not B.has_canonical_format
     h = hip.Handle(0)
-    h.set_tuning(14, 2)
+    h.set_tuning(_capi.TUNE_SPMV_PLAN, 2)
     h.set_csr(B.shape[0], 0, B.indptr, B.indices, B.data)
     assert h.spmv_plan() == "two-phase"
     x = np.random.default_rng(3).standard_normal(B.shape[0])

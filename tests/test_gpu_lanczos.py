@@ -580,7 +580,7 @@ def test_retired_ritz_gemm_arms_in_the_kernel_bench_build(kb, variant, dims, n):
     per SIMD, 32-row tiles, S through LDS; 6 (n <= 128): the 16-row-tile form of the S-in-LDS kernel, superseded by the 32-row
     form - all measured slower than the defaults, kept correct."""
     h = kb.Handle(0)
-    h.set_tuning(9, variant)
+    h.set_tuning(_capi.TUNE_RITZ_KERNEL, variant)
     V, S = _ritz_case(h, dims, n)
     np.testing.assert_allclose(h.ritz_vectors(S), V.T @ S, rtol=0, atol=1e-13)
     h.close()
@@ -605,7 +605,7 @@ def test_ritz_backtransform_kernels(hip, variant, dims, n):
     v0 = synthetic.reference_start_vector(M)
     v0 /= np.linalg.norm(v0)
     h = hip.Handle(0)
-    h.set_tuning(9, variant)
+    h.set_tuning(_capi.TUNE_RITZ_KERNEL, variant)
     h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
     a, b = h.run(n, v0)
     V = h.get_basis()
@@ -624,7 +624,7 @@ def test_ritz_backtransform_kernels(hip, variant, dims, n):
     else:
         assert info["tiles"] == 0
     # the same vectors re-formed in row chunks (what BASELINE C4 needs on one GPU: no room for a second M x n array)
-    h.set_tuning(16, 20000)
+    h.set_tuning(_capi.TUNE_RITZ_CHUNK_ROWS, 20000)
     h.ritz_vectors(S, fetch=False)
     assert h.ritz_info()["chunk_rows"] == 20000
     np.testing.assert_allclose(h.ritz_fetch(), Y, rtol=0, atol=1e-13)
@@ -633,7 +633,7 @@ def test_ritz_backtransform_kernels(hip, variant, dims, n):
     Gc = h.ritz_gram()
     assert np.abs(Gc - G).max() < 1e-13
     q_chunked = h.ritz_quality()
-    h.set_tuning(16, 0)
+    h.set_tuning(_capi.TUNE_RITZ_CHUNK_ROWS, 0)
     h.ritz_vectors(S, fetch=False)
     assert np.abs(q_chunked - h.ritz_quality()).max() <= 1e-12
     h.close()

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from lanczos_amd import Lanczos, synthetic
+from lanczos_amd import Lanczos, synthetic, _capi
 
 pytestmark = pytest.mark.gpu
 
@@ -34,7 +34,7 @@ def _run(hip, H, n, engine_off, flags=None, knob=None):
     h = hip.Handle(0)
     h.set_options(hip.FLAG_FUSED_NORM if flags is None else flags)
     # knob 15: 0 = default (fused three-launch path where it applies), 1 = plain six-launch path, 2 = one-kernel engine (opt-in)
-    h.set_tuning(15, knob if knob is not None else (1 if engine_off else 2))
+    h.set_tuning(_capi.TUNE_LOOP, knob if knob is not None else (1 if engine_off else 2))
     if scipy.sparse.issparse(H):
         A = H.tocsr()
         h.set_csr(A.shape[0], 0, A.indptr, A.indices, A.data)
@@ -137,7 +137,7 @@ def test_device_scope_arm_is_bit_identical_too(hip, kb):
     a1, b1, V1, e1, t1 = _run(hip, H, n, engine_off=True)
     h = kb.Handle(0)
     h.set_options(hip.FLAG_FUSED_NORM)
-    h.set_tuning(15, 3)
+    h.set_tuning(_capi.TUNE_LOOP, 3)
     h.set_dense(H)
     v0 = synthetic.reference_start_vector(512)
     v0 /= np.linalg.norm(v0)

@@ -12,7 +12,7 @@ import scipy.sparse
 import pytest
 
 from conftest import GOLDEN_DIR, load_golden, two_sided_names
-from lanczos_amd import IrrLanczos, synthetic
+from lanczos_amd import IrrLanczos, synthetic, _capi
 from oracle import two_sided_ref as ts
 
 pytestmark = pytest.mark.gpu
@@ -237,7 +237,7 @@ def test_deferred_fold_links_are_bit_identical(build, n, kb):
             s._handle = kb.Handle(0)
             s._handle_devices = ((0,), s.comm_backend)
         s.execute_Lanczos(3, seed=4)  # creates the handle (and loads the code objects)
-        s._handle.set_tuning(11, knob)
+        s._handle.set_tuning(_capi.TUNE_BI_LINKS, knob)
         s.execute_Lanczos(n, seed=4)
         s.execute_Lanczos(n, seed=4)
         dt = s._timings["total_ms"] * 1e-3  # device time of that run (host-side set-up of the class excluded)

@@ -21,8 +21,8 @@ x = np.random.default_rng(0).standard_normal(M)
 for arm in ((0, 1, 2, 7) if only not in ("ritz", "sreg") else ()):
     h = _capi.Handle(0)
     h.set_options(_capi.FLAG_PROFILE)
-    h.set_tuning(3, arm)
-    h.set_tuning(14, 2)
+    h.set_tuning(_capi.TUNE_SPMV_ABLATION, arm)
+    h.set_tuning(_capi.TUNE_SPMV_PLAN, 2)
     h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
     h.basis_alloc(2)
     h.basis_set_row(1, x)
@@ -49,7 +49,7 @@ h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
 a, b = h.run(200, v0)
 S = np.linalg.eigh(np.diag(a) + np.diag(b, 1) + np.diag(b, -1))[1]
 for arm in ((0, 5, 20, 21, 22, 23, 5) if only == "sreg" else (0, 2, 3, 4, 5, 0, 5)):
-    h.set_tuning(9, arm)
+    h.set_tuning(_capi.TUNE_RITZ_KERNEL, arm)
     h.ritz_vectors(S, fetch=False)
     h.timings()
     for _ in range(3):

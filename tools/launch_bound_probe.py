@@ -21,7 +21,7 @@ for name, M, n in (("c1_dense512_k20", 512, 20), ("box1d_N500_n50", 500, 50)):
     for knob in (0, 1):
         h = _capi.Handle(0)
         h.set_options(_capi.FLAG_FUSED_NORM)
-        h.set_tuning(15, knob)
+        h.set_tuning(_capi.TUNE_LOOP, knob)
         h.set_dense(H)
         for rep in range(4):
             t = time.perf_counter()

@@ -28,7 +28,7 @@ for name, flags, comm in (("no_comm", 0, False), ("inline", _capi.FLAG_FUSED_NOR
     h = _capi.Handle(0)
     if comm:
         h.comm_init_rccl(1, 0, h.unique_id())
-        h.set_tuning(6, 1)
+        h.set_tuning(_capi.TUNE_FORCE_COLLECTIVES, 1)
         h.set_options(flags)
         h.set_csr(M, 0, A.rowptr, col.astype(np.int32), A.vals, ncols_ext=rows_pad + len(ghost_cols))
         h.set_halo([0, 0], [nx, nx], ghost_cols.astype(np.int32), [nx, nx])

@@ -11,7 +11,7 @@ from lanczos_amd import _capi, synthetic  # noqa: E402
 A = synthetic.random_graph_laplacian(10_000_000, 35_000_000, seed=1234)
 M = A.shape[0]
 h = _capi.Handle(0)
-h.set_tuning(14, 2)
+h.set_tuning(_capi.TUNE_SPMV_PLAN, 2)
 h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
 assert h.spmv_plan() == "two-phase"
 h.basis_alloc(2)

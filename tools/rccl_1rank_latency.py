@@ -19,7 +19,7 @@ out = {}
 for name, flags in (("unfused", 0), ("fused_norm", _capi.FLAG_FUSED_NORM)):
     h = _capi.Handle(0)
     h.comm_init_rccl(1, 0, h.unique_id())
-    h.set_tuning(6, 1)
+    h.set_tuning(_capi.TUNE_FORCE_COLLECTIVES, 1)
     h.set_options(_capi.FLAG_PROFILE | flags)
     rows_pad = h.padded_rows(M)
     h.set_csr(M, 0, A.rowptr, A.colidx, A.vals, ncols_ext=rows_pad)

@@ -31,7 +31,7 @@ for n in sorted({c[0] for c in cases}):
     for nn, variant in cases:
         if nn != n:
             continue
-        h.set_tuning(9, variant)
+        h.set_tuning(_capi.TUNE_RITZ_KERNEL, variant)
         h.ritz_vectors(S, fetch=False)  # first call of a kernel: code-object load
         h.timings()
         ms = []

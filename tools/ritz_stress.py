@@ -33,7 +33,7 @@ for t in range(trials):
     e1 = float(np.abs(Y - ref).max())
     G = h.ritz_gram()
     chunk = int(rng.integers(1, 40)) * 16 * int(rng.choice([1, 7, 64]))
-    h.set_tuning(16, chunk)
+    h.set_tuning(_capi.TUNE_RITZ_CHUNK_ROWS, chunk)
     h.ritz_vectors(S, fetch=False)
     lo = int(rng.integers(0, M - 1))
     hi = int(min(M, lo + rng.integers(1, 3000)))

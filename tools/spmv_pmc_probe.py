@@ -16,7 +16,7 @@ for name, dims, pts in CASES:
     h = _capi.Handle(0)
     h.set_options(_capi.FLAG_FUSED_NORM | _capi.FLAG_PROFILE)
     if os.environ.get("LZ_RB"):  # A/B arms of the fixed-K kernel (knob 5)
-        h.set_tuning(5, int(os.environ["LZ_RB"]))
+        h.set_tuning(_capi.TUNE_FIXED_ROWS, int(os.environ["LZ_RB"]))
     if os.environ.get("LZ_LAYOUT"):  # knob 17: 1 CSR-order kernel, 2 ELL one row per lane (default), 3 ELL two rows per lane
         h.set_tuning(_capi.TUNE_FIXED_LAYOUT, int(os.environ["LZ_LAYOUT"]))
     if pts == 7:

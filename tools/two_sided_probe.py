@@ -18,7 +18,7 @@ for (nx, ny, n, arm) in [(1000, 1000, 50, 2), (1000, 1000, 50, 1), (4000, 2500, 
     s = IrrLanczos(A)
     s.options = _capi.FLAG_PROFILE
     s.execute_Lanczos(4, seed=1)  # warm-up (code objects)
-    s._handle.set_tuning(11, arm)  # 2 = single-launch links (last block folds the partials), 1 = separate fold kernel
+    s._handle.set_tuning(_capi.TUNE_BI_LINKS, arm)  # 2 = single-launch links (last block folds the partials), 1 = separate fold kernel
     s.execute_Lanczos(4, seed=1)
     t0 = time.perf_counter()
     s.execute_Lanczos(n, seed=1)
