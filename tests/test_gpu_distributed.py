@@ -188,6 +188,36 @@ def test_rccl_single_rank_communicator():
     h0.close()
 
 
+def test_partial_loop_over_a_one_rank_rccl_communicator():
+    """The device-decided partial re-orthogonalisation loop on a partition issues its collectives EVERY step (the host cannot
+    skip a collective the device may need): alpha, ||r||^2 and - used or not - the coefficient vector.  Run with real RCCL calls
+    (1-rank communicator, forced through the tuning knob) on a matrix whose Ritz values converge (several sweeps): coefficients,
+    basis and sweep count equal to the plain single-rank run bit for bit, still no host synchronisation inside lz_run."""
+    A = synthetic.laplacian_3d_7pt(20, 18, 16)
+    M = A.shape[0]
+    n = 120
+    v0 = np.random.RandomState(99).uniform(-1, 1, M)
+    v0 /= np.linalg.norm(v0)
+    h0 = _capi.Handle(0)
+    h0.set_options(_capi.FLAG_REORTH_PARTIAL)
+    h0.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    a0, b0 = h0.run(n, v0)
+    V0, s0 = h0.get_basis(), h0.last_sweeps()
+    h = _capi.Handle(0)
+    h.comm_init_rccl(1, 0, h.unique_id())
+    h.set_tuning(_capi.TUNE_FORCE_COLLECTIVES, 1)
+    h.set_options(_capi.FLAG_REORTH_PARTIAL)
+    h.set_csr(M, 0, A.rowptr, A.colidx, A.vals, ncols_ext=h.padded_rows(M))
+    h.set_allgather(h.padded_rows(M))
+    a1, b1 = h.run(n, v0)
+    assert h.last_engine() == "partial-device" and h.last_host_syncs() == 0
+    assert 1 < s0 < n and h.last_sweeps() == s0
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1) and np.array_equal(V0, h.get_basis())
+    assert h.timings()["comm"]["launches"] >= 4 * n  # all-gather + three all-reduces per step
+    h.close()
+    h0.close()
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("faces", ["both", "one"])
 def test_rccl_self_send_recv_halo(faces, overlap):
