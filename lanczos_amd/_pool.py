@@ -42,6 +42,27 @@ def _close_live_pools():
 atexit.register(_close_live_pools)
 
 
+def _copy_parallel(pairs, piece=16 << 20):
+    """dst[...] = src for every pair, in pieces on a few threads (NumPy's copy loops release the GIL)"""
+    jobs = []
+    for dst, src in pairs:
+        d, s_ = dst.reshape(-1), np.asarray(src).reshape(-1)
+        step = max(1, piece // max(d.itemsize, 1))
+        jobs += [(d, s_, o, min(o + step, d.size)) for o in range(0, d.size, step)]
+    if len(jobs) <= 2:
+        for d, s_, lo, hi in jobs:
+            d[lo:hi] = s_[lo:hi]
+        return
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(j):
+        d, s_, lo, hi = j
+        d[lo:hi] = s_[lo:hi]
+
+    with ThreadPoolExecutor(max_workers=max(1, min(6, (os.cpu_count() or 2) // 2))) as ex:
+        list(ex.map(one, jobs))
+
+
 class _Shm:
     """A parent-owned file in /dev/shm holding one array; ``spec`` is what a worker needs to map it."""
 
@@ -300,9 +321,7 @@ class PoolHandle:
     def set_csr(self, M_global, row0, rowptr, colidx, vals, ncols_ext=None, mode="auto"):
         rowptr, colidx, vals = np.asarray(rowptr), np.asarray(colidx), np.asarray(vals, dtype=np.float64)
         with self._seg("rowptr", rowptr.shape, np.int64) as a, self._seg("colidx", colidx.shape, np.int32) as b, self._seg("vals", vals.shape, np.float64) as c:
-            a.arr[...] = rowptr
-            b.arr[...] = colidx
-            c.arr[...] = vals
+            _copy_parallel([(a.arr, rowptr), (b.arr, colidx), (c.arr, vals)])  # (640 MB at the headline: a few threads, not one)
             self._matrix({"kind": "csr", "M": int(M_global), "rowptr": a.spec, "colidx": b.spec, "vals": c.spec, "mode": mode},
                          host_bytes=float(rowptr.nbytes + colidx.nbytes + vals.nbytes))
 
