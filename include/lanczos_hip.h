@@ -124,7 +124,8 @@ int lz_set_options(lz_handle h, int flags);
  *   16  rows per chunk of the CHUNKED Ritz mode (0 auto: chunked only when Y does not fit beside the basis; > 0 forces it: tests)
  *   11  two-sided Gram-Schmidt links (0 / 1: streaming kernel + fold kernel per link)
  *   17  fixed-K (stencil) SpMV layout: 0 auto (CSR-order kernel with products staged through LDS; the ELL-ordered second copy -
- *       a lane owns whole rows - is built and used only by the partial re-orthogonalisation loop's fused SpMV), 1 never ELL,
+ *       a lane owns whole rows - is built and used only by the partial re-orthogonalisation loop's fused SpMV; 27 entries per
+ *       row, which have no CSR-order fixed-K kernel: ELL for every SpMV, 3 % faster than CSR-stream), 1 never ELL,
  *       2 ELL for every SpMV, one row per lane and trip, 3 ELL, two adjacent rows per lane (16-byte loads)
  *   19  Gram matrix of the Ritz vectors: 0 auto (accumulator-stationary symmetric kernel where it applies), 1 the split-K TN GEMM always
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop

@@ -323,7 +323,7 @@ bool small_args(lz_handle h, int n, SmallArgs& sa) {
     const CsrDev& A = h->csr;
     const bool fixed = !(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7);
     // (one lane walks one row in the engine: rows of more than 32 entries would turn into a chain of dependent loads)
-    if (A.pb || A.max_row_nnz > 32 || (fixed && A.fixed_rb != 512)) return false;
+    if (A.pb || A.ell_default || A.max_row_nnz > 32 || (fixed && A.fixed_rb != 512)) return false;  // (the engine replays the CSR kernels' alpha grouping)
     sa.rowptr = A.rowptr;
     sa.colidx = A.colidx;
     sa.vals = A.vals;

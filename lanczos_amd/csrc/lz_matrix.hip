@@ -78,8 +78,12 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   // builds it on first use.  tune[17]: 0 auto (as just said), 1 never (not even for the partial loop), 2 ELL for every SpMV,
   // one row per lane and trip, 3 ELL with two adjacent rows per lane.
   ell_free(A);
-  A.ell_default = h->tune[17] >= 2;  // the plain SpMV takes the ELL copy only on request: measured no faster than the CSR-order kernel
-  if (h->tune[17] >= 2 && (fixed_k == 5 || fixed_k == 7 || fixed_k == 27)) LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
+  // 5 / 7 entries per row: the plain SpMV takes the ELL copy only on request (measured equal to the CSR-order kernel).  27-point
+  // rows have no CSR-order fixed-K kernel - they ran the generic CSR-stream kernel - and there ELL wins: 247.9 vs 256.3 us on the
+  // reference's largest run (deuteron N = 160: 0.710 vs 0.687; the partial loop 223 vs 232 ms with the fused r / beta), so it is
+  // their default (gpurun r4q; +12 bytes per entry of device memory).
+  A.ell_default = h->tune[17] >= 2 || (h->tune[17] == 0 && fixed_k == 27);
+  if (A.ell_default && (fixed_k == 5 || fixed_k == 7 || fixed_k == 27)) LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
   const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
     const hipError_t pe = pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]);
@@ -295,7 +299,7 @@ int lz_spmv_plan(lz_handle h, int* plan) {
   const CsrDev& A = h->csr;
   if (h->flags & LZ_FLAG_SPMV_SCALAR) *plan = 0;
   else if (A.pb && !(h->flags & LZ_FLAG_SPMV_STREAM)) *plan = 3;
-  else if (!(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7)) *plan = 2;
+  else if (!(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7 || (A.ell_default && ell_usable(A, h->flags)))) *plan = 2;
   else *plan = 1;
   return LZ_OK;
 }
