@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "lz_device.h"
 
@@ -1348,6 +1349,144 @@ __global__ __launch_bounds__(kTPB) void k_gram_sym(const double* __restrict__ Y,
   }
 }
 
+// ---- more than 13 column tiles (n > 208; BASELINE config C5: n = 500): the same accumulator-stationary scheme over GROUPS of
+// kGramGS = 11 column tiles.  A workgroup owns a K range AND one unit of the upper triangle of groups: a diagonal unit (the
+// triangle of one group, 66 tiles) or an off-diagonal pair (11 x 11 = 121 tiles).  Within a unit the tiles are dealt to the four
+// waves BY ROW TILE - rows w, w + 4, w + 8 of a pair; a snake over the rows of a triangle (18 / 17 / 16 / 15 tiles) - so that a wave
+// loads only the fragments of its own rows plus the column fragments: 14 loads for 33 MFMAs in a pair (the first, tile-by-tile
+// deal of this round needed 17 loads for 17 MFMAs and was SLOWER than the split-K GEMM it replaces: 96.7 vs 84.9 ms at C5 - the
+// operand fetch, not the matrix pipe, is what this kernel has to economise).  Tile indices are compile-time within a unit; the
+// unit's tile offsets (ta0, tb0) come from a table.  Column tiles at or past ceil(n / 16) (the last group's padding) are loaded
+// from the last real tile - valid memory - and their results are dropped by the store's bounds.
+constexpr int kGramGS = 11;
+constexpr int gram_snake_wave(int row) { return (row / 4) % 2 == 0 ? row % 4 : 3 - row % 4; }  // rows 0 1 2 3 | 3 2 1 0 | 0 1 2 3 ...
+// DIAG: the Q-th tile of wave W walking its rows (snake) in increasing order, each row i over columns i .. NA-1
+constexpr int gram_diag_count(int NA, int W) {
+  int c = 0;
+  for (int i = 0; i < NA; ++i)
+    if (gram_snake_wave(i) == W) c += NA - i;
+  return c;
+}
+constexpr int gram_diag_minrow(int NA, int W) {
+  for (int i = 0; i < NA; ++i)
+    if (gram_snake_wave(i) == W) return i;
+  return NA;
+}
+constexpr int gram_diag_row(int NA, int W, int q) {
+  for (int i = 0; i < NA; ++i)
+    if (gram_snake_wave(i) == W) {
+      if (q < NA - i) return i;
+      q -= NA - i;
+    }
+  return 0;
+}
+constexpr int gram_diag_col(int NA, int W, int q) {
+  for (int i = 0; i < NA; ++i)
+    if (gram_snake_wave(i) == W) {
+      if (q < NA - i) return i + q;
+      q -= NA - i;
+    }
+  return 0;
+}
+template <int NA, int NB, bool DIAG, int W>
+struct GramUnit {
+  static constexpr int RW = (NA - W + 3) / 4;                               // pair: row tiles W, W + 4, ... of group a
+  static constexpr int F0 = DIAG ? gram_diag_minrow(NA, W) : 0;            // triangle: fragments F0 .. NA-1 of the one group
+  static constexpr int NF = DIAG ? NA - F0 : RW + NB;                       // fragments this wave loads per k-step
+  static constexpr int NTW = DIAG ? gram_diag_count(NA, W) : RW * NB;       // tiles it owns
+};
+template <int NA, int NB, bool DIAG, int W, int Q>
+struct GramUnitTile {
+  using U = GramUnit<NA, NB, DIAG, W>;
+  static constexpr int it = DIAG ? gram_diag_row(NA, W, Q) : W + 4 * (Q / NB);  // row tile within group a
+  static constexpr int jt = DIAG ? gram_diag_col(NA, W, Q) : Q % NB;            // column tile within group b (DIAG: group a)
+  static constexpr int fi = DIAG ? it - U::F0 : Q / NB;                          // their fragment slots
+  static constexpr int fj = DIAG ? jt - U::F0 : U::RW + jt;
+};
+template <int NA, int NB, bool DIAG, int W, int NF, int... Q>
+__device__ __forceinline__ void gram_unit_mfmas(const double (&f)[NF], double4_t* acc, std::integer_sequence<int, Q...>) {
+  ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[GramUnitTile<NA, NB, DIAG, W, Q>::fi], f[GramUnitTile<NA, NB, DIAG, W, Q>::fj], acc[Q], 0, 0, 0)), ...);
+}
+template <int NA, int NB, bool DIAG, int W, int Q>
+__device__ __forceinline__ void gram_unit_store_tile(const double4_t& a, int n, int ta0, int tb0, int lr, int lk, double* __restrict__ Cz) {
+  const int col = 16 * (tb0 + GramUnitTile<NA, NB, DIAG, W, Q>::jt) + lr;
+  if (col >= n) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int r = 16 * (ta0 + GramUnitTile<NA, NB, DIAG, W, Q>::it) + lk + 4 * g;
+    if (r < n) Cz[(int64_t)r * n + col] = a[g];
+  }
+}
+template <int NA, int NB, bool DIAG, int W, int... Q>
+__device__ __forceinline__ void gram_unit_store(const double4_t* acc, int n, int ta0, int tb0, int lr, int lk, double* __restrict__ Cz,
+                                                std::integer_sequence<int, Q...>) {
+  (gram_unit_store_tile<NA, NB, DIAG, W, Q>(acc[Q], n, ta0, tb0, lr, lk, Cz), ...);
+}
+
+template <int NA, int NB, bool DIAG, int W>
+__device__ __forceinline__ void gram_unit_wave(const double* __restrict__ Y, int64_t ldy, int64_t k_lo, int64_t k_hi, int n, int CT, int ta0,
+                                               int tb0, double* __restrict__ Cz) {
+  using U = GramUnit<NA, NB, DIAG, W>;
+  constexpr int NTW = U::NTW, NF = U::NF;
+  // k-steps the fragment loads run ahead of the MFMAs: ~4 us worth of matrix-pipe time (a triangle's k-step is 15-18 MFMAs = half a
+  // pair's: with 4 k-steps its loads were 2.3 us ahead and the unit ran at half its MFMA rate - profiles/r04/gram_groups_c5.txt)
+  constexpr int PA = DIAG ? 8 : 4;
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  double4_t acc[NTW > 0 ? NTW : 1];
+#pragma unroll
+  for (int q = 0; q < NTW; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int nsteps = k_hi > k_lo ? (int)((k_hi - k_lo + 3) >> 2) : 0;
+  int off[NF > 0 ? NF : 1];  // element offsets of this wave's fragments within a row (tiles past the last real one alias it)
+#pragma unroll
+  for (int t = 0; t < NF; ++t) {
+    const int tile = DIAG ? ta0 + U::F0 + t : (t < U::RW ? ta0 + W + 4 * t : tb0 + (t - U::RW));
+    off[t] = 16 * (tile < CT ? tile : CT - 1);
+  }
+  double ring[PA][NF > 0 ? NF : 1];
+  auto load = [&](int step, double (&f)[NF > 0 ? NF : 1]) {
+    int64_t kr = k_lo + 4 * (int64_t)step + lk;
+    const bool ok = kr < k_hi;
+    if (!ok) kr = k_hi - 1;
+    const double* row = Y + kr * ldy + lr;
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+      const double v = row[off[t]];
+      f[t] = ok ? v : 0.0;
+    }
+  };
+  if (nsteps > 0) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) load(p < nsteps ? p : nsteps - 1, ring[p]);
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += PA) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int st = s0 + p;
+      if (st < nsteps) {
+        gram_unit_mfmas<NA, NB, DIAG, W, (NF > 0 ? NF : 1)>(ring[p], acc, std::make_integer_sequence<int, NTW>());
+        load(st + PA < nsteps ? st + PA : nsteps - 1, ring[p]);
+      }
+    }
+  }
+  gram_unit_store<NA, NB, DIAG, W>(acc, n, ta0, tb0, lr, lk, Cz, std::make_integer_sequence<int, NTW>());
+}
+
+template <int NA, int NB, bool DIAG>
+__global__ __launch_bounds__(kTPB) void k_gram_unit(const double* __restrict__ Y, int64_t ldy, int64_t rows, int64_t kchunk, int n, int CT,
+                                                   const int2* __restrict__ units, double* __restrict__ part) {
+  const int64_t k_lo = (int64_t)blockIdx.x * kchunk;
+  const int64_t k_hi = k_lo + kchunk < rows ? k_lo + kchunk : rows;
+  double* Cz = part + (int64_t)blockIdx.x * n * n;
+  const int2 u = units[blockIdx.y];  // {first row tile, first column tile}
+  switch (threadIdx.x >> 6) {
+    case 0: gram_unit_wave<NA, NB, DIAG, 0>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+    case 1: gram_unit_wave<NA, NB, DIAG, 1>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+    case 2: gram_unit_wave<NA, NB, DIAG, 2>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+    default: gram_unit_wave<NA, NB, DIAG, 3>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+  }
+}
+
 // out[r][c] = sum_z slice_z[r][c] for the upper 16 x 16 tiles, mirrored into the lower ones (fixed order of z)
 __global__ __launch_bounds__(kTPB) void k_sum_slices_sym(const double* __restrict__ part, int nz, int n, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x;
@@ -1367,11 +1506,16 @@ __global__ __launch_bounds__(kTPB) void k_sum_slices_sym(const double* __restric
 
 // G = Y^T Y into out (n x n, symmetric, complete); `part` = scratch of gram_scratch_doubles(n) doubles.
 // Returns false when the shape is not covered (n > 208 or a handful of rows): the caller takes launch_gram + launch_sum_slices.
-size_t gram_scratch_doubles(int n) { return (size_t)kGramMaxSlices * n * n; }
+// K slices: at most kGramMaxSlices, and no more than ~1 GB of n x n partial slices (n = 1000: 125)
+int gram_max_slices(int n) {
+  const int64_t cap = ((int64_t)1 << 27) / ((int64_t)n * n);
+  return (int)std::max<int64_t>(16, std::min<int64_t>(kGramMaxSlices, cap));
+}
+size_t gram_scratch_doubles(int n) { return (size_t)gram_max_slices(n) * n * n + 4096; }  // (+ the unit table of the grouped form)
 bool launch_gram_sym(const double* Y, int64_t ldy, int64_t rows, int n, double* part, double* out, hipStream_t s, unsigned long long* clk) {
   const int CT = (n + 15) / 16;
-  if (CT < 3 || CT > 13 || rows < 4096 || ldy != n) return false;
-  int nz = (int)std::min<int64_t>(kGramMaxSlices, (rows + 1023) / 1024);
+  if (CT < 3 || rows < 4096 || ldy != n) return false;
+  int nz = (int)std::min<int64_t>(gram_max_slices(n), (rows + 1023) / 1024);
   int64_t kchunk = (rows + nz - 1) / nz;
   kchunk = (kchunk + 3) & ~(int64_t)3;
   nz = (int)((rows + kchunk - 1) / kchunk);
@@ -1379,9 +1523,30 @@ bool launch_gram_sym(const double* Y, int64_t ldy, int64_t rows, int n, double* 
   case ct:                                                                                             \
     hipLaunchKernelGGL((k_gram_sym<ct>), dim3(nz), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, part, clk); \
     break;
-  switch (CT) {
-    LZ_GS(3) LZ_GS(4) LZ_GS(5) LZ_GS(6) LZ_GS(7) LZ_GS(8) LZ_GS(9) LZ_GS(10) LZ_GS(11) LZ_GS(12) LZ_GS(13)
-    default: return false;
+  if (CT <= 13) {
+    switch (CT) {
+      LZ_GS(3) LZ_GS(4) LZ_GS(5) LZ_GS(6) LZ_GS(7) LZ_GS(8) LZ_GS(9) LZ_GS(10) LZ_GS(11) LZ_GS(12) LZ_GS(13)
+      default: return false;
+    }
+  } else {
+    // groups of kGramGS column tiles: the diagonal units and the off-diagonal pairs of the upper triangle of groups
+    const int ng = (CT + kGramGS - 1) / kGramGS;
+    if (ng > 20) return false;  // (n > 3520: the split-K form)
+    std::vector<int2> ud, up;
+    for (int a = 0; a < ng; ++a) {
+      ud.push_back(make_int2(kGramGS * a, kGramGS * a));
+      for (int b = a + 1; b < ng; ++b) up.push_back(make_int2(kGramGS * a, kGramGS * b));
+    }
+    // the unit table rides behind the partial slices (gram_scratch_doubles reserves 4096 doubles = 4096 int2 for it)
+    int2* tab = reinterpret_cast<int2*>(part + (size_t)gram_max_slices(n) * n * n);
+    std::vector<int2> all(ud);
+    all.insert(all.end(), up.begin(), up.end());
+    if (hipMemcpyAsync(tab, all.data(), all.size() * sizeof(int2), hipMemcpyHostToDevice, s) != hipSuccess) return false;
+    if (hipStreamSynchronize(s) != hipSuccess) return false;  // (`all` is a local; once per Gram matrix)
+    // the pairs first: they are the long blocks (33 tiles on their busiest wave against 18)
+    hipLaunchKernelGGL((k_gram_unit<kGramGS, kGramGS, false>), dim3(nz, (unsigned)up.size()), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, CT, tab + ud.size(),
+                       part);
+    hipLaunchKernelGGL((k_gram_unit<kGramGS, kGramGS, true>), dim3(nz, (unsigned)ud.size()), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, CT, tab, part);
   }
 #undef LZ_GS
   hipLaunchKernelGGL(k_sum_slices_sym, dim3((unsigned)(((int64_t)n * n + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, part, nz, n, out);

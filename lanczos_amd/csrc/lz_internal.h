@@ -209,7 +209,8 @@ void launch_ritz_gemm_cols(const double* V, int64_t ldv, int64_t rows, int kcoun
 // G = Y^T Y as K-chunk partials (n x n each); returns the number of chunks (<= nz_max)
 int launch_gram(const double* Y, int64_t ldy, int64_t rows, int n, double* part, int nz_max, hipStream_t s);
 void launch_sum_slices(const double* part, int nz, int64_t count, double* out, hipStream_t s);
-// accumulator-stationary symmetric Gram kernel (48 <= n <= 208, >= 4096 rows): out = Y^T Y complete; false: not covered
+// accumulator-stationary symmetric Gram kernel (n >= 33, >= 4096 rows; more than 208 columns: in groups of 11 column tiles):
+// out = Y^T Y complete; false: not covered
 constexpr int kGramMaxSlices = 768;
 size_t gram_scratch_doubles(int n);
 bool launch_gram_sym(const double* Y, int64_t ldy, int64_t rows, int n, double* part, double* out, hipStream_t s,

@@ -95,7 +95,7 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
     LZ_HIP(h, hipMemGetInfo(&free_b, &total_b));
     // what has to stay free beside Y: lz_ritz_gram's scratch (K-slice partials + G; 0.25 GB at n = 200, 4 GB at n = 1000 on the
     // split-K path) plus 512 MB for the runtime and the quality sums
-    const size_t gram_need = (std::max<size_t>(gram_scratch_doubles(n) / ((size_t)n * n), 512) + 2) * (size_t)n * n * sizeof(double);
+    const size_t gram_need = (std::max<size_t>((gram_scratch_doubles(n) + (size_t)n * n - 1) / ((size_t)n * n), 512) + 2) * (size_t)n * n * sizeof(double);
     chunked = full * sizeof(double) + gram_need + ((size_t)512 << 20) > free_b;
   }
   h->y_rows = h->rows;
@@ -213,7 +213,8 @@ int lz_ritz_gram(lz_handle h, double* gram_out) {
   if (h->y_chunked && (!h->d_V || h->n != n || h->rows != h->y_rows)) return fail(h, LZ_ERR_STATE, "lz_ritz_gram: the basis of the run is gone");
   // scratch: the K-slice partials of one chunk (the symmetric kernel's or the split-K TN GEMM's), one n x n slice per chunk
   // (added in chunk order at the end), G.  Kept in the handle: a 160-250 MB hipMalloc + hipFree per call cost milliseconds.
-  const size_t slices = std::max<size_t>(gram_scratch_doubles(n) / ((size_t)n * n), (size_t)nz_max);
+  // (rounded UP to whole n x n slices: the grouped form's unit table rides behind the symmetric kernel's partial slices)
+  const size_t slices = std::max<size_t>((gram_scratch_doubles(n) + (size_t)n * n - 1) / ((size_t)n * n), (size_t)nz_max);
   const size_t need = (slices + (size_t)nchunks + 1) * (size_t)n * n;
   if (h->gram_cap < need) {
     LZ_TRY(dev_alloc(h, h->d_gram, need));

@@ -234,12 +234,14 @@ def test_device_gram_and_quality_match_numpy():
     assert "Eigvec InnerProd" in buf.getvalue() and len(buf.getvalue().splitlines()) == 22
 
 
-@pytest.mark.parametrize("M,n,chunk", [(4096, 48, 0), (70001, 100, 0), (30011, 200, 0), (20000, 208, 0), (50000, 117, 0), (30011, 200, 8000), (5000, 33, 0), (5000, 32, 0), (3000, 100, 0)])
+@pytest.mark.parametrize("M,n,chunk", [(4096, 48, 0), (70001, 100, 0), (30011, 200, 0), (20000, 208, 0), (50000, 117, 0), (30011, 200, 8000), (5000, 33, 0), (5000, 32, 0), (3000, 100, 0),
+                                       (9000, 209, 0), (8200, 353, 0), (6000, 500, 0), (12000, 420, 5000)])
 def test_symmetric_gram_kernel(hip, M, n, chunk):
     """Round 4: the accumulator-stationary symmetric Gram kernel (k_gram_sym: upper 16 x 16 tiles of Y^T Y kept in the
     accumulators, Y streamed once, result mirrored) against NumPy and against the split-K TN GEMM it replaces (knob 19 = 1),
     on a Y that is NOT orthonormal (random S) so every entry is exercised: ragged last column tile, ragged last k-step,
-    resident and chunked Y.  Fewer than three column tiles (n <= 32) or fewer than 4096 rows stay on the old path."""
+    resident and chunked Y; more than 208 columns go through groups of 11 column tiles (diagonal units + halves of the
+    off-diagonal pairs, padded last group).  Fewer than three column tiles (n <= 32) or fewer than 4096 rows stay on the old path."""
     A = synthetic.random_graph_laplacian(M, 3 * M, seed=5)
     v0 = synthetic.reference_start_vector(M)
     v0 /= np.linalg.norm(v0)
@@ -257,7 +259,7 @@ def test_symmetric_gram_kernel(hip, M, n, chunk):
         h.ritz_vectors(S, fetch=False)
         G = h.ritz_gram()
         info = h.gram_info()
-        assert (info["ksteps"] > 0) == (knob == 0 and n > 32 and min(M, chunk or M) >= 4096)
+        assert (info["ksteps"] > 0) == (knob == 0 and 32 < n <= 208 and min(M, chunk or M) >= 4096)  # (the clock record: single-group form only)
         out[knob] = G
         h.close()
     Y = V.T @ S
