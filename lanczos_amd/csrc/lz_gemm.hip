@@ -1256,35 +1256,35 @@ constexpr int gram_tri_col(int CT, int t) {
   return i + t;
 }
 
-template <int CT, int W, int Q>
-struct GramTile {  // the Q-th tile of wave W: indices as compile-time constants (register arrays must never be indexed at run time)
-  static constexpr int t = W + 4 * Q;
+template <int CT, int W, int Q, int NW = 4>
+struct GramTile {  // the Q-th tile of wave W of NW: indices as compile-time constants (register arrays must never be indexed at run time)
+  static constexpr int t = W + NW * Q;
   static constexpr int i = gram_tri_row(CT, t), j = gram_tri_col(CT, t);
 };
-template <int CT, int W, int... Q>
+template <int CT, int W, int NW, int... Q>
 __device__ __forceinline__ void gram_mfmas(const double (&f)[CT], double4_t* acc, std::integer_sequence<int, Q...>) {
-  ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[GramTile<CT, W, Q>::i], f[GramTile<CT, W, Q>::j], acc[Q], 0, 0, 0)), ...);
+  ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[GramTile<CT, W, Q, NW>::i], f[GramTile<CT, W, Q, NW>::j], acc[Q], 0, 0, 0)), ...);
 }
-template <int CT, int W, int Q>
+template <int CT, int W, int Q, int NW>
 __device__ __forceinline__ void gram_store_tile(const double4_t& a, int n, int lr, int lk, double* __restrict__ Cz) {
-  const int col = 16 * GramTile<CT, W, Q>::j + lr;
+  const int col = 16 * GramTile<CT, W, Q, NW>::j + lr;
   if (col >= n) return;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const int r = 16 * GramTile<CT, W, Q>::i + lk + 4 * g;
+    const int r = 16 * GramTile<CT, W, Q, NW>::i + lk + 4 * g;
     if (r < n) Cz[(int64_t)r * n + col] = a[g];
   }
 }
-template <int CT, int W, int... Q>
+template <int CT, int W, int NW, int... Q>
 __device__ __forceinline__ void gram_store(const double4_t* acc, int n, int lr, int lk, double* __restrict__ Cz, std::integer_sequence<int, Q...>) {
-  (gram_store_tile<CT, W, Q>(acc[Q], n, lr, lk, Cz), ...);
+  (gram_store_tile<CT, W, Q, NW>(acc[Q], n, lr, lk, Cz), ...);
 }
 
-template <int CT, int W>
+template <int CT, int W, int NW = 4>
 __device__ __forceinline__ void gram_wave(const double* __restrict__ Y, int64_t ldy, int64_t k_lo, int64_t k_hi, int n,
                                           double* __restrict__ Cz) {
   constexpr int NTRI = gram_tri_count(CT);
-  constexpr int NTW = (NTRI - W + 3) / 4;  // this wave's tiles: t = W, W + 4, ...
+  constexpr int NTW = (NTRI - W + NW - 1) / NW;  // this wave's tiles: t = W, W + NW, ...
   constexpr int PA = 4;                    // k-steps the slab loads run ahead of the MFMAs
   const int lane = threadIdx.x & 63;
   const int lr = lane & 15, lk = lane >> 4;
@@ -1313,14 +1313,17 @@ __device__ __forceinline__ void gram_wave(const double* __restrict__ Y, int64_t 
     for (int p = 0; p < PA; ++p) {
       const int st = s0 + p;
       if (st < nsteps) {
-        gram_mfmas<CT, W>(ring[p], acc, std::make_integer_sequence<int, NTW>());
+        gram_mfmas<CT, W, NW>(ring[p], acc, std::make_integer_sequence<int, NTW>());
         load(st + PA < nsteps ? st + PA : nsteps - 1, ring[p]);  // refill this ring slot
       }
     }
   }
-  gram_store<CT, W>(acc, n, lr, lk, Cz, std::make_integer_sequence<int, NTW>());
+  gram_store<CT, W, NW>(acc, n, lr, lk, Cz, std::make_integer_sequence<int, NTW>());
 }
 
+// (An eight-wave form - two waves per SIMD, 11-12 tiles each, so that one wave's fragment loads hide behind the other's MFMAs - was
+// built and measured in round 4: 12.1 ms against 7.9-8.2 ms (profiles/r04/ab_gram_eight_waves.jsonl): every fragment is then fetched
+// by twice as many waves, and the operand fetch is what this kernel is bound by.  Not kept.)
 // clk (may be null; 4 words): in-kernel clock record of workgroup 0's wave 0, like the Ritz kernels' (lz_gram_info): shader
 // cycles (s_memtime), ticks of the constant 100 MHz counter (s_memrealtime), k-steps walked, MFMAs per k-step of that wave.
 template <int CT>
