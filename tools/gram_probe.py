@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Gram matrix G = Y^T Y of the Ritz vectors at the headline size for a list of knob-19 arms (0 symmetric kernel, 1 split-K TN GEMM,
-2 eight-wave A/B arm), event-timed, second call of each arm.  usage: gram_probe.py [n] [arms, e.g. 0,2,1]"""
+"""Gram matrix G = Y^T Y of the Ritz vectors at the headline size for a list of knob-19 arms (0 symmetric kernel, 1 split-K TN GEMM;
+round 4 also measured an eight-wave arm with it: profiles/r04/ab_gram_eight_waves.jsonl), event-timed, second call of each arm.
+usage: gram_probe.py [n] [arms, e.g. 0,1]"""
 import json
 import os
 import sys
@@ -11,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lanczos_amd import _capi, synthetic  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-arms = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,2,1").split(",")]
+arms = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1").split(",")]
 A = synthetic.laplacian_2d_5pt(4000, 2500)
 M = A.shape[0]
 v0 = synthetic.reference_start_vector(M)
