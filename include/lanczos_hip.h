@@ -68,7 +68,14 @@ enum lz_flags {
                                  bit-identical to the default, and within 1e-10 only while |alpha| is not >> beta.  A guard
                                  watches exactly that: when |r|^2 falls below 1e-4 of r''.r'' (or is not positive) at any
                                  step, lz_run REPEATS the solve on the default loop and lz_last_engine reports 5 - the
-                                 delivered coefficients then are the default loop's, bit for bit.                      */
+                                 delivered coefficients then are the default loop's, bit for bit.
+                                 With LZ_FLAG_REORTH_PARTIAL (round 5, lz_last_engine 8): the device-decided partial loop with
+                                 ONE all-reduce + one exchange per iteration, sweep or no sweep (instead of three + one): the
+                                 one reduced buffer carries alpha's partial, the three self terms of |r|^2 and - in a step
+                                 that sweeps - the basis dots; the sweep decision is a one-step look-ahead of Simon's
+                                 recurrence taken from reduced sums only, so every rank agrees (lz_last_sweep_misses counts
+                                 the vectors the look-ahead should have swept and did not; they are swept one step late).
+                                 Same guard; a repeat runs the three-collective partial loop (engine 5).              */
   LZ_FLAG_REORTH_PARTIAL = 64 /* opt-in: partial re-orthogonalisation (Simon 1984).  The reference sweeps the whole basis
                                  every step; with this flag the sweep (same kernels, same arithmetic) runs only when the
                                  omega-recurrence estimate of the loss of orthogonality exceeds sqrt(eps), on that and the
@@ -131,6 +138,8 @@ int lz_set_options(lz_handle h, int flags);
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
  *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta),
  *       3 device-resident with pass 1's second-stage sums as a kernel of their own (default: pass 1's last block adds them)
+ *   20  one-reduce partial loop (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE): safety factor kappa of the look-ahead sweep
+ *       decision (a sweep is due when kappa * max |predicted omega| > sqrt(eps); 0 = the default, 4)
  * The product library returns LZ_ERR_ARG for everything that lives only in the kernel-bench build (make KBENCH=1 ->
  * liblanczos_kbench.so, loaded by tools/ and by the tests of those arms): the timing-only ablation arms (knob 1 >= 20,
  * knob 3) and the A/B arms retired in round 3 because they measured slower - the one-kernel and one-launch-per-step engines
@@ -295,6 +304,10 @@ int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
 int lz_last_sweeps(lz_handle h, int* sweeps);
+/* LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE only (else 0): vectors of the last lz_run whose exact omega-recurrence estimate
+ * exceeded sqrt(eps) although the one-step look-ahead gate had not swept them (lz_set_tuning(h, 20, kappa) sets the look-ahead's
+ * safety factor, default 4). */
+int lz_last_sweep_misses(lz_handle h, int* misses);
 /* How the last lz_run was executed (choose_loop, lz_loops.hip).  0: six launches per step (also: the host-decided partial
  * re-orthogonalisation loop, every kernel A/B arm, more than 4e6 rows per rank).  7: LZ_FLAG_REORTH_PARTIAL with the decision on
  * the device (round 4, the default of that flag): the sweep kernels of every step are enqueued and return at once when the
@@ -303,6 +316,7 @@ int lz_last_sweeps(lz_handle h, int* sweeps);
  * of their consumer kernels - three launches per step, bit-identical results.  3: up to 4e6 rows per rank in fused-norm mode
  * with the full sweep: the three-term recurrence rides in the prologue of the next step's pass 1 (five launches per step,
  * bit-identical; not with LZ_FLAG_OVERLAP_HALO).  lz_set_tuning(h, 15, 1) selects 0 in both cases.  6: LZ_FLAG_ONE_REDUCE.
+ * 8: LZ_FLAG_ONE_REDUCE | LZ_FLAG_REORTH_PARTIAL (one all-reduce per step, look-ahead sweep decision on the device).
  * 5: a one-reduce run whose cancellation guard fired and that was repeated on the default loop.  1 / 4: the one-kernel and
  * one-launch-per-step engines of the kernel-bench build (retired from the product library in round 3: bit-identical, not
  * faster - DESIGN.md section 4). */

@@ -50,6 +50,7 @@ TUNE_LOOP = 15              # loop structure (0 auto, 1 six launches per step al
 TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 forces it)
 TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto: CSR order, ELL only in the partial loop; 1 never ELL; 2 / 3 ELL always, one / two rows per lane)
 TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel, 1 split-K TN GEMM)
+TUNE_PARTIAL_LOOKAHEAD = 20 # one-reduce partial loop: safety factor of the look-ahead sweep decision (0 = default 4)
 TUNE_PARTIAL_LOOP = 18      # partial re-orthogonalisation loop (0 device-resident, 1 host-decided, 2 device-resident without the fused scale,
                             # 3 device-resident with a separate second-stage kernel behind pass 1)
 
@@ -123,6 +124,7 @@ SIGNATURES = {
     "lz_ritz_quality": (C.c_int, [_P, _D]),
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
     "lz_last_sweeps": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "lz_last_sweep_misses": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_last_engine": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_last_host_syncs": (C.c_int, [_P, _I64]),
     "lz_basis_alloc": (C.c_int, [_P, C.c_int]),
@@ -571,17 +573,24 @@ class Handle:
         self.check(self.lib.lz_last_sweeps(self._h, C.byref(k)))
         return k.value
 
+    def last_sweep_misses(self):
+        """one-reduce partial loop: vectors the look-ahead gate should have swept and did not (swept one step late)"""
+        k = C.c_int()
+        self.check(self.lib.lz_last_sweep_misses(self._h, C.byref(k)))
+        return k.value
+
     def last_engine(self):
         """"kernels": six launches per step; "fused": the three-launch path of small problems (second-stage reductions
         and the three-term recurrence folded into their consumer kernels); "three-term-fused": five launches per step (the
         three-term recurrence folded into pass 1; the default between the small problems and 4e6 rows per rank);
         "one-reduce": LZ_FLAG_ONE_REDUCE; "one-reduce-repeated": such a run whose cancellation guard fired and that was
         repeated on the default loop; "partial-device": LZ_FLAG_REORTH_PARTIAL with the omega-recurrence and the sweep decision on
-        the device (no host synchronisation inside the run); "step" / "small": the retired one-launch-per-step / one-kernel
+        the device (no host synchronisation inside the run); "partial-one-reduce": the same with ONE all-reduce per step
+        (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE, look-ahead sweep decision); "step" / "small": the retired one-launch-per-step / one-kernel
         engines (kernel-bench build)."""
         k = C.c_int()
         self.check(self.lib.lz_last_engine(self._h, C.byref(k)))
-        return ("kernels", "small", "fused", "three-term-fused", "step", "one-reduce-repeated", "one-reduce", "partial-device")[k.value]
+        return ("kernels", "small", "fused", "three-term-fused", "step", "one-reduce-repeated", "one-reduce", "partial-device", "partial-one-reduce")[k.value]
 
     def last_host_syncs(self):
         """host <-> device synchronisations inside the last lz_run (between its first and its last launch)"""

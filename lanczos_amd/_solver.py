@@ -91,6 +91,29 @@ def _fingerprint(*arrays):
     return _fingerprint_start(*arrays)()
 
 
+def _canonical_key(H):
+    """What a checkpoint says about the operator it was made with: one fixed hash (BLAKE2b, stdlib) over the CANONICAL form - the
+    packed int32 / float64 CSR arrays - so that the same operator held as CSR, CSC, COO or dense (or the CSR copy `execute_Lanczos`
+    leaves in ``self.H``, Lanczos.py:137), on a host with or without xxhash, resumes.  (The device-cache key `_matrix_key` is hashed
+    from the arrays as the caller holds them and stays what it was: it only has to recognise the very same object again, fast.)"""
+    import hashlib
+
+    if hasattr(H, "dims") and hasattr(H, "points"):
+        return "stencil:" + json.dumps(H.key(), default=str)
+    packed = _pack_matrix(H)
+    if packed[0] == "dense":
+        A = scipy.sparse.csr_matrix(packed[1])
+        packed = ("csr", A.indptr.astype(np.int32, copy=False), A.indices.astype(np.int32, copy=False), A.data)
+    hsh = hashlib.blake2b(digest_size=16)
+    hsh.update(np.asarray(np.shape(H), dtype=np.int64).tobytes())
+    for a in packed[1:]:
+        a = np.ascontiguousarray(a)
+        hsh.update(np.int64(a.size).tobytes())
+        if a.size:
+            hsh.update(memoryview(a).cast("B"))
+    return "csr-blake2b:" + hsh.hexdigest()
+
+
 def _native_arrays(H):
     """the arrays that ARE the matrix as the caller holds it (no conversion, no copy): what the cache key is hashed from"""
     if scipy.sparse.issparse(H):
@@ -367,7 +390,7 @@ class LanczosBase:
                 self._v0_cache = ((seed, M), v0, state)  # (never written to again: lz_run only reads it)
             else:
                 v0 = np.array(v0)
-                v0 /= np.linalg.norm(v0)  # (in place, like the reference: v0 is this call's own copy)
+                v0 = v0 / np.linalg.norm(v0)  # out of place, like the reference (Lanczos.py:100): an integer or list v0 becomes float64 here
         t_1 = time.perf_counter()
         if n < 2:
             # the reference allocates beta = zeros(n-1) and writes beta[-1] at j = 0 (Lanczos.py:107,112)
@@ -435,11 +458,10 @@ class LanczosBase:
         if not self.Lanczos_has_been_executed:
             raise ValueError(_NOT_EXECUTED)
         h = self._device()
-        key = self._matrix_key
         return {"alpha": self._alpha.copy(), "beta": self._beta.copy(), "V": np.array(h.get_basis()), "r": h.get_residual(), "M": self.M,
                 "fused_norm": bool(self.fused_norm), "options": int(self.options), "reorth": str(self.reorth),
-                # what the run was made WITH: resume refuses a different operator of the same size (content hash of H as held then)
-                "matrix_key": json.dumps(key, default=str) if key is not None else ""}
+                # what the run was made WITH: resume refuses a different operator of the same size (hash of its canonical CSR form)
+                "matrix_key": _canonical_key(self.H)}
 
     def save_checkpoint(self, path):
         np.savez(path, **self.checkpoint())
@@ -457,7 +479,7 @@ class LanczosBase:
         if n <= j0:
             raise ValueError("resume_Lanczos: n must exceed the %d steps already in the checkpoint" % j0)
         if self.reorth != "full":
-            raise NotImplementedError("resume needs reorth='full' (the partial mode's omega-recurrence is not part of the checkpoint)")
+            raise NotImplementedError("resume needs reorth='full' (the partial mode's omega-recurrence state is not part of the checkpoint)")
         if "reorth" in ck and str(ck["reorth"]) != "full":
             raise ValueError("the checkpoint was written by a reorth='%s' run" % str(ck["reorth"]))
         if "options" in ck and int(ck["options"]) & ~_capi.FLAG_PROFILE != int(self.options) & ~_capi.FLAG_PROFILE:
@@ -469,8 +491,17 @@ class LanczosBase:
         h.set_options(self.options | (_capi.FLAG_FUSED_NORM if fused else 0))
         self._upload_matrix(h)
         stored = str(ck["matrix_key"]) if "matrix_key" in ck else ""
-        if stored and self._matrix_key is not None and stored != json.dumps(self._matrix_key, default=str):
-            raise ValueError("the checkpoint belongs to a different matrix (same size, different content)")
+        if stored.startswith(("csr-blake2b:", "stencil:")):
+            # format-independent: CSR / CSC / COO / dense holders of one operator (and `Lanczos(old.H)`) all resume
+            if stored != _canonical_key(self.H):
+                raise ValueError("the checkpoint belongs to a different matrix (same size, different content)")
+        elif stored and self._matrix_key is not None and stored != json.dumps(self._matrix_key, default=str):
+            # a checkpoint of an earlier version (key of the arrays as the caller held them): a mismatch may be a change of container
+            # format or of the hash function only, so it is reported, not refused
+            import warnings
+
+            warnings.warn("the checkpoint's matrix key is in the pre-round-5 format and does not match this object's H as held now; "
+                          "resuming on the caller's word that it is the same operator", RuntimeWarning, stacklevel=2)
         alpha, beta = h.run_resume(n, ck["V"], ck["r"], ck["alpha"], ck["beta"])
         if h.breakdown:
             import warnings

@@ -522,7 +522,7 @@ int lz::api::basis_alloc(lz_handle h, int n, int zero_rows) {
     LZ_TRY(dev_alloc(h, h->d_r2, (size_t)h->ldv));
     LZ_TRY(dev_alloc(h, h->d_alpha, (size_t)n + 1));
     LZ_TRY(dev_alloc(h, h->d_beta, (size_t)n + 1));
-    LZ_TRY(dev_alloc(h, h->d_c, (size_t)2 * qtw_ldp(n + 2) + 8));  // n + 1 coefficients; one-reduce mode: two runs + alpha
+    LZ_TRY(dev_alloc(h, h->d_c, 2 * ((size_t)2 * qtw_ldp(n + 2) + 8)));  // n + 1 coefficients; one-reduce mode: two runs + alpha (partial one-reduce loop: two such buffers alternate)
     LZ_TRY(dev_alloc(h, h->d_nrm2, 2));
   }
   if (fresh) {
@@ -539,7 +539,7 @@ int lz::api::basis_alloc(lz_handle h, int n, int zero_rows) {
   size_t need = (size_t)(n + 16) * (size_t)h->qplan.P;
   if (h->flags & LZ_FLAG_ONE_REDUCE) need = (size_t)2 * qtw_ldp(n + 2) * (size_t)h->qplan.P;
   if (h->qplan.G <= 8) need = std::max<size_t>(need, fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G);  // fused small-problem path
-  need = std::max<size_t>(need, 4096);
+  need = std::max<size_t>(need, 8192);  // (>= 3 x 2048: the three self-term partial runs of k_three_term_self)
   need = std::max<size_t>(need, (size_t)(h->rows / 4 + 64));                     // dense gemv / scalar spmv partials
   need = std::max<size_t>(need, (size_t)h->csr.n_rowblk + 64);
   if (h->csr.pb) need = std::max<size_t>(need, (size_t)pb_num_partials(h->csr.pb) + 64);
@@ -550,7 +550,7 @@ int lz::api::basis_alloc(lz_handle h, int n, int zero_rows) {
   LZ_HIP(h, hipMemsetAsync(h->d_r2, 0, (size_t)h->ldv * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_alpha, 0, ((size_t)n + 1) * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_beta, 0, ((size_t)n + 1) * sizeof(double), h->stream));
-  LZ_HIP(h, hipMemsetAsync(h->d_c, 0, ((size_t)2 * qtw_ldp(n + 2) + 8) * sizeof(double), h->stream));
+  LZ_HIP(h, hipMemsetAsync(h->d_c, 0, 2 * ((size_t)2 * qtw_ldp(n + 2) + 8) * sizeof(double), h->stream));
   LZ_HIP(h, hipMemsetAsync(h->d_nrm2, 0, 2 * sizeof(double), h->stream));
   LZ_HIP(h, hipStreamSynchronize(h->stream));
   return LZ_OK;
@@ -654,6 +654,12 @@ int lz_last_host_syncs(lz_handle h, int64_t* syncs) {
 int lz_last_sweeps(lz_handle h, int* sweeps) {
   if (!h || !sweeps) return LZ_ERR_ARG;
   *sweeps = h->last_sweeps;
+  return LZ_OK;
+}
+
+int lz_last_sweep_misses(lz_handle h, int* misses) {
+  if (!h || !misses) return LZ_ERR_ARG;
+  *misses = h->last_misses;
   return LZ_OK;
 }
 

@@ -133,6 +133,7 @@ struct lz_context {
   hipEvent_t run_a = nullptr, run_b = nullptr;
   bool run_timed = false;
   int last_sweeps = 0;
+  int last_misses = 0;  // one-reduce partial loop: vectors whose exact omega exceeded sqrt(eps) although the look-ahead gate had not swept them
   int last_engine = 0;  // which loop ran last (enum Loop)
   int r_state = 0;      // what d_r holds after the last run: 0 nothing usable, 1 the residual entering step n, 2 y = A v_{n-1} (three-term pending)
   Xfer* xfer = nullptr;        // staging ring of the large device -> host copies (lz_xfer.hip), created at the first one

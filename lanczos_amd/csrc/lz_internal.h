@@ -117,7 +117,14 @@ void launch_final_sum(const double* part, int n, double* out, hipStream_t s);
 // c[i] = sum_b part[i*G + b]; transposed (4x4x4 MFMA kernel): c[i] = sum_b part[b*qtw_ldp(nrows) + i]
 inline int qtw_ldp(int nrows) { return (nrows + 15) & ~15; }
 void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed = false, const int* gate = nullptr);
-void launch_final_rows_t(const double* part, int G, int ldp, int nout, double* c, hipStream_t s);
+void launch_final_rows_t(const double* part, int G, int ldp, int nout, double* c, hipStream_t s, const int* gate = nullptr);
+// up to four independent k_final_sum's in one launch: out[q][0] = sum(part[q][0 .. n[q])) in k_final_sum's grouping
+struct FinalMulti {
+  const double* part[4];
+  int n[4];
+  double* out[4];
+};
+void launch_final_sum_multi(const FinalMulti& fm, int count, hipStream_t s);
 
 struct QtwPlan {
   int64_t L = 0;    // elements of w owned by one block (multiple of 512)
@@ -166,6 +173,14 @@ inline size_t omega_state_ints(int n) { return (size_t)2 + n + 1; }
 // Prepares the decision for step jn (called after step jn - 1 has left alpha[jn-1] and ||r||^2; jn == 0: after the warm-up).
 // part != nullptr: first nrm2[0] = sum(part[0..np)) in k_final_sum's order (single rank: one launch for both).
 void launch_omega(const double* part, int np, double* nrm2, const double* alpha, int jn, int n, double* st, int* ist, hipStream_t s);
+// The post-reduce kernel of the one-reduce partial loop (k_partial_onered_post, lz_reorth.hip): finishes the all-reduced buffer,
+// advances the omega-recurrence, takes the look-ahead sweep decision of step j + 1, clears the next step's buffer.  j < 0: initialises
+// the gates (ist: omega_onered_ints(n) ints).
+inline size_t omega_onered_ints(int n) { return (size_t)4 + n + 2; }
+void launch_partial_onered_post(double* buf, double* bufn, int nzero_next, int m, int ldp, double* alpha_slot, double* nrm2, const double* alpha,
+                                int j, int n, double* st, int* ist, double kappa, hipStream_t s);
+// r = r - beta vm (vm may be nullptr: r unchanged) + block partials of [r.r, u.r, u.u] at part[b], part[G + b], part[2 G + b]; returns G
+int launch_three_term_self(double* r, const double* u, const double* vm, const double* beta, int64_t len, double* part, hipStream_t s);
 void launch_fused_prepare(double* c, int j, double* beta_slot, hipStream_t s);
 void launch_onereduce_prepare(double* buf, int m, int ldp, double* alpha_slot, double* bad, hipStream_t s);
 // r = (r - alpha v_j) - beta v_jm1 ; part[b] = partial ||r||^2 ; returns number of partials

@@ -400,7 +400,8 @@ enum Loop {
   LOOP_SMALL_STEP = 4,        // kernel-bench build only: one launch per step
   LOOP_ONE_REDUCE_REPEATED = 5,  // a one-reduce run whose cancellation guard fired: repeated on the default loop
   LOOP_ONE_REDUCE = 6,        // LZ_FLAG_ONE_REDUCE: one all-reduce per iteration
-  LOOP_PARTIAL_DEVICE = 7     // LZ_FLAG_REORTH_PARTIAL, default: the omega-recurrence and the sweep decision live on the device
+  LOOP_PARTIAL_DEVICE = 7,    // LZ_FLAG_REORTH_PARTIAL, default: the omega-recurrence and the sweep decision live on the device
+  LOOP_PARTIAL_ONE_REDUCE = 8 // LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE: the same with one all-reduce per iteration (look-ahead gate)
 };
 
 Loop choose_loop(lz_handle h, int n) {
@@ -408,6 +409,8 @@ Loop choose_loop(lz_handle h, int n) {
   const bool default_kernels = h->qplan.family == 2 && !(f & (LZ_FLAG_QTW_MFMA | LZ_FLAG_QTW_VALU)) && h->tune[1] == 0 && h->tune[8] == 0;
   const bool full_fused = (f & LZ_FLAG_FUSED_NORM) && !(f & LZ_FLAG_REORTH_PARTIAL);
   if ((f & LZ_FLAG_ONE_REDUCE) && !(f & LZ_FLAG_REORTH_PARTIAL) && h->qplan.family == 2) return LOOP_ONE_REDUCE;
+  if ((f & LZ_FLAG_ONE_REDUCE) && (f & LZ_FLAG_REORTH_PARTIAL) && default_kernels && h->tune[18] != 1 && !(f & LZ_FLAG_OVERLAP_HALO))
+    return LOOP_PARTIAL_ONE_REDUCE;
   // partial re-orthogonalisation: device-resident decisions with the default kernels (tune[18] == 1: the host-decided loop,
   // two scalars read back per step - kept for the bit-identity test and as an A/B arm)
   if ((f & LZ_FLAG_REORTH_PARTIAL) && default_kernels && h->tune[18] != 1 && !(f & LZ_FLAG_OVERLAP_HALO)) return LOOP_PARTIAL_DEVICE;
@@ -642,14 +645,116 @@ int run_loop_partial_device(lz_handle h, int n) {
   return LZ_OK;
 }
 
+// ---- partial re-orthogonalisation with ONE all-reduce per step (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE; round 5) --------
+// The device-decided loop above issues three collectives per step on a partition (alpha, ||r||^2 and - used or not - the
+// coefficient vector): at the N = 8 rank share a step without a sweep is ~26 us of kernels, so three latency-bound all-reduces
+// would make the selective arm scale negatively.  Here a step costs ONE all-reduce + ONE exchange, sweep or no sweep, exactly like
+// run_loop_onereduce: the single buffer [p_0..p_{m-1}, r''.r'' | q_0..q_{m-1}, u.u, u.r'', alpha] carries alpha's partial, the three
+// self terms and the sweep's dots (zero in a step without a sweep); the gate is read by every kernel from device memory and is the
+// same on every rank because it is derived from reduced sums only (k_partial_onered_post: a one-step look-ahead of Simon's
+// recurrence, since the exact test of omega_{j,:} needs the very sums this all-reduce delivers).
+// Per step:  [pass 1, two columns - gated]  [second stage - gated]  ALL-REDUCE  [post: alpha, c, ||r||^2, omega, next gate]
+//            [r = r'' - alpha u]  [update - gated | scale V[j] = r / beta - gated the other way]  EXCHANGE  [SpMV + alpha partial]
+//            [r'' = A v_j - beta v_{j-1} + the three self terms' partials]  [their sums + alpha's into the next buffer]
+// Two buffers alternate (the update of step j still reads buffer j & 1 while the post kernel clears the other).  No host
+// synchronisation inside the loop over RCCL.  The three-sum ||r||^2 cancels like the full one-reduce loop's: same guard, same
+// repeat of the solve (on the three-collective device loop) when it fires.
+int run_loop_partial_onereduce(lz_handle h, int n) {
+  const double M = (double)h->rows;
+  if (h->om_n < n + 4) {  // (omega_onered_ints(n) <= omega_state_ints(n + 4) + 1)
+    LZ_TRY(dev_alloc(h, h->d_om, omega_state_doubles(n + 4)));
+    LZ_TRY(dev_alloc(h, h->d_omi, omega_state_ints(n + 4) + 1));
+    h->om_n = n + 4;
+  }
+  const double kappa = h->tune[20] > 0 ? (double)h->tune[20] : 4.0;
+  const size_t bstride = (size_t)2 * qtw_ldp(n + 2) + 8;
+  {
+    Scope sc(h, LZ_K_FINAL, 0, 0);
+    launch_partial_onered_post(nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, -1, n, h->d_om, h->d_omi, kappa, h->stream);
+    LZ_TRY(check_launch(h, "partial_onered_post(init)"));
+  }
+  LZ_TRY(step_spmv(h, 0, h->d_c + onered_slot(0), false));  // warm-up: r'' = A v0 (Lanczos.py:108), alpha0 partial
+  const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+  for (int j = 0; j < n; ++j) {
+    h->prof_iter = (j % pstride) == pstride / 2;
+    const int bidx = (j + n - 2) % (n - 1);
+    const int m = j, urow = j > 0 ? j - 1 : 0, ldp = onered_ldp(m);
+    const bool last = j == n - 1;
+    double* buf = h->d_c + (size_t)(j & 1) * bstride;
+    double* bufn = h->d_c + (size_t)((j + 1) & 1) * bstride;
+    const int* gate = h->d_omi + (j & 1);
+    double* u = h->d_V + (int64_t)urow * h->ldv;
+    double* vj = h->d_V + (int64_t)j * h->ldv;
+    h->qplan.variant = 0;
+    {
+      QtwFuse fz;
+      fz.gate = gate;
+      Scope sc(h, LZ_K_QTW, 0, 0);  // (bytes of the launches that really ran: accounted after the run from the device's sweep log)
+      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, m, urow, h->d_r, nullptr, nullptr, h->qplan, h->d_part, 3, h->stream, &fz));
+      LZ_TRY(check_launch(h, "qtw(two columns, gated)"));
+    }
+    {
+      Scope sc(h, LZ_K_FINAL, 0, 0);
+      launch_final_rows_t(h->d_part, h->qplan.G, 2 * ldp, ldp + m + 2, buf, h->stream, gate);
+      LZ_TRY(check_launch(h, "final_rows(gated)"));
+    }
+    LZ_TRY(comm_allreduce(h, buf, onered_slot(m) + 1));  // THE collective of this iteration
+    {
+      Scope sc(h, LZ_K_FINAL, 0, 0);
+      launch_partial_onered_post(buf, last ? nullptr : bufn, last ? 0 : onered_slot(j + 1) + 1, m, ldp, h->d_alpha + urow, h->d_nrm2, h->d_alpha, j, n,
+                                 h->d_om, h->d_omi, kappa, h->stream);
+      LZ_TRY(check_launch(h, "partial_onered_post"));
+    }
+    {
+      Scope sc(h, LZ_K_THREE, 24.0 * M, 2.0 * M);
+      launch_three_term(h->d_r, u, nullptr, h->d_alpha + urow, nullptr, h->rows_pad, h->d_part, h->stream);  // r = r'' - alpha u
+      LZ_TRY(check_launch(h, "three_term(alpha)"));
+    }
+    {
+      Scope sc(h, LZ_K_UPDATE, 0, 0);
+      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, buf, h->d_r, h->d_beta + bidx, 0, h->stream, 0, -1, 1, 0, 0, 0, 0, gate);
+      LZ_TRY(check_launch(h, "update(gated)"));
+    }
+    {
+      Scope sc(h, LZ_K_QTW, 16.0 * M, M);
+      launch_scale_store(vj, h->d_r, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream, gate);
+      LZ_TRY(check_launch(h, "scale_store(gated)"));
+    }
+    LZ_TRY(step_spmv(h, j, last ? h->d_alpha + j : bufn + onered_slot(j + 1), last));  // the last alpha has no pass to ride on
+    if (!last) {
+      // r'' = A V[j] - beta V[j-1] (at j = 0 the reference's V[-1] is the zero row) + the self terms of the next step's ||r||^2
+      const int mn = j + 1, ldpn = onered_ldp(mn);
+      int G3 = 0;
+      {
+        Scope sc(h, LZ_K_THREE, (j > 0 ? 40.0 : 16.0) * M, (j > 0 ? 8.0 : 6.0) * M);
+        G3 = launch_three_term_self(h->d_r, vj, j > 0 ? h->d_V + (int64_t)(j - 1) * h->ldv : nullptr, h->d_beta + bidx, h->rows_pad, h->d_part, h->stream);
+        LZ_TRY(check_launch(h, "three_term(beta) + self terms"));
+      }
+      FinalMulti fm;
+      for (int q = 0; q < 3; ++q) {
+        fm.part[q] = h->d_part + (size_t)q * G3;
+        fm.n[q] = G3;
+      }
+      fm.out[0] = bufn + mn;             // r''.r''
+      fm.out[1] = bufn + ldpn + mn + 1;  // u.r''
+      fm.out[2] = bufn + ldpn + mn;      // u.u
+      fm.part[3] = nullptr, fm.n[3] = 0, fm.out[3] = nullptr;
+      Scope sc(h, LZ_K_FINAL, 0, 0);
+      launch_final_sum_multi(fm, 3, h->stream);
+      LZ_TRY(check_launch(h, "final_sum(self terms)"));
+    }
+  }
+  return LZ_OK;
+}
+
 // after the final synchronisation of lz_run: the device's sweep log -> lz_last_sweeps and the byte / flop accounting of the
 // gated launches (pass 1: 8 j M + 16 M bytes, pass 2 the same; in a swept step the scale kernel / fused scale did no work)
-void account_partial_device(lz_handle h, int n, const std::vector<int>& log, int* sweeps_out) {
+void account_partial_device(lz_handle h, int n, const std::vector<int>& log, int* sweeps_out, size_t log0 = 2) {
   const double M = (double)h->rows;
   const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
   int sweeps = 0;
   for (int j = 0; j < n; ++j) {
-    if (!log[(size_t)2 + j]) continue;
+    if (!log[log0 + j]) continue;
     ++sweeps;
     // (pass 1's read of r and write of V[j], 16 M bytes, are on the books already: the scale pass is accounted in every step)
     const double flops = 2.0 * (j + 1) * M;
@@ -756,7 +861,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
   h->host_syncs = 0;
   const Loop loop = choose_loop(h, n);
-  const bool one_reduce = loop == LOOP_ONE_REDUCE;
+  const bool one_reduce = loop == LOOP_ONE_REDUCE || loop == LOOP_PARTIAL_ONE_REDUCE;
   int sweeps = n;
   h->last_engine = (int)loop;
   switch (loop) {
@@ -776,6 +881,7 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
     case LOOP_THREE_TERM_FUSED: LZ_TRY(run_loop_three_term_fused(h, n)); break;
     case LOOP_ONE_REDUCE: LZ_TRY(run_loop_onereduce(h, n)); break;
     case LOOP_PARTIAL_DEVICE: LZ_TRY(run_loop_partial_device(h, n)); break;
+    case LOOP_PARTIAL_ONE_REDUCE: LZ_TRY(run_loop_partial_onereduce(h, n)); break;
     default: LZ_TRY(run_loop_six(h, n, &sweeps)); break;
   }
   h->last_sweeps = sweeps;
@@ -790,12 +896,17 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   double onered_bad = 0.0;
   if (one_reduce) LZ_HIP(h, hipMemcpyAsync(&onered_bad, h->d_nrm2 + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   std::vector<int> sweep_log;
-  if (loop == LOOP_PARTIAL_DEVICE) {
-    sweep_log.resize(omega_state_ints(n));
+  if (loop == LOOP_PARTIAL_DEVICE || loop == LOOP_PARTIAL_ONE_REDUCE) {
+    sweep_log.resize(loop == LOOP_PARTIAL_DEVICE ? omega_state_ints(n) : omega_onered_ints(n));
     LZ_HIP(h, hipMemcpyAsync(sweep_log.data(), h->d_omi, sweep_log.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   }
   LZ_HIP(h, hipStreamSynchronize(h->stream));
+  h->last_misses = 0;
   if (loop == LOOP_PARTIAL_DEVICE) account_partial_device(h, n, sweep_log, &h->last_sweeps);
+  if (loop == LOOP_PARTIAL_ONE_REDUCE) {
+    account_partial_device(h, n, sweep_log, &h->last_sweeps, 4);
+    h->last_misses = sweep_log[3];
+  }
   if (one_reduce && onered_bad != 0.0) {
     // cancellation guard of the one-reduce loop (k_onereduce_prepare): |r|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u lost too
     // many digits at some step (|alpha| >> beta).  Every rank sees the same reduced sums, so every rank takes this branch:
@@ -850,7 +961,7 @@ int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_
   if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run_resume: n cannot be larger than M");
   if (ldv_in < h->rows) return fail(h, LZ_ERR_ARG, "lz_run_resume: ldv_in < rows_local");
   if (h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE))
-    return fail(h, LZ_ERR_STATE, "lz_run_resume: not with partial re-orthogonalisation (its omega-recurrence lives on the host) or the one-reduce loop");
+    return fail(h, LZ_ERR_STATE, "lz_run_resume: not with partial re-orthogonalisation (its omega-recurrence state is not part of a checkpoint) or the one-reduce loop");
   LZ_TRY(basis_alloc(h, n, 1));
   h->halo_inflight_j = -1;
   h->y_n = 0;

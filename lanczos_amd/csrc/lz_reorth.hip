@@ -159,6 +159,162 @@ void launch_omega(const double* part, int np, double* nrm2, const double* alpha,
   hipLaunchKernelGGL(k_omega, dim3(1), dim3(kFinalThreads), 0, s, part, np, nrm2, alpha, jn, n, st, ist);
 }
 
+// ---- the same decision for the loop with ONE all-reduce per step (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE) --------------
+// On a row-block partition the sums a step needs - alpha of the newest vector u = v_{j-1}, the three self terms that give
+// ||r||^2, and (when a sweep runs) the basis dots against r'' and u - travel in ONE buffer and one all-reduce (run_loop_partial_
+// onereduce, lz_loops.hip).  The sweep's dots must be in that buffer BEFORE alpha_{j-1} and beta_j - the inputs of omega_{j,:} -
+// exist on any rank, so the gate of step j cannot be Simon's exact test of omega_{j,:}; it is a ONE-STEP LOOK-AHEAD, taken by this
+// kernel right after the all-reduce of step j - 1:
+//   * omega_{j,:} is advanced exactly (k_omega's recurrence, expression for expression) once alpha_{j-1}, beta_j are known;
+//   * omega_{j+1,:} is PREDICTED with the same recurrence, the two coefficients that do not exist yet replaced by the newest
+//     ones (alpha_j ~ alpha_{j-1}, beta_{j+1} ~ beta_j); a sweep of v_{j+1} (and of v_{j+2}: Simon's pair) is due when
+//     kappa * max_k |pred| > sqrt(eps) (kappa = 4 by default: a sweep comes a step early rather than late - an early sweep costs
+//     nothing but its place in the schedule);
+//   * the exact row is the check on the prediction: a vector that was not swept although its exact omega exceeds sqrt(eps) is a
+//     MISS - counted (lz_last_sweep_misses), and the next two vectors are swept.
+// Every input is an all-reduced sum or derived from one: every rank takes the same decisions.  One block; it also finishes the
+// all-reduced buffer like k_onereduce_prepare (alpha, c_i = p_i - alpha q_i, ||r||^2 by the three-sum form + its cancellation
+// guard) and clears the buffer of the next step (coefficient slots of a step without a sweep must be zero, not stale: they are
+// summed over the ranks every step).
+// State: st / W as k_omega; ist[0], ist[1] = gate of the even / odd steps, ist[2] = sweeps, ist[3] = misses, ist[4 + j] = log.
+__global__ __launch_bounds__(kFinalThreads) void k_partial_onered_post(double* __restrict__ buf, double* __restrict__ bufn, int nzero_next, int m,
+                                                                       int ldp, double* __restrict__ alpha_slot, double* __restrict__ nrm2,
+                                                                       const double* __restrict__ alpha, int j, int n, double* __restrict__ st,
+                                                                       int* __restrict__ ist, double kappa) {
+  __shared__ double sm[kFinalThreads / 64];
+  __shared__ double s_v;
+  __shared__ int s_flag;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (j < 0) {  // before the warm-up: step 0 always sweeps (the reference's one-row sweep)
+    for (int i = threadIdx.x; i < n + 5; i += kFinalThreads) ist[i] = (i == 0 || i == 2 || i == 4) ? 1 : 0;
+    return;
+  }
+  const int g = ist[j & 1];
+  const double a = buf[ldp + m + 2];
+  if (bufn)
+    for (int i = threadIdx.x; i < nzero_next; i += kFinalThreads) bufn[i] = 0.0;
+  if (g)
+    for (int i = threadIdx.x; i < m; i += kFinalThreads) buf[i] = buf[i] - a * buf[ldp + i];
+  if (threadIdx.x == 0) {
+    const double rr = buf[m], uu = buf[ldp + m], ur = buf[ldp + m + 1];
+    const double v = (rr - 2.0 * a * ur) + a * a * uu;
+    if (!(v > 1e-4 * rr)) nrm2[1] = 1.0;  // cancellation guard, as k_onereduce_prepare
+    buf[m] = v;
+    nrm2[0] = v;
+    alpha_slot[0] = a;
+    s_v = v;
+  }
+  __syncthreads();
+  const double eps = 2.220446049250313e-16, thresh = 1.4901161193847656e-08;
+  double* hb = st + 2;
+  double* W = hb + (n + 2);
+  const int ldw = n + 1;
+  const double hbj = sqrt(s_v);
+  if (j == 0) {
+    for (int i = threadIdx.x; i < 3 * ldw; i += kFinalThreads) W[i] = i == 0 ? 1.0 : 0.0;  // omega_{0,0} = v_0 . v_0
+    for (int i = threadIdx.x; i < n + 2; i += kFinalThreads) hb[i] = i == 0 ? hbj : 0.0;
+    if (threadIdx.x == 0) {
+      st[0] = 0.0;
+      st[1] = 0.0;
+      ist[1] = 0;  // step 1: nothing to be orthogonal to but v_0, which the recurrence itself takes care of
+      if (n > 1) ist[4 + 1] = 0;
+    }
+    return;
+  }
+  // exact row j (k_omega's code): alpha_{j-1} = a, beta_j = hbj
+  const double hb_prev = hb[j - 1];
+  double normA = st[0];
+  {
+    const double cand = fabs(a) + hb_prev + hbj;
+    if (cand > normA) normA = cand;
+  }
+  const double* cur = W + (size_t)((j + 2) % 3) * ldw;   // omega_{j-1,:}
+  const double* prev = W + (size_t)((j + 1) % 3) * ldw;  // omega_{j-2,:}
+  double* nw = W + (size_t)(j % 3) * ldw;
+  double worst = 0.0;
+  for (int k = threadIdx.x; k <= n; k += kFinalThreads) {
+    double v = 0.0;
+    if (k == j) {
+      v = 1.0;
+    } else if (k == j - 1) {
+      v = eps;
+    } else if (k + 2 <= j) {
+      const double ak = k == j - 1 ? a : alpha[k];
+      double t = hb[k + 1] * cur[k + 1] + (ak - a) * cur[k] - hb_prev * prev[k];
+      if (k > 0) t += hb[k] * cur[k - 1];
+      t += (t < 0 ? -1.0 : 1.0) * 2.0 * eps * normA;
+      v = t / hbj;
+      const double av = fabs(v);
+      if (av > worst) worst = av;
+    }
+    if (g && k < j) v = eps;  // this vector is being swept
+    nw[k] = v;
+  }
+  auto block_max = [&](double x) -> double {  // valid in thread 0
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double o = __shfl_down(x, off, 64);
+      if (o > x) x = o;
+    }
+    __syncthreads();
+    if (lane == 0) sm[w] = x;
+    __syncthreads();
+    double mx = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < kFinalThreads / 64; ++k)
+        if (sm[k] > mx) mx = sm[k];
+    }
+    return mx;
+  };
+  const double worst_exact = block_max(worst);
+  if (threadIdx.x == 0) s_flag = (!g && worst_exact > thresh) ? 1 : 0;
+  __syncthreads();  // (also: row j complete before the prediction reads it)
+  const int miss = s_flag;
+  // predicted row j + 1: k <= j - 1; unknown alpha_j ~ a, beta_{j+1} ~ hbj; beta_j = hbj exact; hb[j] is not stored yet
+  double worst_p = 0.0;
+  if (j + 1 < n) {
+    for (int k = threadIdx.x; k + 2 <= j + 1; k += kFinalThreads) {
+      const double ak = k == j - 1 ? a : alpha[k];
+      const double hk1 = k + 1 == j ? hbj : hb[k + 1];
+      double t = hk1 * nw[k + 1] + (ak - a) * nw[k] - hbj * cur[k];
+      if (k > 0) t += hb[k] * nw[k - 1];
+      t += (t < 0 ? -1.0 : 1.0) * 2.0 * eps * normA;
+      const double av = fabs(t / hbj);
+      if (av > worst_p) worst_p = av;
+    }
+  }
+  const double wp = block_max(worst_p);
+  if (threadIdx.x == 0) {
+    const bool due = kappa * wp > thresh || miss;
+    const int gn = (due || st[1] != 0.0) ? 1 : 0;
+    st[1] = (due && !g) ? 1.0 : 0.0;  // Simon's pair: the vector after a newly due one is swept too
+    st[0] = normA;
+    hb[j] = hbj;
+    ist[3] += miss;
+    if (j + 1 < n) {
+      ist[(j + 1) & 1] = gn;
+      ist[2] += gn;
+      ist[4 + j + 1] = gn;
+    }
+  }
+}
+void launch_partial_onered_post(double* buf, double* bufn, int nzero_next, int m, int ldp, double* alpha_slot, double* nrm2, const double* alpha,
+                                int j, int n, double* st, int* ist, double kappa, hipStream_t s) {
+  hipLaunchKernelGGL(k_partial_onered_post, dim3(1), dim3(kFinalThreads), 0, s, buf, bufn, nzero_next, m, ldp, alpha_slot, nrm2, alpha, j, n, st, ist,
+                     kappa);
+}
+
+// up to four independent k_final_sum's in one launch (block q adds its own run into its own slot)
+__global__ __launch_bounds__(kFinalThreads) void k_final_sum_multi(FinalMulti fm) {
+  __shared__ double sm[kFinalThreads / 64];
+  const double t = final_sum_1024(fm.part[blockIdx.x], fm.n[blockIdx.x], sm);
+  if (threadIdx.x == 0) fm.out[blockIdx.x][0] = t;
+}
+void launch_final_sum_multi(const FinalMulti& fm, int count, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_sum_multi, dim3(count), dim3(kFinalThreads), 0, s, fm);
+}
+
 __global__ __launch_bounds__(kTPB) void k_final_rows(const double* __restrict__ part, int G, double* __restrict__ c) {
   __shared__ double sm[kTPB / 64];
   const double* p = part + (int64_t)blockIdx.x * G;
@@ -200,9 +356,9 @@ void launch_final_sum(const double* part, int n, double* out, hipStream_t s) {
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(kFinalThreads), 0, s, part, n, out);
 }
 // explicit run length: c[i] = sum_b part[b * ldp + i], i < nout (one-reduce mode: two coefficient runs per block)
-void launch_final_rows_t(const double* part, int G, int ldp, int nout, double* c, hipStream_t s) {
+void launch_final_rows_t(const double* part, int G, int ldp, int nout, double* c, hipStream_t s, const int* gate) {
   if (nout <= 0) return;
-  hipLaunchKernelGGL(k_final_rows_t, dim3((nout + 7) / 8), dim3(kFinalThreads), 0, s, part, G, ldp, nout, c, (const int*)nullptr);
+  hipLaunchKernelGGL(k_final_rows_t, dim3((nout + 7) / 8), dim3(kFinalThreads), 0, s, part, G, ldp, nout, c, gate);
 }
 void launch_final_rows(const double* part, int nrows, int G, double* c, hipStream_t s, bool transposed, const int* gate) {
   if (nrows <= 0) return;
@@ -1036,7 +1192,7 @@ static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
                    double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi, int raw_c, int64_t pos_lo_b,
                    int64_t pos_hi_b, int cG, int cldp, const int* gate) {
-  // gate (device-resident partial re-orthogonalisation): scale-then-dot order and the default slice-owner kernels only
+  // gate (device-resident partial re-orthogonalisation): the default slice-owner kernels only
   // double2 positions [pos_lo, pos_hi) of the row (default: the whole row)
   const int64_t n2 = pos_hi >= 0 ? pos_hi : (len >> 1);
   const int64_t p0 = pos_lo > 0 ? pos_lo : 0;
@@ -1077,11 +1233,11 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
   if (variant == 6 || (variant == 0 && P == 16 && span > 16384)) {
     // 16 positions per lane, one row per trip (still 16 loads in flight): half as many, longer-lived blocks - fewer
     // residency rounds, so V[j] leaves in fewer, larger write bursts (1250 -> 1218 us at the headline)
-    if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
+    if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate);
     else launch_update_slice<false, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
     return;
   }
-  if (variant == 0 && span <= 4096 && r_fused && nrows > 64 && pos_hi < 0 && pos_lo <= 0) {
+  if (variant == 0 && span <= 4096 && r_fused && nrows > 64 && pos_hi < 0 && pos_lo <= 0 && !gate) {
     // a short vector against many rows: the element-per-lane, double-buffered kernel (see k_update_elem)
     const int grid_e = (int)((len + kTPB - 1) / kTPB);
     hipLaunchKernelGGL(k_update_elem, dim3(grid_e), dim3(kTPB), raw_c == 2 ? (size_t)nrows * sizeof(double) : 0, s, V, ldv, len, nrows, j, c, r_fused,
@@ -1091,16 +1247,16 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
   if ((variant == 0 && span <= 16384) || variant == 5) {
     // a face of the slab (overlap mode) or a tiny vector: a handful of blocks walk all rows, which is a latency chain,
     // not a bandwidth problem - one position per lane (most blocks) and 32 rows in flight per lane
-    if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, pos_lo_b, pos_hi_b, cG, cldp);
+    if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, pos_lo_b, pos_hi_b, cG, cldp, gate);
     else launch_update_slice<false, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, pos_lo_b, pos_hi_b, 0, 0, gate);
   } else if (P == 8) {
-    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
+    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate);
     else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   } else if (P == 4) {
-    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
+    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate);
     else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   } else {
-    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp);
+    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate);
     else launch_update_slice<false, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   }
 }
@@ -1205,6 +1361,51 @@ int launch_three_term(double* r, const double* vj, const double* vjm1, const dou
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(k_three_term, dim3((int)g), dim3(kTPB), 0, s, r, vj, vjm1, alpha, beta, n2, part);
+  return (int)g;
+}
+
+// One-reduce partial loop, behind the SpMV of step j: r'' = y - beta v_{j-1} (k_three_term's expression) and, in the same pass,
+// the block partials of the three self terms the next step's ||r||^2 is made of - r''.r'' -> part[b], u.r'' -> part[G + b],
+// u.u -> part[2 G + b] with u = v_j - so that a step without a sweep needs no pass 1 at all.
+__global__ __launch_bounds__(kTPB) void k_three_term_self(double* __restrict__ r, const double* __restrict__ u, const double* __restrict__ vm,
+                                                         const double* __restrict__ beta, int64_t n2, double* __restrict__ part) {
+  __shared__ double sm[kTPB / 64];
+  const double b = vm ? beta[0] : 0.0;
+  double2* r2 = reinterpret_cast<double2*>(r);
+  const double2* u2 = reinterpret_cast<const double2*>(u);
+  const double2* m2 = reinterpret_cast<const double2*>(vm);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kTPB) {
+    double2 x = r2[i];
+    const double2 uu = u2[i];  // (v_j was just written and read by the SpMV: plain load)
+    if (vm) {
+      const double2 m = ld_stream<1>(m2 + i);
+      x.x = x.x - m.x * b;
+      x.y = x.y - m.y * b;
+      r2[i] = x;
+    }
+    s0 = fma(x.x, x.x, s0);
+    s0 = fma(x.y, x.y, s0);
+    s1 = fma(uu.x, x.x, s1);
+    s1 = fma(uu.y, x.y, s1);
+    s2 = fma(uu.x, uu.x, s2);
+    s2 = fma(uu.y, uu.y, s2);
+  }
+  s0 = block_sum(s0, sm);
+  s1 = block_sum(s1, sm);
+  s2 = block_sum(s2, sm);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s0;
+    part[gridDim.x + blockIdx.x] = s1;
+    part[2 * gridDim.x + blockIdx.x] = s2;
+  }
+}
+int launch_three_term_self(double* r, const double* u, const double* vm, const double* beta, int64_t len, double* part, hipStream_t s) {
+  const int64_t n2 = len >> 1;
+  int64_t g = (n2 + kTPB - 1) / kTPB;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_three_term_self, dim3((int)g), dim3(kTPB), 0, s, r, u, vm, beta, n2, part);
   return (int)g;
 }
 

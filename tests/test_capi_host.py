@@ -264,3 +264,20 @@ print("OUT" + json.dumps(out))
     assert len(bad["maps"]["amdhip64"]) == 2 and len(bad["maps"]["hsa-runtime64"]) == 2 and bad["refused"] and bad["bootstrap_refused"]
     assert len(good["maps"]["amdhip64"]) == 1 and not good["refused"] and not good["bootstrap_refused"]
     assert "torch/lib" in good["info"]["hip"] and good["maps"]["amdhip64"] == [os.path.realpath(good["info"]["hip"])] or good["info"]["hip"] in good["maps"]["amdhip64"]
+
+
+def test_checkpoint_matrix_key_is_independent_of_the_container_format():
+    """a checkpoint names its operator by one fixed hash of the canonical CSR form, so CSR / CSC / COO / dense holders of
+    the same matrix (and the CSR copy `execute_Lanczos` leaves in ``self.H``, Lanczos.py:137) are the same matrix to `resume_Lanczos`,
+    with or without xxhash on the host; another matrix of the same size is not."""
+    import scipy.sparse
+
+    from lanczos_amd import _solver
+
+    H = synthetic.laplacian_2d_5pt(12, 9).to_scipy()
+    key = _solver._canonical_key(H)
+    assert key.startswith("csr-blake2b:")
+    for other in (H.tocsc(), H.tocoo(), H.toarray(), scipy.sparse.csr_matrix(H.toarray()), synthetic.laplacian_2d_5pt(12, 9)):
+        assert _solver._canonical_key(other) == key
+    assert _solver._canonical_key(H + scipy.sparse.identity(H.shape[0], format="csr")) != key
+    assert _solver._canonical_key(synthetic.laplacian_2d_5pt(9, 12).to_scipy()) != key

@@ -37,6 +37,9 @@ WORKER = textwrap.dedent('''
              # LZ_FLAG_ONE_REDUCE: one all-reduce (+ one halo exchange / all-gather) per iteration instead of two
              ("lap2d_onereduce", lambda lo, hi: synthetic.laplacian_2d_5pt(96, 80, rows=(lo, hi)), 96 * 80, "halo", 40),
              ("graph_onereduce", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 30),
+             # LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE (round 5): the device-decided partial loop with ONE all-reduce per step
+             ("lap3d_partial_onereduce", lambda lo, hi: synthetic.laplacian_3d_7pt(20, 18, 16, rows=(lo, hi)), 20 * 18 * 16, "halo", 120),
+             ("graph_partial_onereduce", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 60),
              # the column-blocked two-phase SpMV (what config C3 runs) on every rank's row block against the all-gathered vector
              ("graph_twophase", lambda lo, hi: synthetic.random_graph_laplacian(6000, 20000, seed=4).row_slice(lo, hi), 6000, "auto", 30),
              # M = 1000 is not a multiple of world * 32: the last rank's all-gather chunk has a tail no kernel writes; the
@@ -49,7 +52,7 @@ WORKER = textwrap.dedent('''
     for name, build, M, mode, n in cases:
         b = partition.row_bounds(M, boot.world)
         lo, hi = b[boot.rank], b[boot.rank + 1]
-        opts = 64 if name.endswith("_partial") else 0  # LZ_FLAG_REORTH_PARTIAL: every rank must take the same sweep decisions
+        opts = 64 if "_partial" in name else 0  # LZ_FLAG_REORTH_PARTIAL: every rank must take the same sweep decisions
         s = distributed.DistributedLanczos(build(lo, hi), M, boot, device_id=0, backend="host", mode=mode, fused_norm=(name != "lap3d"), options=opts,
                                            one_reduce=name.endswith("_onereduce"), tuning={14: 2} if name == "graph_twophase" else None)
         if name == "graph_twophase":
@@ -57,7 +60,7 @@ WORKER = textwrap.dedent('''
         if name == "dense_poison":
             s.h.set_tuning(_capi.TUNE_POISON_BASIS, 1)
         a, bta = s.execute_Lanczos(n)
-        sweeps = s.h.last_sweeps()
+        sweeps, misses, engine = s.h.last_sweeps(), s.h.last_sweep_misses(), s.h.last_engine()
         device_built_equal = None
         if name == "c4_slab_k200":  # the same slab assembled on the device from the boundary-row plan: identical matrix, identical run
             s2 = distributed.DistributedLanczos.from_stencil((24, 24, 32), 7, boot, device_id=0, backend="host")
@@ -96,13 +99,14 @@ WORKER = textwrap.dedent('''
             dq = float(np.abs(qual - qref).max() / np.abs(qref).max())
         # long runs outlive the prefix the reference arithmetic itself determines (converged Ritz values make the late
         # coefficients rounding noise, see oracle.stable_masks): compare coefficients on that prefix, Ritz values on the mask
-        prefix, mask = (n, np.ones(n, bool)) if n < 100 or name.endswith("_partial") else oracle.stable_masks(full, n, ao, bo)
+        prefix, mask = (n, np.ones(n, bool)) if n < 100 or "_partial" in name else oracle.stable_masks(full, n, ao, bo)
         out[name] = dict(mode=s.plan.mode, da=float(np.abs(a - ao)[:prefix].max()), db=float(np.abs(bta - bo)[:max(prefix - 1, 1)].max()),
                          dth=float(np.abs(theta - th_o)[mask].max() / np.abs(th_o).max()), prefix=int(prefix), nmask=int(mask.sum()),
                          scale=float(max(np.abs(ao).max(), np.abs(bo).max())),
                          dV=float(np.abs(V[:, :8] - Vo[:8, lo:hi].T).max() / np.abs(Vo[:8]).max()), dY=float(np.abs(Y - V @ S).max()),
                          orth=float(np.abs(boot.allreduce_sum(V.T @ V) - np.eye(n)).max()),
-                         comm_launches=comm_launches, sweeps=sweeps, n=n, device_built_equal=device_built_equal, dq=dq, chunked=chunked)
+                         comm_launches=comm_launches, sweeps=sweeps, misses=misses, engine=engine, n=n, device_built_equal=device_built_equal, dq=dq,
+                         chunked=chunked)
     res = boot.allgather_obj(out)
     if boot.rank == 0:
         import json
@@ -141,10 +145,18 @@ def test_partitioned_run_on_one_gpu(tmp_path, world):
         # coefficients agree to rounding, not bit for bit: held to the same tolerances below)
         assert per_rank["c4_slab_k200"]["prefix"] >= 100 and per_rank["c5_k500"]["prefix"] >= 300, per_rank
         for name, r in per_rank.items():
-            if name.endswith("_partial"):
+            if "_partial" in name:
                 # converging run with sweeps: Ritz values of the partial mode vs the oracle's full sweep
                 assert 1 <= r["sweeps"] < r["n"] and r["dth"] < 1e-10 and r["dY"] < 1e-12, (name, r)
                 assert r["sweeps"] == res[0][name]["sweeps"]
+                if name.endswith("_onereduce"):
+                    # ONE all-reduce + one exchange per iteration, sweep or no sweep: (n + 1) exchanges + n
+                    # combined all-reduces + the last alpha - against exchange + three all-reduces per step in the device loop
+                    assert r["engine"] == "partial-one-reduce" and r["misses"] == 0, (name, r)
+                    assert r["comm_launches"] == 2 * r["n"] + 2, (name, r)
+                    assert r["orth"] < 1e-6, (name, r)
+                else:
+                    assert r["engine"] == "partial-device" and r["comm_launches"] >= 4 * r["n"], (name, r)
                 continue
             # short runs: 1e-11 absolute on every coefficient; the k = 200 / 500 runs: the north-star bar (1e-10 of the
             # spectral scale) on the stable prefix, whose end is by definition where coefficients start to move at 1e-12
@@ -214,6 +226,37 @@ def test_partial_loop_over_a_one_rank_rccl_communicator():
     assert 1 < s0 < n and h.last_sweeps() == s0
     assert np.array_equal(a0, a1) and np.array_equal(b0, b1) and np.array_equal(V0, h.get_basis())
     assert h.timings()["comm"]["launches"] >= 4 * n  # all-gather + three all-reduces per step
+    h.close()
+    h0.close()
+
+
+def test_partial_one_reduce_loop_over_a_one_rank_rccl_communicator():
+    """The one-reduce partial loop (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE) with real RCCL calls (1-rank communicator, forced
+    through the tuning knob), on a matrix whose Ritz values converge (several sweeps): ONE ncclAllReduce + one exchange per step -
+    2 n + 2 collectives per run against more than 4 n of the three-collective loop -, no host synchronisation, and results equal to
+    the same loop without a communicator bit for bit."""
+    A = synthetic.laplacian_3d_7pt(20, 18, 16)
+    M = A.shape[0]
+    n = 120
+    v0 = np.random.RandomState(99).uniform(-1, 1, M)
+    v0 /= np.linalg.norm(v0)
+    flags = _capi.FLAG_REORTH_PARTIAL | _capi.FLAG_ONE_REDUCE
+    h0 = _capi.Handle(0)
+    h0.set_options(flags)
+    h0.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    a0, b0 = h0.run(n, v0)
+    V0, s0 = h0.get_basis(), h0.last_sweeps()
+    h = _capi.Handle(0)
+    h.comm_init_rccl(1, 0, h.unique_id())
+    h.set_tuning(_capi.TUNE_FORCE_COLLECTIVES, 1)
+    h.set_options(flags)
+    h.set_csr(M, 0, A.rowptr, A.colidx, A.vals, ncols_ext=h.padded_rows(M))
+    h.set_allgather(h.padded_rows(M))
+    a1, b1 = h.run(n, v0)
+    assert h.last_engine() == "partial-one-reduce" and h.last_host_syncs() == 0 and h.last_sweep_misses() == 0
+    assert 1 < s0 < n and h.last_sweeps() == s0
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1) and np.array_equal(V0, h.get_basis())
+    assert h.timings()["comm"]["launches"] == 2 * n + 2  # (n + 1) all-gathers + n combined all-reduces + the last alpha
     h.close()
     h0.close()
 

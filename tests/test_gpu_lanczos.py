@@ -182,6 +182,29 @@ def test_error_surface_on_device():
     assert ritz_close(s.H_eigvals, d["H_eigvals"])
 
 
+def test_integer_and_list_start_vectors_are_accepted_like_the_reference():
+    """Lanczos.py:99-100 copies the caller's v0 and divides OUT of place: an int array or a plain list becomes float64 there.
+    (an in-place divide raised UFuncTypeError here.)"""
+    Lanczos.verbose = False
+    H = synthetic.laplacian_2d_5pt(20, 13).to_scipy()
+    M, n = H.shape[0], 12
+    vi = (np.arange(M) % 7 - 3).astype(np.int64)
+    vi[0] = 5
+    ref = Lanczos(H)
+    ref.execute_Lanczos(n, v0=vi.astype(np.float64))
+    for v0 in (vi, vi.tolist(), vi.astype(np.int32), vi.astype(np.float32)):
+        keep = np.array(v0).copy()
+        s = Lanczos(H)
+        s.execute_Lanczos(n, v0=v0)
+        if np.array(v0).dtype == np.float32:  # v0 / norm(v0) stays float32 in NumPy (in the reference too): a start vector rounded to 24 bits
+            assert np.abs(s.H_eff - ref.H_eff).max() < 1e-5
+        else:
+            assert np.array_equal(s.H_eff, ref.H_eff)
+        assert np.array_equal(np.array(v0), keep)  # the caller's vector is never written to
+    a, b, _ = oracle.execute_lanczos(H, n, v0=vi)
+    assert ritz_close(ref.H_eigvals, np.linalg.eigvalsh(oracle.build_h_eff(a, b)))
+
+
 @pytest.mark.parametrize("flags", [2, 4, 16, 4 | 16, 32, 8, 16 | 256])
 def test_kernel_variants_agree(flags, hip, kb):
     """VALU (4) Q^T w arm, fused-norm (16, also with VALU), generic CSR-stream (32) and scalar SpMV (8) arms, and the
@@ -727,6 +750,87 @@ def test_one_reduce_cancellation_guard(hip):
             assert np.abs(a1 - a0).max() < 1e-11 and np.abs(b1 - b0).max() < 1e-11
 
 
+@pytest.mark.parametrize("build,n,well", [(lambda: synthetic.laplacian_3d_7pt(20, 18, 16), 150, True),        # Ritz values converge: several sweeps
+                                          (lambda: synthetic.laplacian_2d_5pt(96, 80), 60, True),
+                                          (lambda: synthetic.laplacian_2d_5pt(331, 211), 90, True),          # rows no multiple of a slice
+                                          (lambda: synthetic.random_graph_laplacian(50000, 175000, seed=3), 150, False)])
+def test_partial_one_reduce_loop(hip, build, n, well):
+    """LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE (round 5, lz_last_engine 8): the device-decided partial re-orthogonalisation with
+    ONE all-reduce per step.  The sweep decision is a one-step look-ahead of Simon's recurrence (its exact test
+    needs the sums the step's only all-reduce delivers), so sweeps may come a step earlier than in the three-collective loop; held to:
+    coefficients of a well-conditioned run within 1e-10 of the scale of the default (full-sweep) loop's, converged Ritz values to
+    1e-10 whatever the conditioning, a semi-orthogonal basis (sqrt(eps) level), no look-ahead miss, no host synchronisation, and a
+    sweep count in the neighbourhood of the exact loop's."""
+    A = build()
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    res = {}
+    for tag, flags in (("full", hip.FLAG_FUSED_NORM), ("partial", hip.FLAG_REORTH_PARTIAL), ("onered", hip.FLAG_REORTH_PARTIAL | hip.FLAG_ONE_REDUCE)):
+        h = hip.Handle(0)
+        h.set_options(flags)
+        h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+        a, b = h.run(n, v0)
+        res[tag] = dict(a=a, b=b, V=h.get_basis(), sweeps=h.last_sweeps(), misses=h.last_sweep_misses(), engine=h.last_engine(),
+                        syncs=h.last_host_syncs(), bd=h.breakdown)
+        h.close()
+    f, p1, o = res["full"], res["partial"], res["onered"]
+    assert o["engine"] == "partial-one-reduce" and o["syncs"] == 0 and o["misses"] == 0 and not o["bd"]
+    assert p1["engine"] == "partial-device" and p1["misses"] == 0
+    assert 1 <= o["sweeps"] < n and abs(o["sweeps"] - p1["sweeps"]) <= max(3, p1["sweeps"] // 2), (o["sweeps"], p1["sweeps"])
+    scale = max(np.abs(f["a"]).max(), np.abs(f["b"]).max())
+    th_f = np.linalg.eigvalsh(oracle.build_h_eff(f["a"], f["b"]))
+    th_o = np.linalg.eigvalsh(oracle.build_h_eff(o["a"], o["b"]))
+    conv = oracle.converged_ritz(f["a"], f["b"], tol=1e-9)
+    if len(conv):
+        assert np.abs(th_o[None, :] - conv[:, None]).min(axis=1).max() <= RTOL * np.abs(th_f).max()
+    if well:
+        prefix, mask = oracle.stable_masks(A.to_scipy(), n, f["a"], f["b"], v0=v0)
+        assert prefix >= n // 2
+        assert np.abs(o["a"] - f["a"])[:prefix].max() <= 1e-10 * scale and np.abs(o["b"] - f["b"])[: prefix - 1].max() <= 1e-10 * scale
+        if prefix == n:
+            assert np.abs(th_o - th_f).max() <= RTOL * np.abs(th_f).max()
+    assert np.abs(o["V"] @ o["V"].T - np.eye(n)).max() < 1e-6  # semi-orthogonal, like the three-collective partial loop
+    # a second run on a fresh handle: bit-identical (deterministic reductions, device-side decisions)
+    h = hip.Handle(0)
+    h.set_options(hip.FLAG_REORTH_PARTIAL | hip.FLAG_ONE_REDUCE)
+    h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    a2, b2 = h.run(n, v0)
+    assert np.array_equal(a2, o["a"]) and np.array_equal(b2, o["b"]) and np.array_equal(h.get_basis(), o["V"]) and h.last_sweeps() == o["sweeps"]
+    # the look-ahead's safety factor (knob 20): a larger kappa can only sweep earlier / more often, never lose the bar
+    h.set_tuning(hip.TUNE_PARTIAL_LOOKAHEAD, 64)
+    a3, b3 = h.run(n, v0)
+    assert h.last_sweeps() >= o["sweeps"] and h.last_sweep_misses() == 0
+    if well:
+        assert np.abs(a3 - f["a"])[:prefix].max() <= 1e-10 * scale
+    h.close()
+
+
+def test_partial_one_reduce_cancellation_guard(hip):
+    """The one-reduce partial loop forms |r|^2 from three sums like the full one-reduce loop and carries the same guard: on a
+    strongly shifted operator the solve is repeated - on the three-collective device loop, whose coefficients it then delivers
+    bit for bit (lz_last_engine 5)."""
+    import scipy.sparse
+
+    A = synthetic.laplacian_2d_5pt(120, 100).to_scipy()
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    H = (A + 1.0e4 * scipy.sparse.identity(M, format="csr")).tocsr()
+    H.sort_indices()
+    out = []
+    for flags in (hip.FLAG_REORTH_PARTIAL, hip.FLAG_REORTH_PARTIAL | hip.FLAG_ONE_REDUCE):
+        h = hip.Handle(0)
+        h.set_options(flags)
+        h.set_csr(M, 0, H.indptr, H.indices, H.data)
+        a, b = h.run(40, v0)
+        out.append((a, b, h.last_engine(), h.last_sweeps(), h.breakdown))
+        h.close()
+    (a0, b0, e0, s0, bd0), (a1, b1, e1, s1, bd1) = out
+    assert e0 == "partial-device" and e1 == "one-reduce-repeated" and not bd0 and not bd1
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1) and s0 == s1
+
+
 @pytest.mark.parametrize("build,n1,n2", [(lambda: synthetic.laplacian_2d_5pt(64, 48).to_scipy(), 10, 31),             # three-launch loop
                                          (lambda: synthetic.laplacian_3d_7pt(40, 30, 20).to_scipy(), 17, 40),         # five-launch loop
                                          (lambda: synthetic.random_graph_laplacian(50000, 175000, seed=3).to_scipy(), 2, 12),
@@ -763,6 +867,22 @@ def test_checkpoint_and_resume_is_bit_identical(tmp_path, build, n1, n2, fused):
     assert np.array_equal(r2, whole.checkpoint()["r"])
     with pytest.raises(ValueError, match="must exceed"):
         third.resume_Lanczos(n1, ck)
+    # the checkpoint's matrix key is format-independent - the same operator held in another container resumes (CSC for
+    # the sparse cases: symmetric, so the same CSR arrays and the same bits; the CSR form of the dense case: another SpMV kernel,
+    # same operator, coefficients to rounding), and so does `Lanczos(old.H)` (the CSR copy execute_Lanczos leaves in self.H)
+    if scipy.sparse.issparse(H):
+        fourth = Lanczos(H.tocsc())
+        fourth.resume_Lanczos(n2, ck)
+        assert np.array_equal(fourth.H_eff, whole.H_eff)
+    else:
+        fourth = Lanczos(scipy.sparse.csr_matrix(H))
+        fourth.resume_Lanczos(n2, ck)
+        assert np.abs(fourth.H_eff - whole.H_eff).max() <= 1e-10 * np.abs(whole.H_eff).max()
+    fourth.close()
+    fifth = Lanczos(whole.H)
+    fifth.resume_Lanczos(n2, ck)
+    assert np.isfinite(fifth.H_eff).all()
+    fifth.close()
     # the resumed run's norm order is the checkpoint's, but the object's own setting is left alone; a checkpoint
     # is refused by a different operator of the same size and by other options; a closed object says so clearly
     assert second.fused_norm is Lanczos.fused_norm
