@@ -466,6 +466,9 @@ def main():
             "comm_ms_per_step": round(tm["comm"]["ms"] * tm["comm"]["launches"] / max(tm["comm"]["timed_launches"], 1) / args.steps, 3),
             "comm_avg_us_per_call": round(1e3 * tm["comm"]["ms"] / max(tm["comm"]["timed_launches"], 1), 2),
             "comm_calls_per_step": tm["comm"]["launches"] // max(args.steps, 1),
+            # by kind and per Lanczos ITERATION (a bench step is a whole k-iteration solve): all-reduces + SpMV-input exchanges
+            "comm_calls_per_iteration": {"allreduce": round(tm["allreduces"] / max(args.steps, 1) / k, 3),
+                                         "exchange": round(tm["exchanges"] / max(args.steps, 1) / k, 3)},
             "final_ms_per_step": round(tm["final"]["ms"] * tm["final"]["launches"] / max(tm["final"]["timed_launches"], 1) / args.steps, 3),
             "setup_s": {"matrix_build": round(t_build, 2)},
             "device": solver.h.device_name(),
@@ -501,6 +504,7 @@ def main():
     watchdog.daemon = True
     watchdog.start()
     alpha_main, beta_main = alpha.copy(), beta.copy()
+    H_eff_main = np.diag(alpha_main) + np.diag(beta_main, 1) + np.diag(beta_main, -1)
 
     partial = overlap_arm = one_reduce_arm = None
     try:
@@ -539,6 +543,8 @@ def main():
                 "basis_semi_orthogonality_max_dev": gdev,
                 "iterations_per_s": round(2 * k / tp, 1), "ms_per_solve": round(1e3 * tp / 2, 3), "sweeps": solver.h.last_sweeps(), "of": k,
                 "engine": solver.h.last_engine(), "host_syncs_inside_lz_run": solver.h.last_host_syncs(),
+                "comm_calls_per_iteration": {"allreduce": round(tmp["allreduces"] / 2.0 / k, 3), "exchange": round(tmp["exchanges"] / 2.0 / k, 3)},
+                "lookahead_misses": solver.h.last_sweep_misses(),
                 "device_ms_per_solve": round(tmp["total_ms"] / 2, 3),
                 "max_rel_ritz_diff_vs_full": float(np.abs(theta_part - theta_full).max() / np.abs(theta_full).max()),
                 "converged_ritz_values": int(conv_full.sum()),
@@ -594,6 +600,27 @@ def main():
             one_reduce_arm = {"iterations_per_s": round(2 * k / t1r, 1), "ms_per_solve": round(1e3 * t1r / 2, 3),
                               "comm_calls_per_iteration": round(tm1["comm"]["launches"] / 2.0 / k, 2),
                               "max_abs_coeff_diff_vs_default": float(max(np.abs(a_1 - alpha_main).max(), np.abs(b_1 - beta_main).max()))}
+            # ... and the partial (selective) loop with one all-reduce per step (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE, round 5)
+            if not args.no_partial:
+                arm_state["arm"] = "partial_one_reduce"
+                solver.h.set_options(solver.options | _capi.FLAG_ONE_REDUCE | _capi.FLAG_REORTH_PARTIAL)
+                solver.execute_Lanczos(k, v0_normalized_local=v0)
+                solver.timings()
+                boot.barrier()
+                solver.h.synchronize()
+                t1p = time.perf_counter()
+                for _ in range(2):
+                    a_p, b_p = solver.execute_Lanczos(k, v0_normalized_local=v0)
+                solver.h.synchronize()
+                boot.barrier()
+                t1p = max(boot.allgather_obj(time.perf_counter() - t1p))
+                tmq = solver.timings()
+                one_reduce_arm["partial"] = {
+                    "iterations_per_s": round(2 * k / t1p, 1), "ms_per_solve": round(1e3 * t1p / 2, 3), "engine": solver.h.last_engine(),
+                    "sweeps": solver.h.last_sweeps(), "lookahead_misses": solver.h.last_sweep_misses(),
+                    "comm_calls_per_iteration": {"allreduce": round(tmq["allreduces"] / 2.0 / k, 3), "exchange": round(tmq["exchanges"] / 2.0 / k, 3)},
+                    "max_rel_ritz_diff_vs_full": float(np.abs(np.linalg.eigvalsh(solver.H_eff) - np.linalg.eigvalsh(H_eff_main)).max()
+                                                       / np.abs(np.linalg.eigvalsh(H_eff_main)).max())}
             solver.h.set_options(solver.options)
         # (4) N = 1: what the DROP-IN caller waits for.  `value` times lz_run; a user of the reference calls
         # Lanczos(H).execute_Lanczos(k) and reads .H_eigvals / .V / .H_eigvecs (Lanczos.py:75-163).  Wall seconds of each through
@@ -601,6 +628,9 @@ def main():
         # second call on the unchanged H (hash only + solve), then the lazily fetched results.
         if world == 1 and not args.no_class_surface and hasattr(local, "to_scipy"):
             arm_state["arm"] = "class_surface"
+            if 16.0 * M * k > 120e9:
+                # (C4: the class-surface object allocates its own 160 GB basis - release this solver's first; it is not used again)
+                solver.h.close()
             line_cs = class_surface(lanczos_amd, local, k)
             if rank == 0:
                 line["class_surface"] = line_cs
@@ -613,7 +643,10 @@ def main():
             if rank == 0:
                 print(json.dumps(line), flush=True)
             os._exit(4)
-        solver.h.set_options(solver.options)
+        try:
+            solver.h.set_options(solver.options)
+        except Exception:
+            pass  # (the handle was released for the class-surface arm)
     watchdog.cancel()
     arm_state["arm"] = "none"
 

@@ -302,6 +302,9 @@ int lz_gram_info(lz_handle h, double* info4);
  * (CSR or dense), the 2 n sums travel in one all-reduce, every rank receives the same n values. */
 int lz_ritz_quality(lz_handle h, double* out);
 int lz_get_timings(lz_handle h, lz_timings* out);
+/* The collectives behind lz_timings.launches[LZ_K_COMM] of the interval the LAST lz_get_timings closed, by kind: all-reduces
+ * (alpha / ||r||^2 / coefficient sums) and SpMV-input exchanges (halo send/recv group or all-gather). */
+int lz_comm_counts(lz_handle h, int64_t* allreduces, int64_t* exchanges);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
 int lz_last_sweeps(lz_handle h, int* sweeps);
 /* LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE only (else 0): vectors of the last lz_run whose exact omega-recurrence estimate

@@ -125,6 +125,7 @@ SIGNATURES = {
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
     "lz_last_sweeps": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_last_sweep_misses": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "lz_comm_counts": (C.c_int, [_P, _I64, _I64]),
     "lz_last_engine": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_last_host_syncs": (C.c_int, [_P, _I64]),
     "lz_basis_alloc": (C.c_int, [_P, C.c_int]),
@@ -602,6 +603,9 @@ class Handle:
         t = LzTimings()
         self.check(self.lib.lz_get_timings(self._h, C.byref(t)))
         out = {"total_ms": t.total_ms}
+        ar, ex = C.c_int64(), C.c_int64()
+        self.check(self.lib.lz_comm_counts(self._h, C.byref(ar), C.byref(ex)))
+        out["allreduces"], out["exchanges"] = ar.value, ex.value  # the collectives of this interval by kind
         for i, k in enumerate(KERNEL_CLASSES):
             out[k] = {"ms": t.ms[i], "timed_bytes": t.timed_bytes[i], "timed_launches": int(t.timed_launches[i]),
                       "bytes": t.bytes[i], "flops": t.flops[i], "launches": int(t.launches[i])}

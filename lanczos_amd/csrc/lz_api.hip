@@ -184,6 +184,7 @@ int drain_events(lz_handle h) {
 int comm_allreduce(lz_handle h, double* dbuf, int64_t count) {
   if ((h->world <= 1 && !(h->tune[6] && h->comm_kind)) || count <= 0) return LZ_OK;
   Scope sc(h, LZ_K_COMM, 8.0 * count, 0);
+  h->n_allreduce += 1;
   if (h->comm_kind == 1) {
     LZ_NCCL(h, g_rccl.AllReduce(dbuf, dbuf, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream));
     return LZ_OK;
@@ -209,6 +210,7 @@ int comm_exchange_x(lz_handle h, int j, const double** x_out) {
   if (h->xmode == 1) {
     if (h->peers.empty()) return LZ_OK;
     Scope sc(h, LZ_K_COMM, 8.0 * (h->total_send + h->total_recv), 0);
+    h->n_exchange += 1;
     const bool direct = h->all_contig && h->comm_kind == 1;  // contiguous faces are sent straight out of V[j]
     if (!direct) {
       launch_gather(vj, h->d_send_idx, h->total_send, h->d_sendbuf, h->stream);
@@ -241,6 +243,7 @@ int comm_exchange_x(lz_handle h, int j, const double** x_out) {
   }
   if (h->xmode == 2) {
     Scope sc(h, LZ_K_COMM, 8.0 * h->ag_chunk * h->world, 0);
+    h->n_exchange += 1;
     if (h->comm_kind == 1) {
       LZ_NCCL(h, g_rccl.AllGather(vj, h->d_xfull, (size_t)h->ag_chunk, ncclDouble, h->comm, h->stream));
     } else {
@@ -538,6 +541,7 @@ int lz::api::basis_alloc(lz_handle h, int n, int zero_rows) {
   h->qplan = plan_qtw(h->rows_pad, h->flags, h->tune, n);
   size_t need = (size_t)(n + 16) * (size_t)h->qplan.P;
   if (h->flags & LZ_FLAG_ONE_REDUCE) need = (size_t)2 * qtw_ldp(n + 2) * (size_t)h->qplan.P;
+  if ((h->flags & LZ_FLAG_ONE_REDUCE) && (h->flags & LZ_FLAG_REORTH_PARTIAL)) need = onered_part_off(h) + std::max<size_t>(need, 8192);
   if (h->qplan.G <= 8) need = std::max<size_t>(need, fused_coff(h) + (size_t)(n + 16) * (size_t)h->qplan.G);  // fused small-problem path
   need = std::max<size_t>(need, 8192);  // (>= 3 x 2048: the three self-term partial runs of k_three_term_self)
   need = std::max<size_t>(need, (size_t)(h->rows / 4 + 64));                     // dense gemv / scalar spmv partials
@@ -669,6 +673,16 @@ int lz_get_timings(lz_handle h, lz_timings* out) {
   LZ_TRY(drain_events(h));
   *out = h->acc;
   memset(&h->acc, 0, sizeof(h->acc));
+  h->n_allreduce_last = h->n_allreduce;
+  h->n_exchange_last = h->n_exchange;
+  h->n_allreduce = h->n_exchange = 0;
+  return LZ_OK;
+}
+
+int lz_comm_counts(lz_handle h, int64_t* allreduces, int64_t* exchanges) {
+  if (!h || !allreduces || !exchanges) return LZ_ERR_ARG;
+  *allreduces = h->n_allreduce_last;
+  *exchanges = h->n_exchange_last;
   return LZ_OK;
 }
 

@@ -122,6 +122,8 @@ struct lz_context {
   int halo_inflight_j = -1;
   std::vector<std::pair<int64_t, int64_t>> bnd_ranges, int_ranges;  // double2 position ranges of a basis row
   int64_t total_send = 0, total_recv = 0;
+  int64_t n_allreduce = 0, n_exchange = 0;            // collectives issued since the last lz_get_timings ...
+  int64_t n_allreduce_last = 0, n_exchange_last = 0;  // ... and in the interval that call closed (lz_comm_counts)
   int32_t* d_send_idx = nullptr;
   double* d_sendbuf = nullptr;
   int64_t ag_chunk = 0;
@@ -231,6 +233,7 @@ int step_spmv(lz_handle h, int j, double* alpha_dst = nullptr, bool reduce = tru
 int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in_run_loop = false);
 int step_three_term(lz_handle h, int j, int jm1, const double* d_alpha, const double* d_beta, bool need_norm = true);
 size_t fused_coff(lz_handle h);
+size_t onered_part_off(lz_handle h);
 int breakdown_status(lz_handle h, int n, const double* alpha_out, const double* beta_out);
 
 // basis (lz_api.hip)

@@ -161,7 +161,10 @@ hipError_t launch_qtw(double* V, int64_t ldv, int64_t len, int nrows, int j, con
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
                    double* beta, int variant, hipStream_t s, int64_t pos_lo = 0, int64_t pos_hi = -1, int raw_c = 0,
                    int64_t pos_lo_b = 0, int64_t pos_hi_b = 0,  // second range: only with the small-range (face) kernel
-                   int cG = 0, int cldp = 0, const int* gate = nullptr);
+                   int cG = 0, int cldp = 0, const int* gate = nullptr,
+                   // one-reduce partial loop (r_fused, raw_c == 1, gate): w = (r_fused - asub[0] usub) / beta formed in the kernel; gate[0] == 0:
+                   // V[j] = w (no sweep) instead of returning
+                   const double* usub = nullptr, const double* asub = nullptr);
 // gate != nullptr: runs only when gate[0] == 0 (the step without a sweep)
 void launch_scale_store(double* vj, const double* r, const double* nrm2, double* beta_slot, int64_t len, hipStream_t s, const int* gate = nullptr);
 // ---- device-resident partial re-orthogonalisation (Simon's omega-recurrence in a one-block kernel) ----

@@ -117,6 +117,7 @@ int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in
   LZ_HIP(h, hipStreamWaitEvent(h->cstream, h->e_bnd, 0));
   h->acc.bytes[LZ_K_COMM] += 8.0 * (h->total_send + h->total_recv);
   h->acc.launches[LZ_K_COMM] += 1;
+  h->n_exchange += 1;
   LZ_NCCL(h, g_rccl.GroupStart());
   for (size_t p = 0; p < h->peers.size(); ++p) {
     if (h->scount[p] > 0)
@@ -213,6 +214,13 @@ int run_loop_onereduce(lz_handle h, int n) {
 // prologue of their consumer: [pass 1: alpha from the SpMV's block partials, r = (y - alpha v) - beta v', stage, dots]
 // [pass 2: coefficients from pass 1's block partials, update] [SpMV].  Same arithmetic, same summation trees: bit-identical
 // to the six-launch path (tests/test_gpu_small.py).
+// one-reduce partial loop: where the self terms' (and pass 1's) partials start in d_part - behind the alpha partials of ANY SpMV plan
+size_t onered_part_off(lz_handle h) {
+  size_t np = std::max<size_t>((size_t)h->rows / 4 + 2, (size_t)std::max(h->csr.n_rowblk, 1));
+  if (h->csr.pb) np = std::max<size_t>(np, (size_t)pb_num_partials(h->csr.pb));
+  return (np + 64 + 63) / 64 * 64;
+}
+
 size_t fused_coff(lz_handle h) {  // where pass 1's partials start in d_part (behind the SpMV's alpha partials)
   const size_t npmax = std::max<size_t>((size_t)h->rows / 4 + 2, (size_t)std::max(h->csr.n_rowblk, 1)) + 64;
   return (npmax + 63) / 64 * 64;
@@ -673,8 +681,12 @@ int run_loop_partial_onereduce(lz_handle h, int n) {
     launch_partial_onered_post(nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, -1, n, h->d_om, h->d_omi, kappa, h->stream);
     LZ_TRY(check_launch(h, "partial_onered_post(init)"));
   }
+  unsigned* ticket = reinterpret_cast<unsigned*>(h->d_omi + omega_onered_ints(n));
+  LZ_HIP(h, hipMemsetAsync(ticket, 0, sizeof(unsigned), h->stream));
+  const bool lean = h->tune[18] != 3;  // (knob 18 = 3: every folded stage as a kernel of its own - the first form of this loop, kept as the A/B arm)
   LZ_TRY(step_spmv(h, 0, h->d_c + onered_slot(0), false));  // warm-up: r'' = A v0 (Lanczos.py:108), alpha0 partial
   const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
+  const size_t self_off = onered_part_off(h);  // the self terms' partials live behind the SpMV's alpha partials in d_part
   for (int j = 0; j < n; ++j) {
     h->prof_iter = (j % pstride) == pstride / 2;
     const int bidx = (j + n - 2) % (n - 1);
@@ -689,11 +701,15 @@ int run_loop_partial_onereduce(lz_handle h, int n) {
     {
       QtwFuse fz;
       fz.gate = gate;
+      if (lean) {  // pass 1's last block adds the blocks' runs itself (k_final_rows_t's order)
+        fz.ticket = ticket;
+        fz.c_out = buf;
+      }
       Scope sc(h, LZ_K_QTW, 0, 0);  // (bytes of the launches that really ran: accounted after the run from the device's sweep log)
-      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, m, urow, h->d_r, nullptr, nullptr, h->qplan, h->d_part, 3, h->stream, &fz));
+      LZ_HIP(h, launch_qtw(h->d_V, h->ldv, h->rows_pad, m, urow, h->d_r, nullptr, nullptr, h->qplan, h->d_part + (lean ? self_off : 0), 3, h->stream, &fz));
       LZ_TRY(check_launch(h, "qtw(two columns, gated)"));
     }
-    {
+    if (!lean) {
       Scope sc(h, LZ_K_FINAL, 0, 0);
       launch_final_rows_t(h->d_part, h->qplan.G, 2 * ldp, ldp + m + 2, buf, h->stream, gate);
       LZ_TRY(check_launch(h, "final_rows(gated)"));
@@ -705,44 +721,58 @@ int run_loop_partial_onereduce(lz_handle h, int n) {
                                  h->d_om, h->d_omi, kappa, h->stream);
       LZ_TRY(check_launch(h, "partial_onered_post"));
     }
-    {
-      Scope sc(h, LZ_K_THREE, 24.0 * M, 2.0 * M);
-      launch_three_term(h->d_r, u, nullptr, h->d_alpha + urow, nullptr, h->rows_pad, h->d_part, h->stream);  // r = r'' - alpha u
-      LZ_TRY(check_launch(h, "three_term(alpha)"));
-    }
-    {
-      Scope sc(h, LZ_K_UPDATE, 0, 0);
-      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, buf, h->d_r, h->d_beta + bidx, 0, h->stream, 0, -1, 1, 0, 0, 0, 0, gate);
-      LZ_TRY(check_launch(h, "update(gated)"));
-    }
-    {
-      Scope sc(h, LZ_K_QTW, 16.0 * M, M);
-      launch_scale_store(vj, h->d_r, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream, gate);
-      LZ_TRY(check_launch(h, "scale_store(gated)"));
-    }
-    LZ_TRY(step_spmv(h, j, last ? h->d_alpha + j : bufn + onered_slot(j + 1), last));  // the last alpha has no pass to ride on
-    if (!last) {
-      // r'' = A V[j] - beta V[j-1] (at j = 0 the reference's V[-1] is the zero row) + the self terms of the next step's ||r||^2
-      const int mn = j + 1, ldpn = onered_ldp(mn);
-      int G3 = 0;
+    if (lean) {
+      // ONE launch forms w = (r'' - alpha u) / beta and either sweeps (V[j] = 2 w - sum c_i V_i) or stores V[j] = w
+      Scope sc(h, LZ_K_UPDATE, 32.0 * M, 4.0 * M);  // (a sweep's basis rows: accounted after the run)
+      launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, buf, h->d_r, h->d_beta + bidx, 0, h->stream, 0, -1, 1, 0, 0, 0, 0, gate, u, h->d_alpha + urow);
+      LZ_TRY(check_launch(h, "update | scale (gated)"));
+    } else {
       {
-        Scope sc(h, LZ_K_THREE, (j > 0 ? 40.0 : 16.0) * M, (j > 0 ? 8.0 : 6.0) * M);
-        G3 = launch_three_term_self(h->d_r, vj, j > 0 ? h->d_V + (int64_t)(j - 1) * h->ldv : nullptr, h->d_beta + bidx, h->rows_pad, h->d_part, h->stream);
-        LZ_TRY(check_launch(h, "three_term(beta) + self terms"));
+        Scope sc(h, LZ_K_THREE, 24.0 * M, 2.0 * M);
+        launch_three_term(h->d_r, u, nullptr, h->d_alpha + urow, nullptr, h->rows_pad, h->d_part, h->stream);  // r = r'' - alpha u
+        LZ_TRY(check_launch(h, "three_term(alpha)"));
       }
-      FinalMulti fm;
-      for (int q = 0; q < 3; ++q) {
-        fm.part[q] = h->d_part + (size_t)q * G3;
-        fm.n[q] = G3;
+      {
+        Scope sc(h, LZ_K_UPDATE, 0, 0);
+        launch_update(h->d_V, h->ldv, h->rows_pad, j + 1, j, buf, h->d_r, h->d_beta + bidx, 0, h->stream, 0, -1, 1, 0, 0, 0, 0, gate);
+        LZ_TRY(check_launch(h, "update(gated)"));
       }
-      fm.out[0] = bufn + mn;             // r''.r''
-      fm.out[1] = bufn + ldpn + mn + 1;  // u.r''
-      fm.out[2] = bufn + ldpn + mn;      // u.u
-      fm.part[3] = nullptr, fm.n[3] = 0, fm.out[3] = nullptr;
-      Scope sc(h, LZ_K_FINAL, 0, 0);
-      launch_final_sum_multi(fm, 3, h->stream);
-      LZ_TRY(check_launch(h, "final_sum(self terms)"));
+      {
+        Scope sc(h, LZ_K_QTW, 16.0 * M, M);
+        launch_scale_store(vj, h->d_r, h->d_nrm2, h->d_beta + bidx, h->rows_pad, h->stream, gate);
+        LZ_TRY(check_launch(h, "scale_store(gated)"));
+      }
     }
+    if (last) {
+      LZ_TRY(step_spmv(h, j, h->d_alpha + j, true));  // the last alpha has no pass to ride on
+      break;
+    }
+    // r'' = A V[j] - beta V[j-1] (at j = 0 the reference's V[-1] is the zero row) + the self terms of the next step's ||r||^2;
+    // the four second-stage sums (alpha's partial and the three self terms) leave in one launch
+    const int mn = j + 1, ldpn = onered_ldp(mn);
+    int npa = 0, G3 = 0;
+    if (lean)
+      LZ_TRY(step_spmv(h, j, nullptr, false, &npa));
+    else
+      LZ_TRY(step_spmv(h, j, bufn + onered_slot(mn), false));
+    double* spart = h->d_part + (lean ? self_off : 0);
+    {
+      Scope sc(h, LZ_K_THREE, (j > 0 ? 40.0 : 16.0) * M, (j > 0 ? 8.0 : 6.0) * M);
+      G3 = launch_three_term_self(h->d_r, vj, j > 0 ? h->d_V + (int64_t)(j - 1) * h->ldv : nullptr, h->d_beta + bidx, h->rows_pad, spart, h->stream);
+      LZ_TRY(check_launch(h, "three_term(beta) + self terms"));
+    }
+    FinalMulti fm;
+    for (int q = 0; q < 3; ++q) {
+      fm.part[q] = spart + (size_t)q * G3;
+      fm.n[q] = G3;
+    }
+    fm.out[0] = bufn + mn;             // r''.r''
+    fm.out[1] = bufn + ldpn + mn + 1;  // u.r''
+    fm.out[2] = bufn + ldpn + mn;      // u.u
+    fm.part[3] = h->d_part, fm.n[3] = npa, fm.out[3] = bufn + onered_slot(mn);  // alpha's partial (k_final_sum's grouping)
+    Scope sc(h, LZ_K_FINAL, 0, 0);
+    launch_final_sum_multi(fm, lean ? 4 : 3, h->stream);
+    LZ_TRY(check_launch(h, "final_sum(alpha, self terms)"));
   }
   return LZ_OK;
 }

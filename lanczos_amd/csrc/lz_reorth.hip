@@ -784,12 +784,12 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
     }
     __builtin_nontemporal_store(((k0[i] + k0[run + i]) + k0[2 * run + i]) + k0[3 * run + i], mine + i);
   }
-  // Device-resident partial re-orthogonalisation (fz.ticket != nullptr; SCALE == 1, no row split): the block that finishes LAST
+  // Device-resident partial re-orthogonalisation (fz.ticket != nullptr; SCALE == 1 or 3, no row split): the block that finishes LAST
   // adds up every block's run itself - k_final_rows_t's additions in k_final_rows_t's order, so c has the same bits - which
   // saves that kernel's launch in the 99 % of steps where this kernel returns at its first line.  The release / acquire
   // pair around the ticket costs more than the launch it replaces (the two-sided links measured 2-4x), but only a step that
   // really sweeps pays it.
-  if constexpr (SCALE == 1) {
+  if constexpr (SCALE == 1 || SCALE == 3) {
     if (fz.ticket != nullptr) {
       __shared__ unsigned s_last;
       __threadfence();  // this block's run is visible device-wide before its ticket is
@@ -801,7 +801,8 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
         double* smf = reinterpret_cast<double*>(sw);  // [128][8] doubles of the (now free) slice image
         constexpr int S = kFinalThreads / 8;
         const int P = (int)gridDim.x;
-        for (int g8 = 0; g8 < (nrows + 7) / 8; ++g8) {
+        const int ldrun = NCOL * ldp;  // (one-reduce mode: runs of 2 ldp doubles, ldp + nrows + 2 of them meaningful)
+        for (int g8 = 0; g8 < (nout + 7) / 8; ++g8) {
 #pragma unroll
           for (int q = 0; q < kFinalThreads / kTPB; ++q) {  // a 256-thread block plays k_final_rows_t's 1024 threads
             const int vt = threadIdx.x + q * kTPB;
@@ -810,16 +811,16 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             int pid = pl;
             for (; pid + 3 * S < P; pid += 4 * S) {
-              a0 += p[(int64_t)pid * ldp];
-              a1 += p[(int64_t)(pid + S) * ldp];
-              a2 += p[(int64_t)(pid + 2 * S) * ldp];
-              a3 += p[(int64_t)(pid + 3 * S) * ldp];
+              a0 += p[(int64_t)pid * ldrun];
+              a1 += p[(int64_t)(pid + S) * ldrun];
+              a2 += p[(int64_t)(pid + 2 * S) * ldrun];
+              a3 += p[(int64_t)(pid + 3 * S) * ldrun];
             }
-            for (; pid < P; pid += S) a0 += p[(int64_t)pid * ldp];
+            for (; pid < P; pid += S) a0 += p[(int64_t)pid * ldrun];
             smf[pl * 8 + rl] = (a0 + a1) + (a2 + a3);
           }
           __syncthreads();
-          if (threadIdx.x < 8 && g8 * 8 + (int)threadIdx.x < nrows) {
+          if (threadIdx.x < 8 && g8 * 8 + (int)threadIdx.x < nout) {
             double t = 0.0;
             for (int k = 0; k < S; ++k) t += smf[k * 8 + threadIdx.x];
             fz.c_out[g8 * 8 + threadIdx.x] = t;
@@ -1035,12 +1036,21 @@ __global__ __launch_bounds__(kTPB) void k_update(double* __restrict__ V, int64_t
 // block of a residency round finishes at about the same time, so the 8M bytes of stores arrive as a few bursts at the
 // end instead of trickling in between the reads for the whole launch.  A 1 % trickle of writes costs ~15 % of HBM read
 // throughput on MI355X (tools/probes/hbm_read_peak.hip: 6.8 -> 5.8 TB/s), presumably read<->write bus turnarounds.
-template <bool FUSED, int P, int RU>
+// MODE 1 (one-reduce partial loop; FUSED, raw_c == 1): w = (r'' - alpha u) / beta is formed here from the two-term residual r'' (`r`),
+// the newest basis vector u (`usub`) and alpha (`asub`) - k_three_term's expression, then the division - and the gate selects
+// between the sweep (V[j] = 2 w - sum c_i V_i) and the plain V[j] = w: one launch per step does either.
+template <bool FUSED, int P, int RU, int MODE = 0>
 __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, int64_t ldv, int64_t p0, int64_t n2, int nrows,
                                                       int j, const double* __restrict__ c, const double* __restrict__ r,
                                                       double* __restrict__ beta, int raw_c, int nblk_a, int64_t p0b,
-                                                      int64_t n2b, int cG, int cldp, const int* __restrict__ gate) {
-  if (gate && gate[0] == 0) return;  // device-resident partial re-orthogonalisation: no sweep on this vector
+                                                      int64_t n2b, int cG, int cldp, const int* __restrict__ gate,
+                                                      const double* __restrict__ usub, const double* __restrict__ asub) {
+  bool sweep = true;
+  if (MODE == 1) {
+    sweep = gate[0] != 0;
+  } else if (gate && gate[0] == 0) {
+    return;  // device-resident partial re-orthogonalisation: no sweep on this vector
+  }
   // blocks [0, nblk_a) cover positions [p0, n2); any further blocks cover a second range [p0b, n2b) (the two faces of a
   // slab in overlap mode leave in one launch)
   int bx = blockIdx.x;
@@ -1084,13 +1094,20 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
   }
   if (FUSED) {
     const double b = raw_c ? bnorm : beta[0];
+    const double a = MODE == 1 ? asub[0] : 0.0;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       w[p] = reinterpret_cast<const double2*>(r)[pos[p]];
+      if (MODE == 1) {
+        const double2 uu = reinterpret_cast<const double2*>(usub)[pos[p]];
+        w[p].x = w[p].x - uu.x * a;
+        w[p].y = w[p].y - uu.y * a;
+      }
       w[p].x = w[p].x / b;
       w[p].y = w[p].y / b;
     }
   }
+  if (MODE == 1 && !sweep) nrows = 0;  // no sweep on this vector: V[j] = w
   double tx[P], ty[P];
 #pragma unroll
   for (int p = 0; p < P; ++p) tx[p] = ty[p] = 0.0;
@@ -1122,7 +1139,7 @@ __global__ __launch_bounds__(kTPB) void k_update_slice(double* __restrict__ V, i
   double2* out = reinterpret_cast<double2*>(V) + (int64_t)j * ld2;
 #pragma unroll
   for (int p = 0; p < P; ++p)
-    if (ok[p]) st_stream<1>(out + pos[p], make_double2(2.0 * w[p].x - tx[p], 2.0 * w[p].y - ty[p]));
+    if (ok[p]) st_stream<1>(out + pos[p], (MODE == 1 && !sweep) ? w[p] : make_double2(2.0 * w[p].x - tx[p], 2.0 * w[p].y - ty[p]));
 }
 
 // Pass 2 for SHORT vectors with many basis rows (1Ddeuteron.py: M = n = 1001): the walk over the rows is a latency chain
@@ -1182,16 +1199,23 @@ __global__ __launch_bounds__(kTPB) void k_update_elem(double* __restrict__ V, in
 template <bool FUSED, int P, int RU>
 static void launch_update_slice(double* V, int64_t ldv, int64_t p0, int64_t n2, int nrows, int j, const double* c, const double* r,
                                 double* beta, int raw_c, hipStream_t s, int64_t p0b = 0, int64_t n2b = 0, int cG = 0, int cldp = 0,
-                                const int* gate = nullptr) {
+                                const int* gate = nullptr, const double* usub = nullptr, const double* asub = nullptr) {
   const int grid = (int)((n2 - p0 + kTPB * P - 1) / (kTPB * P));
   const int grid_b = n2b > p0b ? (int)((n2b - p0b + kTPB * P - 1) / (kTPB * P)) : 0;
+  if constexpr (FUSED) {
+    if (usub) {  // one-reduce partial loop: the three-term subtraction and the sweep / no-sweep choice live in the kernel
+      hipLaunchKernelGGL((k_update_slice<true, P, RU, 1>), dim3(grid + grid_b), dim3(kTPB), 0, s, V, ldv, p0, n2, nrows, j, c, r, beta, raw_c, grid, p0b, n2b,
+                         cG, cldp, gate, usub, asub);
+      return;
+    }
+  }
   hipLaunchKernelGGL((k_update_slice<FUSED, P, RU>), dim3(grid + grid_b), dim3(kTPB), raw_c == 2 ? (size_t)nrows * sizeof(double) : 0, s, V, ldv, p0,
-                     n2, nrows, j, c, r, beta, raw_c, grid, p0b, n2b, cG, cldp, gate);
+                     n2, nrows, j, c, r, beta, raw_c, grid, p0b, n2b, cG, cldp, gate, (const double*)nullptr, (const double*)nullptr);
 }
 
 void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const double* c, const double* r_fused,
                    double* beta, int variant, hipStream_t s, int64_t pos_lo, int64_t pos_hi, int raw_c, int64_t pos_lo_b,
-                   int64_t pos_hi_b, int cG, int cldp, const int* gate) {
+                   int64_t pos_hi_b, int cG, int cldp, const int* gate, const double* usub, const double* asub) {
   // gate (device-resident partial re-orthogonalisation): the default slice-owner kernels only
   // double2 positions [pos_lo, pos_hi) of the row (default: the whole row)
   const int64_t n2 = pos_hi >= 0 ? pos_hi : (len >> 1);
@@ -1233,7 +1257,7 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
   if (variant == 6 || (variant == 0 && P == 16 && span > 16384)) {
     // 16 positions per lane, one row per trip (still 16 loads in flight): half as many, longer-lived blocks - fewer
     // residency rounds, so V[j] leaves in fewer, larger write bursts (1250 -> 1218 us at the headline)
-    if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate);
+    if (r_fused) launch_update_slice<true, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate, usub, asub);
     else launch_update_slice<false, 16, 1>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
     return;
   }
@@ -1247,16 +1271,16 @@ void launch_update(double* V, int64_t ldv, int64_t len, int nrows, int j, const 
   if ((variant == 0 && span <= 16384) || variant == 5) {
     // a face of the slab (overlap mode) or a tiny vector: a handful of blocks walk all rows, which is a latency chain,
     // not a bandwidth problem - one position per lane (most blocks) and 32 rows in flight per lane
-    if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, pos_lo_b, pos_hi_b, cG, cldp, gate);
+    if (r_fused) launch_update_slice<true, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, pos_lo_b, pos_hi_b, cG, cldp, gate, usub, asub);
     else launch_update_slice<false, 1, 32>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, pos_lo_b, pos_hi_b, 0, 0, gate);
   } else if (P == 8) {
-    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate);
+    if (r_fused) launch_update_slice<true, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate, usub, asub);
     else launch_update_slice<false, 8, 2>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   } else if (P == 4) {
-    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate);
+    if (r_fused) launch_update_slice<true, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate, usub, asub);
     else launch_update_slice<false, 4, 4>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   } else {
-    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate);
+    if (r_fused) launch_update_slice<true, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, raw_c, s, 0, 0, cG, cldp, gate, usub, asub);
     else launch_update_slice<false, 2, 8>(V, ldv, p0, n2, nrows, j, c, r_fused, beta, 0, s, 0, 0, 0, 0, gate);
   }
 }

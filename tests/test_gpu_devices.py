@@ -260,6 +260,17 @@ def test_bench_self_spawn_two_ranks_on_one_gpu():
     assert line["comm_calls_per_step"] == 3 * 100 + 2  # (k + 1) exchanges + (k + 1) alpha all-reduces + k coefficient all-reduces
     assert line["partial_reorth"] is not None and line["one_reduce_arm"] is not None  # both extra arms ran
     assert "stalled" not in line and line["value"] > 0 and line["roofline"]["kernel"] in ("qtw", "update", "spmv")
+    # collectives per Lanczos iteration, by kind: the default loops - full sweep 2 all-reduces + 1 exchange, the
+    # device-decided partial loop 3 + 1; the one-reduce arm - ONE all-reduce + one exchange for BOTH re-orthogonalisation modes
+    cpi = line["comm_calls_per_iteration"]
+    assert abs(cpi["allreduce"] - 2.0) < 0.02 and abs(cpi["exchange"] - 1.0) < 0.02, cpi
+    cpp = line["partial_reorth"]["comm_calls_per_iteration"]
+    assert line["partial_reorth"]["engine"] == "partial-device" and abs(cpp["allreduce"] - 3.0) < 0.03 and abs(cpp["exchange"] - 1.0) < 0.02, cpp
+    arm = line["one_reduce_arm"]
+    assert abs(arm["comm_calls_per_iteration"] - 2.0) < 0.03, arm
+    pa = arm["partial"]
+    assert pa["engine"] == "partial-one-reduce" and pa["lookahead_misses"] == 0 and pa["max_rel_ritz_diff_vs_full"] < 1e-10, pa
+    assert abs(pa["comm_calls_per_iteration"]["allreduce"] - 1.0) < 0.02 and abs(pa["comm_calls_per_iteration"]["exchange"] - 1.0) < 0.02, pa
 
 
 def test_a_dying_worker_ends_the_pool_and_is_reported():

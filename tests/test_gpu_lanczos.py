@@ -797,6 +797,12 @@ def test_partial_one_reduce_loop(hip, build, n, well):
     h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
     a2, b2 = h.run(n, v0)
     assert np.array_equal(a2, o["a"]) and np.array_equal(b2, o["b"]) and np.array_equal(h.get_basis(), o["V"]) and h.last_sweeps() == o["sweeps"]
+    # knob 18 = 3: the loop's first form - second-stage sums, the alpha subtraction, the sweep and the plain scale as kernels of their
+    # own (10 launches per step instead of 6) - same arithmetic, same summation trees: same bits
+    h.set_tuning(hip.TUNE_PARTIAL_LOOP, 3)
+    a4, b4 = h.run(n, v0)
+    assert np.array_equal(a4, o["a"]) and np.array_equal(b4, o["b"]) and np.array_equal(h.get_basis(), o["V"]) and h.last_sweeps() == o["sweeps"]
+    h.set_tuning(hip.TUNE_PARTIAL_LOOP, 0)
     # the look-ahead's safety factor (knob 20): a larger kappa can only sweep earlier / more often, never lose the bar
     h.set_tuning(hip.TUNE_PARTIAL_LOOKAHEAD, 64)
     a3, b3 = h.run(n, v0)
