@@ -134,10 +134,12 @@ int lz_set_options(lz_handle h, int flags);
  *       a lane owns whole rows - is built and used only by the partial re-orthogonalisation loop's fused SpMV; 27 entries per
  *       row, which have no CSR-order fixed-K kernel: ELL for every SpMV, 3 % faster than CSR-stream), 1 never ELL,
  *       2 ELL for every SpMV, one row per lane and trip, 3 ELL, two adjacent rows per lane (16-byte loads)
- *   19  Gram matrix of the Ritz vectors: 0 auto (accumulator-stationary symmetric kernel where it applies), 1 the split-K TN GEMM always
+ *   19  Gram matrix of the Ritz vectors: 0 auto (accumulator-stationary symmetric kernel, operands staged through LDS once per workgroup),
+ *       1 the split-K TN GEMM always, 2 the symmetric kernel with per-wave register rings (round 4; also what an odd n runs)
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
  *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta),
  *       3 device-resident with pass 1's second-stage sums as a kernel of their own (default: pass 1's last block adds them)
+ *   21  Gram matrix: number of K slices (workgroups per unit) of the symmetric kernel; 0 auto (whole residency rounds of 256)
  *   20  one-reduce partial loop (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE): safety factor kappa of the look-ahead sweep
  *       decision (a sweep is due when kappa * max |predicted omega| > sqrt(eps); 0 = the default, 4)
  * The product library returns LZ_ERR_ARG for everything that lives only in the kernel-bench build (make KBENCH=1 ->
@@ -229,8 +231,11 @@ int lz_set_halo(lz_handle h, int npeers, const int32_t* peers, const int64_t* se
 /* all-gather plan: every rank owns `chunk` padded rows; x_full has world*chunk entries. */
 int lz_set_allgather(lz_handle h, int64_t chunk);
 
-/* Optional: allocate the device buffers of the coming run EARLY - the (n, rows_local) Krylov basis and, with with_ritz != 0
- * and where it fits, the (rows_local, n) Ritz vectors.  A first hipMalloc of 16 GB costs 0.1-0.5 s on this platform; the
+/* Optional: allocate the device buffers of the coming run EARLY - the (n, rows_local) Krylov basis (with_ritz 0 or 1) and, where
+ * it fits, the (rows_local, n) Ritz vectors (with_ritz 1; with_ritz 2: the Ritz vectors ONLY - what the helper thread asks for
+ * while the solve already runs on the basis).  A hipMalloc of 16 GB costs 0.2 ms most of the time and 0.1 - 4 s now and then on
+ * this platform (since round 5 buffers of this size are a reserved virtual range backed by physical chunks, which has not been
+ * seen to stall: tools/probes/alloc_pattern_probe.hip); the
  * class mirror issues this call from a helper thread while it draws the start vector, hashes, validates and uploads the
  * matrix (Lanczos.py:85-104 does the same work in sequence), so lz_run / lz_ritz_vectors find their buffers ready.  It is the
  * ONE entry point that may run concurrently with another call on the same handle (lz_set_options / lz_set_tuning / lz_set_csr /

@@ -49,7 +49,8 @@ TUNE_SPMV_PLAN = 14         # irregular SpMV plan (0 auto, 1 never two-phase, 2 
 TUNE_LOOP = 15              # loop structure (0 auto, 1 six launches per step always)
 TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 forces it)
 TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto: CSR order, ELL only in the partial loop; 1 never ELL; 2 / 3 ELL always, one / two rows per lane)
-TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel, 1 split-K TN GEMM)
+TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel with LDS-staged operands, 1 split-K TN GEMM, 2 the register-ring form)
+TUNE_GRAM_SLICES = 21       # Gram matrix: K slices of the symmetric kernel (0 auto)
 TUNE_PARTIAL_LOOKAHEAD = 20 # one-reduce partial loop: safety factor of the look-ahead sweep decision (0 = default 4)
 TUNE_PARTIAL_LOOP = 18      # partial re-orthogonalisation loop (0 device-resident, 1 host-decided, 2 device-resident without the fused scale,
                             # 3 device-resident with a separate second-stage kernel behind pass 1)
@@ -474,10 +475,11 @@ class Handle:
 
     # -- run
     def reserve(self, rows_local, n, with_ritz=True):
-        """allocate the basis (and the Ritz vectors) of the coming run now; safe to call from a helper thread (see lz_reserve)"""
+        """allocate the basis (and the Ritz vectors) of the coming run now; safe to call from a helper thread (see lz_reserve).
+        ``with_ritz``: False the basis only, True both, 2 the Ritz vectors only."""
         with self._reserve_lock:
             if self._h:
-                self.check(self.lib.lz_reserve(self._h, int(rows_local), int(n), 1 if with_ritz else 0))
+                self.check(self.lib.lz_reserve(self._h, int(rows_local), int(n), 2 if with_ritz == 2 else (1 if with_ritz else 0)))
 
     def run(self, n, v0_local):
         v0 = f64(v0_local)

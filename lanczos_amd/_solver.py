@@ -367,46 +367,66 @@ class LanczosBase:
                     pass
                 basis_ready.set()
                 try:
-                    hres.reserve(M, n, with_ritz=True)  # the Ritz vectors: while the solve runs (lz_reserve touches only its own fields)
+                    hres.reserve(M, n, with_ritz=2)  # the Ritz vectors ONLY: while the solve runs (lz_reserve touches only its own fields)
                 except Exception:
                     pass
 
             reserve = threading.Thread(target=_reserve, name="lz-reserve", daemon=True)
             reserve.start()
             self._bg = reserve
-        cached = getattr(self, "_v0_cache", None)
-        if v0 is None and cached is not None and cached[0] == (seed, M):
-            # The default start vector is a pure function of (seed, M): a repeated call reuses the normalised vector of the last
-            # one (drawing 1e7 legacy-RNG doubles is 0.05 s - the whole overhead of a second call) and leaves the GLOBAL RNG exactly
-            # where the reference's `np.random.seed(seed); np.random.uniform(-1, 1, M)` would: the state saved right after the draw.
-            np.random.set_state(cached[2])
-            v0 = cached[1]
-        else:
-            np.random.seed(seed)
-            if v0 is None:
-                v0 = np.random.uniform(-1, 1, size=(M))
-                state = np.random.get_state()
-                v0 /= np.linalg.norm(v0)
-                self._v0_cache = ((seed, M), v0, state)  # (never written to again: lz_run only reads it)
-            else:
-                v0 = np.array(v0)
-                v0 = v0 / np.linalg.norm(v0)  # out of place, like the reference (Lanczos.py:100): an integer or list v0 becomes float64 here
-        t_1 = time.perf_counter()
-        if n < 2:
-            # the reference allocates beta = zeros(n-1) and writes beta[-1] at j = 0 (Lanczos.py:107,112)
-            raise IndexError("index -1 is out of bounds for axis 0 with size 0")
+        # ... and the matrix is packed, validated and uploaded on a third while this thread draws the start vector (round 5: the draw
+        # and normalisation of 1e7 legacy-RNG doubles is 0.05 - 0.14 s, the upload 0.05 - 0.08 s; both release the GIL).  Argument errors
+        # keep the reference's order - they are raised after the RNG has been seeded and drawn from - so the upload only starts when
+        # none is coming.
+        args_ok = n >= 2 and self.reorth in ("full", "partial")
+        upload, upload_err, h = None, [], None
+        if args_ok:
+            import threading
 
-        if self.reorth not in ("full", "partial"):
-            raise ValueError("reorth must be 'full' or 'partial'")
-        h = self._get_handle()
-        h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0)
-                      | (_capi.FLAG_FUSED_NORM if self.fused_norm else 0))
+            h = self._get_handle()
+            h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0)
+                          | (_capi.FLAG_FUSED_NORM if self.fused_norm else 0))
+
+            def _upload():
+                try:
+                    self._upload_matrix(h, pending_key)
+                except BaseException as e:  # re-raised in the calling thread
+                    upload_err.append(e)
+
+            upload = threading.Thread(target=_upload, name="lz-upload", daemon=True)
+            upload.start()
         try:
-            self._upload_matrix(h, pending_key)
+            cached = getattr(self, "_v0_cache", None)
+            if v0 is None and cached is not None and cached[0] == (seed, M):
+                # The default start vector is a pure function of (seed, M): a repeated call reuses the normalised vector of the last
+                # one (drawing 1e7 legacy-RNG doubles is 0.05 s - the whole overhead of a second call) and leaves the GLOBAL RNG exactly
+                # where the reference's `np.random.seed(seed); np.random.uniform(-1, 1, M)` would: the state saved right after the draw.
+                np.random.set_state(cached[2])
+                v0 = cached[1]
+            else:
+                np.random.seed(seed)
+                if v0 is None:
+                    v0 = np.random.uniform(-1, 1, size=(M))
+                    state = np.random.get_state()
+                    v0 /= np.linalg.norm(v0)
+                    self._v0_cache = ((seed, M), v0, state)  # (never written to again: lz_run only reads it)
+                else:
+                    v0 = np.array(v0)
+                    v0 = v0 / np.linalg.norm(v0)  # out of place, like the reference (Lanczos.py:100): an integer or list v0 becomes float64 here
+            t_1 = time.perf_counter()
+            if n < 2:
+                # the reference allocates beta = zeros(n-1) and writes beta[-1] at j = 0 (Lanczos.py:107,112)
+                raise IndexError("index -1 is out of bounds for axis 0 with size 0")
+            if self.reorth not in ("full", "partial"):
+                raise ValueError("reorth must be 'full' or 'partial'")
         finally:
+            if upload is not None:
+                upload.join()
             if reserve is not None:  # the basis must be reserved (or given up on) before lz_run looks for it
                 basis_ready.wait()
                 self._reserved = (M, n)
+        if upload_err:
+            raise upload_err[0]
         t_2 = time.perf_counter()
         alpha, beta = h.run(n, v0)
         t_3 = time.perf_counter()

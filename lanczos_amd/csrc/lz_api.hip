@@ -2,6 +2,8 @@
 // points; plus the helpers every part shares (error reporting, per-launch profiling scope, collectives).  The run loops are
 // in lz_loops.hip, matrix setup in lz_matrix.hip, Ritz vectors / Gram / quality in lz_ritz.hip, the two-sided variant in
 // lz_twosided_api.hip.  See include/lanczos_hip.h for the contract and the reference call sites each entry point replaces.
+#include <unordered_map>
+
 #include "lz_context.h"
 
 using namespace lz;
@@ -159,6 +161,107 @@ Scope::~Scope() {
     hipEventRecord(b, h->stream);
     h->events.push_back({cls, a, b});
   }
+}
+
+// ---- large device buffers (the Krylov basis, the Ritz vectors): virtual range + physical chunks -------------------------------
+// hipMalloc of the headline's 16 GB basis is what the first execute_Lanczos of an object used to wait for: 0.2 ms most of the
+// time, but 0.1 - 4.3 s every few calls on this pool (tools/probes/alloc_pattern_probe.hip, profiles/r05/alloc_pattern_probe.jsonl:
+// 3 of 17 hipMallocs of 16 GB stalled for 1 - 4 s, none of 8 reserve + create + map sequences took more than 0.5 ms, first and
+// second touch of the mapped range at the same rate as hipMalloc'ed memory).  So buffers of 256 MB and more are a reserved virtual
+// range backed by 2 GB physical chunks (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess); kernels see one
+// contiguous pointer.  Any failure on that path falls back to hipMalloc (LZ_NO_VMM=1 forces that).  A registry maps the base
+// pointer to its chunks so that dev_free / lz_destroy release either kind through big_free.
+namespace {
+struct BigBuf {
+  size_t bytes = 0;
+  std::vector<hipMemGenericAllocationHandle_t> chunks;
+  std::vector<size_t> sizes;
+};
+std::mutex g_big_mu;
+std::unordered_map<void*, BigBuf> g_big;
+constexpr size_t kBigChunk = (size_t)2 << 30;
+constexpr size_t kBigAlign = (size_t)2 << 20;
+
+void big_release(void* va, BigBuf& b) {
+  size_t off = 0;
+  for (size_t k = 0; k < b.chunks.size(); ++k) {
+    (void)hipMemUnmap(static_cast<char*>(va) + off, b.sizes[k]);
+    (void)hipMemRelease(b.chunks[k]);
+    off += b.sizes[k];
+  }
+  (void)hipMemAddressFree(va, b.bytes);
+}
+}  // namespace
+
+hipError_t big_alloc(int dev, void** out, size_t bytes) {
+  *out = nullptr;
+  static const bool no_vmm = getenv("LZ_NO_VMM") != nullptr;
+  if (!no_vmm && bytes >= kBigMinBytes) {
+    const size_t total = (bytes + kBigAlign - 1) / kBigAlign * kBigAlign;
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    hipMemAccessDesc acc;
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = dev;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    void* va = nullptr;
+    if (hipMemAddressReserve(&va, total, kBigAlign, nullptr, 0) == hipSuccess && va) {
+      BigBuf b;
+      b.bytes = total;
+      bool ok = true, oom = false;
+      for (size_t off = 0; off < total && ok; off += kBigChunk) {
+        const size_t sz = std::min(kBigChunk, total - off);
+        hipMemGenericAllocationHandle_t hh;
+        hipError_t e = hipMemCreate(&hh, sz, &prop, 0);
+        if (e != hipSuccess) {
+          ok = false;
+          oom = e == hipErrorOutOfMemory;
+          break;
+        }
+        b.chunks.push_back(hh);
+        b.sizes.push_back(sz);
+        if (hipMemMap(static_cast<char*>(va) + off, sz, 0, hh, 0) != hipSuccess) {
+          (void)hipMemRelease(hh);
+          b.chunks.pop_back();
+          b.sizes.pop_back();
+          ok = false;
+          break;
+        }
+        if (hipMemSetAccess(static_cast<char*>(va) + off, sz, &acc, 1) != hipSuccess) ok = false;  // (mapped: big_release unmaps it)
+      }
+      if (ok) {
+        std::lock_guard<std::mutex> lk(g_big_mu);
+        g_big.emplace(va, std::move(b));
+        *out = va;
+        return hipSuccess;
+      }
+      big_release(va, b);
+      (void)hipGetLastError();
+      if (oom) return hipErrorOutOfMemory;  // hipMalloc would say the same
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return hipMalloc(out, bytes);
+}
+
+hipError_t big_free(void* p) {
+  if (!p) return hipSuccess;
+  BigBuf b;
+  {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    auto it = g_big.find(p);
+    if (it == g_big.end()) return hipFree(p);
+    b = std::move(it->second);
+    g_big.erase(it);
+  }
+  // hipFree synchronises the device before it releases; an unmap does not: nothing may still run on the range
+  hipError_t e = hipDeviceSynchronize();
+  big_release(p, b);
+  return e;
 }
 
 int drain_events(lz_handle h) {
@@ -332,8 +435,8 @@ int lz_destroy(lz_handle h) {
   pb_free(h->csrT.pb);
   ell_free(h->csr);
   ell_free(h->csrT);
-  hipFree(h->d_dense);
-  hipFree(h->d_V);
+  big_free(h->d_dense);
+  big_free(h->d_V);
   hipFree(h->d_r);
   hipFree(h->d_r2);
   hipFree(h->d_alpha);
@@ -345,12 +448,12 @@ int lz_destroy(lz_handle h) {
   hipFree(h->csrT.colidx);
   hipFree(h->csrT.vals);
   hipFree(h->csrT.rowblk);
-  hipFree(h->d_B3);
+  big_free(h->d_B3);
   hipFree(h->d_s);
   hipFree(h->d_gamma);
   hipFree(h->d_bi);
   hipFree(h->d_xtmp);
-  hipFree(h->d_Y);
+  big_free(h->d_Y);
   hipFree(h->d_S);
   hipFree(h->d_rclk);
   hipFree(h->d_gram);
@@ -360,8 +463,8 @@ int lz_destroy(lz_handle h) {
   hipFree(h->d_xfull);
   hipFree(h->d_om);
   hipFree(h->d_omi);
-  hipFree(h->res_V);
-  hipFree(h->res_Y);
+  big_free(h->res_V);
+  big_free(h->res_Y);
   if (h->h_pinned) hipHostFree(h->h_pinned);
   xfer_free(h->xfer);
   if (h->cstream) {

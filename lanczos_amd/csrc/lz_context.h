@@ -188,10 +188,16 @@ int fail(lz_handle h, int code, const std::string& msg);
 int64_t skew_stride(lz_handle h, int64_t ld);
 int check_launch(lz_handle h, const char* what);
 
+// large buffers (>= kBigMinBytes: the basis, the Ritz vectors, a dense matrix): a reserved virtual range backed by physical chunks
+// instead of hipMalloc, whose 16 GB calls stall for seconds now and then on this pool (lz_api.hip); big_free releases either kind
+constexpr size_t kBigMinBytes = (size_t)256 << 20;
+hipError_t big_alloc(int dev, void** out, size_t bytes);
+hipError_t big_free(void* p);
+
 template <class T>
 inline int dev_free(lz_handle h, T*& p) {
   if (p) {
-    LZ_HIP(h, hipFree(p));
+    LZ_HIP(h, big_free(p));
     p = nullptr;
   }
   return LZ_OK;
@@ -201,7 +207,7 @@ template <class T>
 inline int dev_alloc(lz_handle h, T*& p, size_t count) {
   LZ_TRY(dev_free(h, p));
   void* q = nullptr;
-  LZ_HIP(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  LZ_HIP(h, big_alloc(h->dev, &q, std::max<size_t>(count, 1) * sizeof(T)));
   p = static_cast<T*>(q);
   return LZ_OK;
 }

@@ -1475,84 +1475,363 @@ __device__ __forceinline__ void gram_unit_wave(const double* __restrict__ Y, int
   gram_unit_store<NA, NB, DIAG, W>(acc, n, ta0, tb0, lr, lk, Cz, std::make_integer_sequence<int, NTW>());
 }
 
-template <int NA, int NB, bool DIAG>
-__global__ __launch_bounds__(kTPB) void k_gram_unit(const double* __restrict__ Y, int64_t ldy, int64_t rows, int64_t kchunk, int n, int CT,
-                                                   const int2* __restrict__ units, double* __restrict__ part) {
+// One launch covers every unit of the upper triangle of groups (round 5): blockIdx.y < npairs -> an off-diagonal pair, else a
+// triangle.  The pairs come first in the dispatch order (they are the long blocks: ceil(GS / 4) GS tiles on their busiest wave
+// against a triangle's ~GS (GS + 1) / 8 + ...), the triangles fill the tail - two launches had two tails.
+template <int GS>
+__global__ __launch_bounds__(kTPB) void k_gram_units(const double* __restrict__ Y, int64_t ldy, int64_t rows, int64_t kchunk, int n, int CT,
+                                                    const int2* __restrict__ units, int npairs, double* __restrict__ part) {
   const int64_t k_lo = (int64_t)blockIdx.x * kchunk;
   const int64_t k_hi = k_lo + kchunk < rows ? k_lo + kchunk : rows;
   double* Cz = part + (int64_t)blockIdx.x * n * n;
   const int2 u = units[blockIdx.y];  // {first row tile, first column tile}
-  switch (threadIdx.x >> 6) {
-    case 0: gram_unit_wave<NA, NB, DIAG, 0>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
-    case 1: gram_unit_wave<NA, NB, DIAG, 1>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
-    case 2: gram_unit_wave<NA, NB, DIAG, 2>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
-    default: gram_unit_wave<NA, NB, DIAG, 3>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+  if ((int)blockIdx.y < npairs) {
+    switch (threadIdx.x >> 6) {
+      case 0: gram_unit_wave<GS, GS, false, 0>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+      case 1: gram_unit_wave<GS, GS, false, 1>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+      case 2: gram_unit_wave<GS, GS, false, 2>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+      default: gram_unit_wave<GS, GS, false, 3>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+    }
+  } else {
+    switch (threadIdx.x >> 6) {
+      case 0: gram_unit_wave<GS, GS, true, 0>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+      case 1: gram_unit_wave<GS, GS, true, 1>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+      case 2: gram_unit_wave<GS, GS, true, 2>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+      default: gram_unit_wave<GS, GS, true, 3>(Y, ldy, k_lo, k_hi, n, CT, u.x, u.y, Cz); break;
+    }
   }
 }
 
-// out[r][c] = sum_z slice_z[r][c] for the upper 16 x 16 tiles, mirrored into the lower ones (fixed order of z)
-__global__ __launch_bounds__(kTPB) void k_sum_slices_sym(const double* __restrict__ part, int nz, int n, double* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * kTPB + threadIdx.x;
-  const int64_t count = (int64_t)n * n;
-  if (i >= count) return;
-  const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
-  const int64_t src = (r >> 4) <= (c >> 4) ? i : (int64_t)c * n + r;
-  double a0 = 0.0, a1 = 0.0;
-  int z = 0;
-  for (; z + 1 < nz; z += 2) {
-    a0 += part[(int64_t)z * count + src];
-    a1 += part[(int64_t)(z + 1) * count + src];
+// ---- round 5: the same two kernels with the row slab staged ONCE PER WORKGROUP through LDS -----------------------------------
+// What bounded the register-ring forms above is the operand fetch: every wave fetched its fragments itself, through L1, four
+// 128-byte lines per 8-byte-per-lane load (tools/probes/mfma_f64_operands: the same MFMA stream runs at 65 TF with operands loaded
+// per k-step from L1/L2 and at 73 TF with operands read from LDS).  Here the workgroup copies a block of KB k-steps (4 KB rows of
+// the unit's one or two column groups: contiguous runs of Y's rows) global -> registers -> LDS with coalesced 16-byte loads, double
+// buffered - the registers of block b + 1 are in flight while block b is multiplied, one barrier per block - and every wave reads
+// its fragments with ds_read_b64 (row stride = 128 bytes mod 256: the four rows of a fragment fall on disjoint banks, two passes
+// of 32 lanes, conflict free), two k-steps of fragments in registers so that the reads hide behind the previous step's MFMAs.
+// Tiles, their dealing to the waves, accumulators, stores and the slice sum are the kernels' above: bit-identical results
+// (same MFMAs in the same order per tile).  Needs an even n (16-byte aligned rows); odd n keeps the register-ring kernels.
+template <int GS, bool DIAG, int W>
+struct GramLdsUnitDeal {
+  using U = GramUnit<GS, GS, DIAG, W>;
+  // (pairs of 10 or 11 column tiles keep 30 / 33 accumulator tiles per wave - 240 / 264 registers: two k-steps per block, so that the
+  //  staging registers are few and nothing spills)
+  static constexpr int NF = U::NF > 0 ? U::NF : 1, NTW = U::NTW, NSEG = DIAG ? 1 : 2, SEGD = 16 * GS, KB = DIAG ? 8 : (GS >= 10 ? 2 : 4);
+  static constexpr int col(int t) { return DIAG ? 16 * (U::F0 + t) : (t < U::RW ? 16 * (W + 4 * t) : SEGD + 16 * (t - U::RW)); }
+  template <int Q>
+  struct Tile {
+    using T = GramUnitTile<GS, GS, DIAG, W, Q>;
+    static constexpr int fi = T::fi, fj = T::fj, it = T::it, jt = T::jt;
+  };
+};
+template <int CT, int W>
+struct GramLdsSymDeal {
+  static constexpr int NTRI = gram_tri_count(CT);
+  static constexpr int NF = CT, NTW = (NTRI - W + 3) / 4, NSEG = 1, SEGD = 16 * CT, KB = 8;
+  static constexpr int col(int t) { return 16 * t; }
+  template <int Q>
+  struct Tile {
+    using T = GramTile<CT, W, Q, 4>;
+    static constexpr int fi = T::i, fj = T::j, it = T::i, jt = T::j;
+  };
+};
+constexpr int gram_lds_stride(int rowd) { return (rowd * 8) % 256 == 128 ? rowd : rowd + 16; }  // doubles; 128 bytes mod 256
+constexpr size_t gram_lds_bytes(int nseg, int segd, int kb) { return (size_t)2 * 4 * kb * gram_lds_stride(nseg * segd) * sizeof(double); }
+
+template <class D, int... Q>
+__device__ __forceinline__ void gram_lds_mfmas(const double (&f)[D::NF], double4_t* acc, std::integer_sequence<int, Q...>) {
+  ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[D::template Tile<Q>::fi], f[D::template Tile<Q>::fj], acc[Q], 0, 0, 0)), ...);
+}
+template <class D, int Q>
+__device__ __forceinline__ void gram_lds_store_tile(const double4_t& a, int n, int ta0, int tb0, int lr, int lk, double* __restrict__ Cz) {
+  const int col = 16 * (tb0 + D::template Tile<Q>::jt) + lr;
+  if (col >= n) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int r = 16 * (ta0 + D::template Tile<Q>::it) + lk + 4 * g;
+    if (r < n) Cz[(int64_t)r * n + col] = a[g];
   }
-  if (z < nz) a0 += part[(int64_t)z * count + src];
-  out[i] = a0 + a1;
+}
+template <class D, int... Q>
+__device__ __forceinline__ void gram_lds_store(const double4_t* acc, int n, int ta0, int tb0, int lr, int lk, double* __restrict__ Cz,
+                                               std::integer_sequence<int, Q...>) {
+  (gram_lds_store_tile<D, Q>(acc[Q], n, ta0, tb0, lr, lk, Cz), ...);
+}
+
+// One wave's whole life (staging included: all four waves of the workgroup run their own instantiation of this function and meet at
+// the same barriers).  ca / cb: first column (doubles) of the one or two column groups in a row of Y.
+template <class D>
+__device__ __forceinline__ void gram_lds_wave(const double* __restrict__ Y, int64_t ldy, int64_t k_lo, int64_t k_hi, int n, int ca, int cb, int ta0,
+                                              int tb0, double* __restrict__ Cz, double* __restrict__ lds) {
+  constexpr int NF = D::NF, NTW = D::NTW, KB = D::KB, NROWB = 4 * KB;
+  constexpr int ROWD = D::NSEG * D::SEGD, S = gram_lds_stride(ROWD);
+  constexpr int ROW2 = ROWD / 2, SEG2 = D::SEGD / 2;   // double2 per staged row / per segment
+  constexpr int ITEMS = NROWB * ROW2;                  // double2 per block
+  constexpr int NR = (ITEMS + kTPB - 1) / kTPB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  double4_t acc[NTW > 0 ? NTW : 1];
+#pragma unroll
+  for (int q = 0; q < NTW; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  const int nblk = k_hi > k_lo ? (int)((k_hi - k_lo + NROWB - 1) / NROWB) : 0;
+  double2 rg[NR];
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int i = tid + q * kTPB;
+      rg[q] = make_double2(0.0, 0.0);
+      if (ITEMS % kTPB == 0 || i < ITEMS) {
+        const int row = i / ROW2, w = i - row * ROW2;
+        const int seg = D::NSEG == 2 ? w / SEG2 : 0, c2 = w - seg * SEG2;
+        const int64_t kr = k0 + row;
+        if (kr < k_hi) rg[q] = *reinterpret_cast<const double2*>(Y + kr * ldy + (seg ? cb : ca) + 2 * c2);  // rows past the range: zero
+      }
+    }
+  };
+  auto sstore = [&](double* buf) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int i = tid + q * kTPB;
+      if (ITEMS % kTPB == 0 || i < ITEMS) {
+        const int row = i / ROW2, w = i - row * ROW2;
+        *reinterpret_cast<double2*>(buf + row * S + 2 * w) = rg[q];
+      }
+    }
+  };
+  auto fload = [&](const double* buf, int s, double (&f)[NF]) {
+    const double* base = buf + (4 * s + lk) * S + lr;
+#pragma unroll
+    for (int t = 0; t < NF; ++t) f[t] = base[D::col(t)];
+  };
+  double* buf0 = lds;
+  double* buf1 = lds + NROWB * S;
+  if (nblk > 0) {
+    gload(k_lo);
+    sstore(buf0);
+  }
+  __syncthreads();
+  for (int b = 0; b < nblk; ++b) {
+    if (b + 1 < nblk) gload(k_lo + (int64_t)(b + 1) * NROWB);  // in flight while this block is multiplied
+    const double* cur = (b & 1) ? buf1 : buf0;
+    double f0[NF], f1[NF];
+    fload(cur, 0, f0);
+#pragma unroll
+    for (int s = 0; s < KB; s += 2) {
+      fload(cur, s + 1, f1);
+      gram_lds_mfmas<D>(f0, acc, std::make_integer_sequence<int, NTW>());
+      if (s + 2 < KB) fload(cur, s + 2, f0);
+      gram_lds_mfmas<D>(f1, acc, std::make_integer_sequence<int, NTW>());
+    }
+    if (b + 1 < nblk) sstore((b & 1) ? buf0 : buf1);
+    __syncthreads();
+  }
+  gram_lds_store<D>(acc, n, ta0, tb0, lr, lk, Cz, std::make_integer_sequence<int, NTW>());
+}
+
+template <int GS>
+__global__ __launch_bounds__(kTPB) void k_gram_units_lds(const double* __restrict__ Y, int64_t ldy, int64_t rows, int64_t kchunk, int n, int CT,
+                                                        const int2* __restrict__ units, int npairs, double* __restrict__ part) {
+  extern __shared__ double gram_lds[];
+  const int64_t k_lo = (int64_t)blockIdx.x * kchunk;
+  const int64_t k_hi = k_lo + kchunk < rows ? k_lo + kchunk : rows;
+  double* Cz = part + (int64_t)blockIdx.x * n * n;
+  const int2 u = units[blockIdx.y];  // {first row tile, first column tile}
+  const int ca = 16 * u.x, cb = 16 * u.y;
+  if ((int)blockIdx.y < npairs) {
+    switch (threadIdx.x >> 6) {
+      case 0: gram_lds_wave<GramLdsUnitDeal<GS, false, 0>>(Y, ldy, k_lo, k_hi, n, ca, cb, u.x, u.y, Cz, gram_lds); break;
+      case 1: gram_lds_wave<GramLdsUnitDeal<GS, false, 1>>(Y, ldy, k_lo, k_hi, n, ca, cb, u.x, u.y, Cz, gram_lds); break;
+      case 2: gram_lds_wave<GramLdsUnitDeal<GS, false, 2>>(Y, ldy, k_lo, k_hi, n, ca, cb, u.x, u.y, Cz, gram_lds); break;
+      default: gram_lds_wave<GramLdsUnitDeal<GS, false, 3>>(Y, ldy, k_lo, k_hi, n, ca, cb, u.x, u.y, Cz, gram_lds); break;
+    }
+  } else {
+    switch (threadIdx.x >> 6) {
+      case 0: gram_lds_wave<GramLdsUnitDeal<GS, true, 0>>(Y, ldy, k_lo, k_hi, n, ca, ca, u.x, u.y, Cz, gram_lds); break;
+      case 1: gram_lds_wave<GramLdsUnitDeal<GS, true, 1>>(Y, ldy, k_lo, k_hi, n, ca, ca, u.x, u.y, Cz, gram_lds); break;
+      case 2: gram_lds_wave<GramLdsUnitDeal<GS, true, 2>>(Y, ldy, k_lo, k_hi, n, ca, ca, u.x, u.y, Cz, gram_lds); break;
+      default: gram_lds_wave<GramLdsUnitDeal<GS, true, 3>>(Y, ldy, k_lo, k_hi, n, ca, ca, u.x, u.y, Cz, gram_lds); break;
+    }
+  }
+}
+
+template <int CT>
+__global__ __launch_bounds__(kTPB) void k_gram_sym_lds(const double* __restrict__ Y, int64_t ldy, int64_t rows, int64_t kchunk, int n,
+                                                      double* __restrict__ part, unsigned long long* __restrict__ clk) {
+  extern __shared__ double gram_lds[];
+  const int64_t k_lo = (int64_t)blockIdx.x * kchunk;
+  const int64_t k_hi = k_lo + kchunk < rows ? k_lo + kchunk : rows;
+  double* Cz = part + (int64_t)blockIdx.x * n * n;
+  const bool rec = clk != nullptr && blockIdx.x == 0 && threadIdx.x < 64;
+  unsigned long long c0 = 0, t0 = 0;
+  if (rec) {
+    c0 = clock64();
+    t0 = wall_clock64();
+  }
+  switch (threadIdx.x >> 6) {
+    case 0: gram_lds_wave<GramLdsSymDeal<CT, 0>>(Y, ldy, k_lo, k_hi, n, 0, 0, 0, 0, Cz, gram_lds); break;
+    case 1: gram_lds_wave<GramLdsSymDeal<CT, 1>>(Y, ldy, k_lo, k_hi, n, 0, 0, 0, 0, Cz, gram_lds); break;
+    case 2: gram_lds_wave<GramLdsSymDeal<CT, 2>>(Y, ldy, k_lo, k_hi, n, 0, 0, 0, 0, Cz, gram_lds); break;
+    default: gram_lds_wave<GramLdsSymDeal<CT, 3>>(Y, ldy, k_lo, k_hi, n, 0, 0, 0, 0, Cz, gram_lds); break;
+  }
+  if (rec && threadIdx.x == 0) {
+    clk[0] = clock64() - c0;
+    clk[1] = wall_clock64() - t0;
+    clk[2] = (unsigned long long)((k_hi - k_lo + 3) >> 2);
+    clk[3] = (unsigned long long)((gram_tri_count(CT) + 3) / 4);
+  }
+}
+
+// out[r][c] = sum_z slice_z[r][c] for the upper 16 x 16 tiles, mirrored into the lower ones (fixed order of z).
+// A workgroup owns 16 consecutive entries of G (one 128-byte line of every slice) and deals the slices to 16 lanes per entry, four
+// independent accumulators each; the 16 lane sums are added in order.  (Until round 5 one thread walked all slices of its entry with
+// two accumulators - 40 workgroups and a chain of 384 dependent loads at n = 100: 0.26 ms of C2's 0.51 ms Gram matrix.)
+__global__ __launch_bounds__(kTPB) void k_sum_slices_sym(const double* __restrict__ part, int nz, int n, double* __restrict__ out) {
+  __shared__ double sm[16][17];
+  const int o = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const int64_t count = (int64_t)n * n;
+  const int64_t i = (int64_t)blockIdx.x * 16 + o;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (i < count) {
+    const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+    const int64_t src = (r >> 4) <= (c >> 4) ? i : (int64_t)c * n + r;
+    const double* p = part + src;
+    int z = zl;
+    for (; z + 48 < nz; z += 64) {
+      a0 += p[(int64_t)z * count];
+      a1 += p[(int64_t)(z + 16) * count];
+      a2 += p[(int64_t)(z + 32) * count];
+      a3 += p[(int64_t)(z + 48) * count];
+    }
+    for (; z < nz; z += 16) a0 += p[(int64_t)z * count];
+  }
+  sm[zl][o] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (threadIdx.x < 16 && i < count) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][threadIdx.x];
+    out[i] = t;
+  }
 }
 
 // G = Y^T Y into out (n x n, symmetric, complete); `part` = scratch of gram_scratch_doubles(n) doubles.
-// Returns false when the shape is not covered (n > 208 or a handful of rows): the caller takes launch_gram + launch_sum_slices.
+// Returns false when the shape is not covered (n > 3520 or a handful of rows): the caller takes launch_gram + launch_sum_slices.
 // K slices: at most kGramMaxSlices, and no more than ~1 GB of n x n partial slices (n = 1000: 125)
 int gram_max_slices(int n) {
   const int64_t cap = ((int64_t)1 << 27) / ((int64_t)n * n);
   return (int)std::max<int64_t>(16, std::min<int64_t>(kGramMaxSlices, cap));
 }
 size_t gram_scratch_doubles(int n) { return (size_t)gram_max_slices(n) * n * n + 4096; }  // (+ the unit table of the grouped form)
-bool launch_gram_sym(const double* Y, int64_t ldy, int64_t rows, int n, double* part, double* out, hipStream_t s, unsigned long long* clk) {
+// Number of K slices (= workgroups per unit).  Every workgroup fills a CU (four waves, one per SIMD, ~330 registers each), so a
+// launch runs in residency rounds of 256 workgroups and a ragged last round idles most of the chip: C5 ran 3 x 536 = 1608 pair
+// blocks = 6.3 rounds (7 to wait for) until round 5; 3 x 512 = 6.0 now.  `weight` = the launch's workgroups per slice in units
+// of its longest block.
+static int gram_slices(int n, int64_t rows, double weight, int override) {
+  const int cap = (int)std::min<int64_t>(gram_max_slices(n), std::max<int64_t>(1, (rows + 1023) / 1024));
+  if (override > 0) return std::min(override, cap);
+  if (cap * weight <= kNumCU) return cap;  // less than one round either way: as many slices as the rows allow
+  int best = cap;
+  double best_eff = -1.0;
+  for (int nz = cap; nz >= std::max(1, (cap * 3) / 5); --nz) {
+    const double rounds = nz * weight / kNumCU;
+    const double eff = rounds / std::ceil(rounds - 1e-9);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = nz;
+    }
+  }
+  return best;
+}
+template <class K>
+static bool gram_lds_attr(K kern, size_t bytes) {  // more than 64 KiB of dynamic LDS has to be allowed per kernel
+  return bytes <= 65536 || hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+bool launch_gram_sym(const double* Y, int64_t ldy, int64_t rows, int n, double* part, double* out, hipStream_t s, unsigned long long* clk,
+                     int nz_override, int variant) {
   const int CT = (n + 15) / 16;
   if (CT < 3 || rows < 4096 || ldy != n) return false;
-  int nz = (int)std::min<int64_t>(gram_max_slices(n), (rows + 1023) / 1024);
-  int64_t kchunk = (rows + nz - 1) / nz;
-  kchunk = (kchunk + 3) & ~(int64_t)3;
-  nz = (int)((rows + kchunk - 1) / kchunk);
-#define LZ_GS(ct)                                                                                      \
-  case ct:                                                                                             \
-    hipLaunchKernelGGL((k_gram_sym<ct>), dim3(nz), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, part, clk); \
+  // variant 0: operands staged through LDS once per workgroup (needs 16-byte aligned rows: even n); 2: the register-ring kernels of round 4
+  const bool use_lds = variant != 2 && (n % 2 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
+  int nz = 0;
+  int64_t kchunk = 0;
+  auto slices = [&](double weight) {
+    nz = gram_slices(n, rows, weight, nz_override);
+    kchunk = (rows + nz - 1) / nz;
+    kchunk = (kchunk + 3) & ~(int64_t)3;
+    nz = (int)((rows + kchunk - 1) / kchunk);
+  };
+#define LZ_GS(ct)                                                                                                                       \
+  case ct:                                                                                                                              \
+    if (use_lds && gram_lds_attr(k_gram_sym_lds<ct>, gram_lds_bytes(1, 16 * ct, 8)))                                                     \
+      hipLaunchKernelGGL((k_gram_sym_lds<ct>), dim3(nz), dim3(kTPB), gram_lds_bytes(1, 16 * ct, 8), s, Y, ldy, rows, kchunk, n, part, clk); \
+    else                                                                                                                                \
+      hipLaunchKernelGGL((k_gram_sym<ct>), dim3(nz), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, part, clk);                              \
     break;
   if (CT <= 13) {
+    slices(1.0);
     switch (CT) {
       LZ_GS(3) LZ_GS(4) LZ_GS(5) LZ_GS(6) LZ_GS(7) LZ_GS(8) LZ_GS(9) LZ_GS(10) LZ_GS(11) LZ_GS(12) LZ_GS(13)
       default: return false;
     }
   } else {
-    // groups of kGramGS column tiles: the diagonal units and the off-diagonal pairs of the upper triangle of groups
-    const int ng = (CT + kGramGS - 1) / kGramGS;
-    if (ng > 20) return false;  // (n > 3520: the split-K form)
+    // groups of GS column tiles, GS the smallest size that covers the CT tiles with ceil(CT / 11) groups (round 4 had 11 always:
+    // n = 400 - 25 tiles - ran as 3 x 11 with 8 tiles of padding, 1.7 x the tile products it needs; 3 x 9 now): the diagonal units
+    // and the off-diagonal pairs of the upper triangle of groups
+    if ((CT + kGramGS - 1) / kGramGS > 20) return false;  // (n > 3520: the split-K form)
+    // group size: the one whose units cost the fewest MFMA issue slots per k-step on their busiest waves (a pair: ceil(GS / 4) GS
+    // tiles, a triangle: the snake's heaviest share) - CT = 32 (C5): 4 groups of 8 tile the triangle exactly (6 x 16 + 4 x 9 = 132
+    // slots, every wave equally loaded) where 3 groups of 11 need 3 x 33 + 3 x 18 = 153; CT = 25 (n = 400): 4 x 7
+    int GS = kGramGS, ng = (CT + kGramGS - 1) / kGramGS;
+    {
+      double best = 1e300;
+      for (int g = 7; g <= kGramGS; ++g) {
+        const int k = (CT + g - 1) / g;
+        double wt = 0.0;
+        for (int w = 0; w < 4; ++w) wt = std::max(wt, (double)gram_diag_count(g, w));
+        // (11: its pairs hold 33 accumulator tiles per wave = 264 registers, the LDS-staged form spills there: it runs the register-ring
+        //  kernel, which measured ~12 % further from its issue floor)
+        const double cost = (0.5 * k * (k - 1) * ((g + 3) / 4) * g + k * wt) * (g == kGramGS ? 1.12 : 1.0);
+        if (cost < best - 1e-9) {
+          best = cost;
+          GS = g;
+          ng = k;
+        }
+      }
+    }
     std::vector<int2> ud, up;
     for (int a = 0; a < ng; ++a) {
-      ud.push_back(make_int2(kGramGS * a, kGramGS * a));
-      for (int b = a + 1; b < ng; ++b) up.push_back(make_int2(kGramGS * a, kGramGS * b));
+      ud.push_back(make_int2(GS * a, GS * a));
+      for (int b = a + 1; b < ng; ++b) up.push_back(make_int2(GS * a, GS * b));
     }
+    // busiest wave of a pair: ceil(GS / 4) row tiles x GS columns; of a triangle: the snake's heaviest share (~ (GS + 1) GS / 8 + ...)
+    const double wp = (double)((GS + 3) / 4) * GS;
+    double wt = 0.0;
+    for (int w = 0; w < 4; ++w) wt = std::max(wt, (double)gram_diag_count(GS, w));
+    slices((double)up.size() + (double)ud.size() * wt / wp);
     // the unit table rides behind the partial slices (gram_scratch_doubles reserves 4096 doubles = 4096 int2 for it)
     int2* tab = reinterpret_cast<int2*>(part + (size_t)gram_max_slices(n) * n * n);
-    std::vector<int2> all(ud);
-    all.insert(all.end(), up.begin(), up.end());
+    std::vector<int2> all(up);  // pairs first
+    all.insert(all.end(), ud.begin(), ud.end());
     if (hipMemcpyAsync(tab, all.data(), all.size() * sizeof(int2), hipMemcpyHostToDevice, s) != hipSuccess) return false;
     if (hipStreamSynchronize(s) != hipSuccess) return false;  // (`all` is a local; once per Gram matrix)
-    // the pairs first: they are the long blocks (33 tiles on their busiest wave against 18)
-    hipLaunchKernelGGL((k_gram_unit<kGramGS, kGramGS, false>), dim3(nz, (unsigned)up.size()), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, CT, tab + ud.size(),
-                       part);
-    hipLaunchKernelGGL((k_gram_unit<kGramGS, kGramGS, true>), dim3(nz, (unsigned)ud.size()), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, CT, tab, part);
+#define LZ_GU(gs)                                                                                                                              \
+  case gs: {                                                                                                                                   \
+    const size_t lb = std::max(gram_lds_bytes(2, 16 * gs, gs >= 10 ? 2 : 4), gram_lds_bytes(1, 16 * gs, 8));                                    \
+    if (use_lds && gs < kGramGS && gram_lds_attr(k_gram_units_lds<(gs < kGramGS ? gs : 7)>, lb))                                                \
+      hipLaunchKernelGGL((k_gram_units_lds<(gs < kGramGS ? gs : 7)>), dim3(nz, (unsigned)all.size()), dim3(kTPB), lb, s, Y, ldy, rows, kchunk, n, CT, tab, (int)up.size(), part); \
+    else                                                                                                                                       \
+      hipLaunchKernelGGL((k_gram_units<gs>), dim3(nz, (unsigned)all.size()), dim3(kTPB), 0, s, Y, ldy, rows, kchunk, n, CT, tab, (int)up.size(), part); \
+    break;                                                                                                                                     \
+  }
+    switch (GS) {
+      LZ_GU(7) LZ_GU(8) LZ_GU(9) LZ_GU(10) LZ_GU(11)
+      default: return false;
+    }
+#undef LZ_GU
   }
 #undef LZ_GS
-  hipLaunchKernelGGL(k_sum_slices_sym, dim3((unsigned)(((int64_t)n * n + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, part, nz, n, out);
+  hipLaunchKernelGGL(k_sum_slices_sym, dim3((unsigned)(((int64_t)n * n + 15) / 16)), dim3(kTPB), 0, s, part, nz, n, out);
   return true;
 }
 

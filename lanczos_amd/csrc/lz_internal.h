@@ -232,7 +232,8 @@ void launch_sum_slices(const double* part, int nz, int64_t count, double* out, h
 constexpr int kGramMaxSlices = 768;
 size_t gram_scratch_doubles(int n);
 bool launch_gram_sym(const double* Y, int64_t ldy, int64_t rows, int n, double* part, double* out, hipStream_t s,
-                     unsigned long long* clk = nullptr);
+                     unsigned long long* clk = nullptr, int nz_override = 0,  // nz_override > 0: that many K slices (A/B knob 21)
+                     int variant = 0);  // 0: operands staged through LDS (even n), 2: the register-ring kernels (knob 19 = 2)
 // per-block [s1 (n), s2 (n)] partials of the Ritz-vector quality sums; returns the number of blocks
 int launch_ritz_quality(const CsrDev& A, const double* Y, int64_t ldy, int n, double* part, hipStream_t s);
 // x[r] = Y[r * ldy + col] for r < rows, 0 for rows <= r < rows_pad

@@ -841,35 +841,42 @@ int lz_reserve(lz_handle h, int64_t rows_local, int n, int with_ritz) {
   const int64_t rows_pad = round_up(rows_local, kPadDoubles);
   const size_t vsz = (size_t)n * (size_t)skew_stride(h, rows_pad);
   const size_t ysz = y_doubles(rows_local, n);
-  std::lock_guard<std::mutex> lk(h->res_mu);
-  size_t free_b = 0, total_b = 0;
-  if (!(h->res_V && h->res_V_count >= vsz)) {
-    if (h->res_V) hipFree(h->res_V);
-    h->res_V = nullptr;
-    h->res_V_count = 0;
-    void* p = nullptr;
+  // One buffer at a time: decide under the lock, allocate / free OUTSIDE it (a device allocation may take seconds and a free
+  // synchronises the device: lz_run's basis_alloc and lz_ritz_vectors take the same lock to adopt a buffer), publish under the lock.
+  // with_ritz: 0 the basis only, 1 both, 2 the Ritz vectors only (the helper thread's second call used to re-check the
+  // basis and could strand a second 8 n M bytes once basis_alloc had adopted the first).
+  auto reserve_one = [&](double*& slot, size_t& slot_count, size_t want) {
+    double* stale = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(h->res_mu);
+      if (slot && slot_count >= want) return;
+      stale = slot;
+      slot = nullptr;
+      slot_count = 0;
+    }
+    if (stale) (void)big_free(stale);
+    size_t free_b = 0, total_b = 0;
     // leave room for the matrix, its layouts and the work vectors: reserve only what leaves a quarter of the device free
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || vsz * sizeof(double) + total_b / 4 > free_b) return LZ_OK;
-    if (hipMalloc(&p, vsz * sizeof(double)) != hipSuccess) {
-      (void)hipGetLastError();
-      return LZ_OK;  // not an error: basis_alloc allocates (and reports) itself
-    }
-    h->res_V = static_cast<double*>(p);
-    h->res_V_count = vsz;
-  }
-  if (with_ritz && !(h->res_Y && h->res_Y_count >= ysz)) {
-    if (h->res_Y) hipFree(h->res_Y);
-    h->res_Y = nullptr;
-    h->res_Y_count = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || want * sizeof(double) + total_b / 4 > free_b) return;
     void* p = nullptr;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || ysz * sizeof(double) + total_b / 4 > free_b) return LZ_OK;
-    if (hipMalloc(&p, ysz * sizeof(double)) != hipSuccess) {
+    if (big_alloc(h->dev, &p, want * sizeof(double)) != hipSuccess) {
       (void)hipGetLastError();
-      return LZ_OK;
+      return;  // not an error: basis_alloc / lz_ritz_vectors allocate (and report) themselves
     }
-    h->res_Y = static_cast<double*>(p);
-    h->res_Y_count = ysz;
-  }
+    double* loser = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(h->res_mu);
+      if (slot) {
+        loser = static_cast<double*>(p);  // (another reserve call got there first)
+      } else {
+        slot = static_cast<double*>(p);
+        slot_count = want;
+      }
+    }
+    if (loser) (void)big_free(loser);
+  };
+  if (with_ritz != 2) reserve_one(h->res_V, h->res_V_count, vsz);
+  if (with_ritz) reserve_one(h->res_Y, h->res_Y_count, ysz);
   return LZ_OK;
 }
 

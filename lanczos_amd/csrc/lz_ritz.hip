@@ -81,7 +81,7 @@ int lz_ritz_vectors(lz_handle h, const double* S, double* Y_out) {
   {
     std::lock_guard<std::mutex> lk(h->res_mu);
     if (h->res_Y && !chunked && h->res_Y_count >= full && !(h->d_Y && !h->y_chunked && h->y_cap >= (int64_t)full)) {
-      hipFree(h->d_Y);  // (a smaller or chunked buffer of an earlier call)
+      big_free(h->d_Y);  // (a smaller or chunked buffer of an earlier call)
       h->d_Y = h->res_Y;
       h->y_cap = (int64_t)h->res_Y_count;
       h->y_chunked = false;
@@ -235,7 +235,7 @@ int lz_ritz_gram(lz_handle h, double* gram_out) {
     if (rc != LZ_OK) break;
     // flops on the books: the symmetric half, n (n + 1) per row (the full product is 2 n^2; the kernel computes the upper tiles)
     Scope sc(h, LZ_K_RITZ, 8.0 * n * (double)nr, (double)nr * n * (n + 1.0));
-    if (h->tune[19] != 1 && launch_gram_sym(h->d_Y, n, nr, n, part, cpart + (size_t)q * n * n, h->stream, reinterpret_cast<unsigned long long*>(h->d_gclk))) {
+    if (h->tune[19] != 1 && launch_gram_sym(h->d_Y, n, nr, n, part, cpart + (size_t)q * n * n, h->stream, reinterpret_cast<unsigned long long*>(h->d_gclk), h->tune[21], h->tune[19])) {
       h->gram_sym_last = true;
     } else {
       const int nz = launch_gram(h->d_Y, n, nr, n, part, nz_max, h->stream);

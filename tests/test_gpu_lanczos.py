@@ -258,7 +258,11 @@ def test_device_gram_and_quality_match_numpy():
 
 
 @pytest.mark.parametrize("M,n,chunk", [(4096, 48, 0), (70001, 100, 0), (30011, 200, 0), (20000, 208, 0), (50000, 117, 0), (30011, 200, 8000), (5000, 33, 0), (5000, 32, 0), (3000, 100, 0),
-                                       (9000, 209, 0), (8200, 353, 0), (6000, 500, 0), (12000, 420, 5000)])
+                                       (9000, 209, 0), (8200, 353, 0), (6000, 500, 0), (12000, 420, 5000),
+                                       # round 5: group sizes 7 .. 11 (n = 224: 2 x 7, 300: 2 x 10, 400: 4 x 7, 500: 4 x 8, 520: 3 x 11, 700: 4 x 11, 290: 2 x 10 ragged),
+                                       # even n: operands staged through LDS; odd n: the register-ring kernels
+                                       (9000, 224, 0), (9001, 300, 0), (8200, 400, 0), (8300, 520, 0), (5000, 700, 0), (9000, 290, 0), (9000, 399, 0), (4100, 50, 0),
+                                       (4099, 112, 0), (8193, 176, 4096)])
 def test_symmetric_gram_kernel(hip, M, n, chunk):
     """Round 4: the accumulator-stationary symmetric Gram kernel (k_gram_sym: upper 16 x 16 tiles of Y^T Y kept in the
     accumulators, Y streamed once, result mirrored) against NumPy and against the split-K TN GEMM it replaces (knob 19 = 1),
@@ -270,7 +274,7 @@ def test_symmetric_gram_kernel(hip, M, n, chunk):
     v0 /= np.linalg.norm(v0)
     out = {}
     S = np.random.default_rng(3).standard_normal((n, n))
-    for knob in (0, 1):
+    for knob in (0, 1, 2):  # 0: symmetric kernel, operands through LDS (round 5); 1: split-K TN GEMM; 2: symmetric kernel, register rings (round 4)
         h = hip.Handle(0)
         h.set_tuning(hip.TUNE_GRAM_KERNEL, knob)
         if chunk:
@@ -282,7 +286,7 @@ def test_symmetric_gram_kernel(hip, M, n, chunk):
         h.ritz_vectors(S, fetch=False)
         G = h.ritz_gram()
         info = h.gram_info()
-        assert (info["ksteps"] > 0) == (knob == 0 and 32 < n <= 208 and min(M, chunk or M) >= 4096)  # (the clock record: single-group form only)
+        assert (info["ksteps"] > 0) == (knob != 1 and 32 < n <= 208 and min(M, chunk or M) >= 4096)  # (the clock record: single-group form only)
         out[knob] = G
         h.close()
     Y = V.T @ S
@@ -291,6 +295,8 @@ def test_symmetric_gram_kernel(hip, M, n, chunk):
     assert np.array_equal(out[0], out[0].T)  # mirrored, not computed twice
     assert np.abs(out[0] - ref).max() <= 1e-12 * scale
     assert np.abs(out[1] - ref).max() <= 1e-12 * scale
+    # the LDS-staged and the register-ring form issue the same MFMAs in the same order per tile and slice: the same bits
+    assert np.array_equal(out[0], out[2])
 
 
 def test_get_H_eigs_asserts_fire_on_device_gram():
