@@ -143,10 +143,11 @@ int lz_set_options(lz_handle h, int flags);
  *   20  one-reduce partial loop (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE): safety factor kappa of the look-ahead sweep
  *       decision (a sweep is due when kappa * max |predicted omega| > sqrt(eps); 0 = the default, 4)
  * The product library returns LZ_ERR_ARG for everything that lives only in the kernel-bench build (make KBENCH=1 ->
- * liblanczos_kbench.so, loaded by tools/ and by the tests of those arms): the timing-only ablation arms (knob 1 >= 20,
- * knob 3) and the A/B arms retired in round 3 because they measured slower - the one-kernel and one-launch-per-step engines
+ * liblanczos_kbench.so, loaded by tools/ and by the tests of those arms; sources: lz_small.hip, lz_*_kbench.h): the A/B arms
+ * retired in round 3 because they measured slower - the one-kernel and one-launch-per-step engines
  * (15 = 2, 3, 5), the persistent / LDS-staged / 16-row-tile Ritz GEMMs (9 = 2, 3, 4, 6), the ticket / deferred-fold two-sided links
- * (11 = 2, 3), and LZ_FLAG_QTW_MFMA (lz_set_options). */
+ * (11 = 2, 3), and LZ_FLAG_QTW_MFMA (lz_set_options).  The timing-only ablation arms of rounds 1-4 (kernel variants that computed
+ * wrong results on purpose: knob 1 >= 20, knob 3, knob 9 >= 10) were deleted from both builds in round 5. */
 int lz_set_tuning(lz_handle h, int index, int value);
 /* "hip=<path of the libamdhip64 this library is bound to>;rccl=<path of the librccl it dlopened, or empty>".
  * RCCL is always taken from the directory of that HIP runtime (LZ_RCCL_PATH overrides): see DESIGN.md section 5. */

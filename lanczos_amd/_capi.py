@@ -34,7 +34,7 @@ FLAG_ONE_REDUCE = 256
 TUNE_QTW_SLICE = 0          # Q^T w slice length per block
 TUNE_QTW_VARIANT = 1        # Q^T w kernel variant (unroll / rows per tile; >= 20: timing-only ablations, kernel-bench build)
 TUNE_STREAM_ROWS = 2        # CSR-stream rows per block
-TUNE_SPMV_ABLATION = 3      # timing-only SpMV ablation arm (kernel-bench build)
+TUNE_SPMV_ABLATION = 3      # (removed in round 5: the timing-only SpMV ablation arms; any non-zero value is refused)
 TUNE_STREAM_ENTRIES = 4     # CSR-stream entries per block
 TUNE_FIXED_ROWS = 5         # fixed-K rows per block (CSR-order kernel)
 TUNE_FORCE_COLLECTIVES = 6  # issue the collectives even when world == 1

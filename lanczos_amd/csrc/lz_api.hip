@@ -503,11 +503,11 @@ int lz_set_options(lz_handle h, int flags) {
 int lz_set_tuning(lz_handle h, int index, int value) {
   if (!h) return LZ_ERR_ARG;
   if (index < 0 || index >= 24) return fail(h, LZ_ERR_ARG, "lz_set_tuning: knob index out of range");
+  // The timing-only ablation arms (kernel variants that computed wrong results on purpose, for one-off measurements: knob 1 >= 20,
+  // knob 3, knob 9 >= 10) were deleted in round 5; their results are in profiles/r01 .. r04.
+  if ((index == 1 && value >= 20) || (index == 3 && value != 0) || (index == 9 && value >= 10))
+    return fail(h, LZ_ERR_ARG, "lz_set_tuning: the timing-only ablation arms were removed in round 5 (their measurements are in profiles/)");
 #ifndef LZ_KBENCH
-  // Timing-only ablation arms (they compute wrong results on purpose) exist only in the kernel-bench build
-  // (`make KBENCH=1` -> liblanczos_kbench.so, loaded by tools/kbench.py); the product library refuses them.
-  if ((index == 1 && value >= 20) || (index == 3 && value != 0))
-    return fail(h, LZ_ERR_ARG, "lz_set_tuning: ablation arms are not part of the product library (build with KBENCH=1)");
   // Retired A/B arms (built, measured slower, kept bit-identity-tested in the kernel-bench build): the one-kernel /
   // one-launch-per-step engines (15 = 2, 3, 5), the persistent and LDS-staged Ritz GEMMs (9 >= 2), the ticket / deferred-fold
   // two-sided links (11 >= 2)

@@ -56,7 +56,6 @@ struct CsrDev {
   int32_t* rowblk = nullptr;  // CSR-stream row blocks: rows [rowblk[b], rowblk[b+1])
   int n_rowblk = 0;
   int fixed_rb = 512;         // rows per block of the fixed-K kernel
-  int ablation = 0;           // timing-only ablation arm (tools/kbench.py), 0 in production
   int blk_nnz_cap = 4096;     // products per row block (LDS tile of the CSR-stream kernel)
   int max_row_nnz = 0;
   double avg_row_nnz = 0;

@@ -53,7 +53,6 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   if (nnz_cap > 16384) nnz_cap = 16384;
   build_rowblocks(rowptr_host, rows_local, rows_cap, nnz_cap, blk);
   A.blk_nnz_cap = nnz_cap;
-  A.ablation = h->tune[3];
   A.fixed_rb = h->tune[5] > 0 ? h->tune[5] : 512;
   LZ_TRY(dev_alloc(h, A.rowblk, blk.size()));
   LZ_HIP(h, hipMemcpy(A.rowblk, blk.data(), blk.size() * sizeof(int32_t), hipMemcpyHostToDevice));

@@ -456,7 +456,7 @@ __device__ __forceinline__ void qtw_stage_two(const double* __restrict__ r, cons
   }
 }
 
-template <int SCALE, int R, int U, int NT = 1, int ABL = 0>  // ABL: timing-only ablation arms, wrong results
+template <int SCALE, int R, int U, int NT = 1>
 __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                   const double* __restrict__ r, const double* __restrict__ nrm2,
                                                   double* __restrict__ beta_slot, int64_t L, int G,
@@ -472,9 +472,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
   // order, so the last ~256 MB this pass reads (rows 0, 1, ...) are the first pass 2 needs - they are still in
   // the Infinity Cache.
   const int i_top = ((nrows - 1) / R) * R;
-  double sink = 0.0;
-  for (int ii = i_top; ii >= 0; ii -= R) {
-    const int i0 = (ABL & 2) ? i_top - ii : ii;  // ABL 2: ascending rows
+  for (int i0 = i_top; i0 >= 0; i0 -= R) {
     const double2* row[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -488,18 +486,13 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
     for (int q = 0; q < R; ++q) acc[q] = 0.0;
 #pragma unroll U
     for (int t = threadIdx.x; t < cnt2; t += kTPB) {
-      const double2 wv = (ABL & 4) ? make_double2(1.0, 2.0) : sw[t];  // ABL 4: no LDS read
+      const double2 wv = sw[t];
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         const double2 v = ld_stream<NT>(row[q] + t);
         acc[q] = fma(v.x, wv.x, acc[q]);
         acc[q] = fma(v.y, wv.y, acc[q]);
       }
-    }
-    if (ABL & 1) {  // ABL 1: no per-tile reduction / barriers / partial stores
-#pragma unroll
-      for (int q = 0; q < R; ++q) sink += acc[q];
-      continue;
     }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -516,77 +509,11 @@ __global__ __launch_bounds__(kTPB) void k_qtw_valu(double* __restrict__ V, int64
     }
     __syncthreads();
   }
-  if ((ABL & 1) && sink == 1.2345e300) part[0] = sink;
 }
 
-#ifdef LZ_KBENCH  // retired A/B arm (LZ_FLAG_QTW_MFMA: 20 % slower than the 4x4x4 kernel): kernel-bench build only
-// MFMA variant.  Lane l of a wave: row r = l & 15 of the current 16-row tile,
-// k-group g = l >> 4.  Step s covers 8 consecutive elements of the slice
-// (64 B per row): the lane loads the double2 at element 8*s + 2*g of its row;
-// the two halves feed two MFMAs whose B operands are the matching w entries
-// (one ds_read_b128 per step, 4 distinct addresses per wave -> conflict free).
-// D layout (f64 16x16x4): lane l holds D[row = (l>>4) + 4*reg][col = l&15];
-// all 16 columns are equal, column-0 lanes write the per-wave partials.
-template <int SCALE, int U, int T>
-__global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
-                                                  const double* __restrict__ r, const double* __restrict__ nrm2,
-                                                  double* __restrict__ beta_slot, int64_t L, int P,
-                                                  double* __restrict__ part) {
-  extern __shared__ double2 sw[];
-  const int64_t base = (int64_t)blockIdx.x * L;
-  const int cnt = (int)(len - base < L ? len - base : L);
-  static_assert(SCALE != 2, "the MFMA kernel streams row j from V[j]; fused-norm mode uses the VALU kernel");
-  qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
-  __syncthreads();  // also makes this block's V[j] stores visible to its own later loads
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int lr = lane & 15, g = lane >> 4;
-  const int sub = (int)(L >> 2);                 // elements per wave (multiple of 128)
-  const int m_lo = w * sub;
-  int m_hi = m_lo + sub;
-  if (m_hi > cnt) m_hi = cnt;
-  const int nsteps = m_hi > m_lo ? (m_hi - m_lo) >> 3 : 0;  // multiple of 4 (cnt and sub are multiples of 32)
-  const int pid = blockIdx.x * (kTPB / 64) + w;
-  const double2* swl = sw + (m_lo >> 1) + g;     // + 4*s per step
-  for (int i0 = ((nrows - 1) / (16 * T)) * (16 * T); i0 >= 0; i0 -= 16 * T) {  // newest rows first (see k_qtw_valu)
-    const double2* a[T];
-    double4_t acc[T][2];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      int i = i0 + 16 * t + lr;
-      if (i >= nrows) i = nrows - 1;             // clamped duplicate, discarded at the store
-      a[t] = reinterpret_cast<const double2*>(V + (int64_t)i * ldv + base + m_lo) + g;
-      acc[t][0] = (double4_t){0.0, 0.0, 0.0, 0.0};
-      acc[t][1] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    }
-    for (int s0 = 0; s0 < nsteps; s0 += U) {
-      double2 av[T][U];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int t = 0; t < T; ++t) av[t][u] = (s0 + u < nsteps) ? ld_stream<1>(a[t] + 4 * (s0 + u)) : make_double2(0.0, 0.0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double2 bv = (s0 + u < nsteps) ? swl[4 * (s0 + u)] : make_double2(0.0, 0.0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t][u].x, bv.x, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t][u].y, bv.y, acc[t][1], 0, 0, 0);
-        }
-      }
-    }
-    if (lr == 0) {
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = i0 + 16 * t + g + 4 * q;
-          if (row < nrows) part[(int64_t)row * P + pid] = acc[t][0][q] + acc[t][1][q];
-        }
-    }
-  }
-}
-
-#endif  // LZ_KBENCH
+#ifdef LZ_KBENCH  // retired A/B arm (LZ_FLAG_QTW_MFMA, the 16x16x4 tiling: 20 % slower): its kernel lives in a kernel-bench-only file
+#include "lz_reorth_kbench.h"
+#endif
 
 // MFMA variant 2: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction).  Lane layout measured on
 // gfx950 (tools/probes/mfma_f64_4x4x4_layout.hip): A[blk][i][k] lives in lane 16k + 4blk + i, B[blk][k][j] in lane
@@ -594,7 +521,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma(double* __restrict__ V, int64
 // four basis rows, so one wave-load covers 4 rows x 256 contiguous bytes (whole 128-byte lines, like the VALU kernel)
 // instead of the 16 rows x 64 bytes the 16x16x4 shape forces.  B = the matching w entries broadcast over j; the four
 // block results of a row are added with two cross-lane steps once per tile.  No barrier in the main loop.
-template <int SCALE, int U, int T, int ABL = 0>  // ABL: timing-only ablation arms (tools/kbench.py), wrong results
+template <int SCALE, int U, int T>
 __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int64_t ldv, int64_t len, int nrows, int j,
                                                    const double* __restrict__ r, const double* __restrict__ nrm2,
                                                    double* __restrict__ beta_slot, int64_t L, int ldp,
@@ -663,7 +590,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
     }
     self = wave_sum(self);
   } else {
-    self = ABL == 4 ? 0.0 : qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
+    self = qtw_stage_w<SCALE>(V, ldv, j, r, nrm2, beta_slot, base, cnt >> 1, sw);
     self = wave_sum(self);  // this wave's share of w.w (lane 0); replaces the streamed row-j result below
   }
   const int jskip = SCALE == 3 ? -1 : j;
@@ -679,8 +606,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   // B operand: column jj = lane & 3 of each 4x4 block; one-reduce mode gives the odd columns the second vector
   const double2* swl = sw + ((m_lo + eoff) >> 1) + ((SCALE == 3 && (lane & 1)) ? (L >> 1) : 0);  // + 16 per step
   const int i_top = nrows > 0 ? ((nrows - 1) / (4 * T)) * (4 * T) : 0;
-  double sink5 = 0.0;
-  // Row pointers of tile k (tiles run from the newest rows down; ABL 3: upwards).
+  // Row pointers of tile k (tiles run from the newest rows down).
   auto tile_rows = [&](int i0, const double2* (&a)[T]) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -699,21 +625,17 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   auto mma_batch = [&](int s0, const double2 (&av)[T][U], double (&acc)[T]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const double2 bv = ABL == 1 ? make_double2(1.0, 2.0) : ((s0 + u < nsteps) ? swl[16 * (s0 + u)] : make_double2(0.0, 0.0));
+      const double2 bv = (s0 + u < nsteps) ? swl[16 * (s0 + u)] : make_double2(0.0, 0.0);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        if (ABL == 2) {
-          acc[t] += av[t][u].x * bv.x + av[t][u].y * bv.y;
-        } else {
-          acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].x, bv.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].y, bv.y, acc[t], 0, 0, 0);
-        }
+        acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].x, bv.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[t][u].y, bv.y, acc[t], 0, 0, 0);
       }
     }
   };
   // The first batch of loads of the NEXT tile is issued before the current tile's results are reduced and stored: the
   // end of a tile otherwise drains the wave's whole load queue (s_waitcnt 0 before the cross-lane adds), a bubble that
-  // cost 6 % of the pass (profiles/r01/ab_qtw_tile_epilogue.json).  ABL 6: the old, unpipelined order.
+  // cost 6 % of the pass (profiles/r01/ab_qtw_tile_epilogue.json).
   const int ntiles = nrows > 0 ? i_top / (4 * T) + 1 : 0;  // one-reduce mode at j = 0: no rows yet, only the self terms
   // Row split (gridDim.y > 1, short vectors with many basis rows - 1Ddeuteron.py: M = n = 1001): the blocks
   // (blockIdx.x, 0..Y-1) share slice blockIdx.x and deal its row tiles round-robin; every (row, slice, quarter) dot is
@@ -723,15 +645,14 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   const double2* a[T];
   double2 av0[T][U];
   if (ky < ntiles) {
-    tile_rows(ABL == 3 ? ky * 4 * T : i_top - ky * 4 * T, a);
-    if (ABL != 6) load_batch(a, 0, av0);
+    tile_rows(i_top - ky * 4 * T, a);
+    load_batch(a, 0, av0);
   }
   for (int k = ky; k < ntiles; k += kstep) {
-    const int i0 = ABL == 3 ? k * 4 * T : i_top - k * 4 * T;
+    const int i0 = i_top - k * 4 * T;
     double acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0.0;
-    if (ABL == 6) load_batch(a, 0, av0);
     mma_batch(0, av0, acc);
     for (int s0 = U; s0 < nsteps; s0 += U) {
       double2 av[T][U];
@@ -739,13 +660,8 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
       mma_batch(s0, av, acc);
     }
     if (k + kstep < ntiles) {
-      tile_rows(ABL == 3 ? (k + kstep) * 4 * T : i_top - (k + kstep) * 4 * T, a);
-      if (ABL != 6) load_batch(a, 0, av0);
-    }
-    if (ABL == 5) {  // ABL 5: no per-tile epilogue (nothing reduced or stored)
-#pragma unroll
-      for (int t = 0; t < T; ++t) sink5 += acc[t];
-      continue;
+      tile_rows(i_top - (k + kstep) * 4 * T, a);
+      load_batch(a, 0, av0);
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -753,15 +669,10 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
       v += __shfl_xor(v, 4, 64);         // add the four blocks (adjacent 64-byte chunks)
       v += __shfl_xor(v, 8, 64);
       const int row = i0 + 4 * t + lk;   // lane 16 i (+0) holds row i
-      if (ABL == 7) {  // ABL 7: cross-lane adds but no partial stores
-        sink5 += v;
-        continue;
-      }
       if ((lane & 15) == 0 && row < nrows) keep[row] = v;
       if (SCALE == 3 && (lane & 15) == 1 && row < nrows) keep[ldp + row] = v;  // column 1: dots with u
     }
   }
-  if ((ABL == 5 || ABL == 7) && sink5 == 1.2345e300) part[0] = sink5;
   if (SCALE == 3) {
     if (lane == 0) {  // slots behind the streamed rows: [nrows] = r''.r'', [ldp + nrows] = u.u, [ldp + nrows + 1] = u.r''
       keep[nrows] = self3[0];
@@ -779,7 +690,7 @@ __global__ __launch_bounds__(kTPB) void k_qtw_mfma4(double* __restrict__ V, int6
   const int t_top = i_top / (4 * T);
   for (int i = threadIdx.x; i < nout; i += kTPB) {
     if (kstep > 1) {  // row split: this block owns the tiles k == ky (mod Y) counted from the top, and block 0 row j's self term
-      const bool mine_row = i == j ? ky == 0 : (ABL == 3 ? i / (4 * T) : t_top - i / (4 * T)) % kstep == ky;
+      const bool mine_row = i == j ? ky == 0 : (t_top - i / (4 * T)) % kstep == ky;
       if (!mine_row) continue;
     }
     __builtin_nontemporal_store(((k0[i] + k0[run + i]) + k0[2 * run + i]) + k0[3 * run + i], mine + i);
@@ -918,15 +829,6 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
       case 10: go(k_qtw_mfma4<SCALE, 4, 4>); break;
       case 11: go(k_qtw_mfma4<SCALE, 2, 8>); break;
       case 13: go(k_qtw_mfma4<SCALE, 8, 2>); break;
-#ifdef LZ_KBENCH  // timing-only ablation arms (wrong results on purpose): kernel-bench build only
-      case 21: go(k_qtw_mfma4<SCALE, 4, 2, 1>); break;  // no LDS read of w
-      case 22: go(k_qtw_mfma4<SCALE, 4, 2, 2>); break;  // VALU instead of MFMA
-      case 23: go(k_qtw_mfma4<SCALE, 4, 2, 3>); break;  // ascending rows
-      case 24: go(k_qtw_mfma4<SCALE, 4, 2, 4>); break;  // no staging of w
-      case 25: go(k_qtw_mfma4<SCALE, 4, 2, 5>); break;  // no per-tile epilogue
-      case 26: go(k_qtw_mfma4<SCALE, 4, 2, 6>); break;  // no cross-tile prefetch
-      case 27: go(k_qtw_mfma4<SCALE, 4, 2, 7>); break;  // coefficients not kept
-#endif
       default: go(k_qtw_mfma4<SCALE, 4, 2>); break;     // measured best: 2 tiles of 4 rows x 4 steps = 8 loads in flight per lane
     }
     return err;
@@ -934,15 +836,7 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
   if constexpr (SCALE == 3 || SCALE == 4) return hipErrorInvalidValue;  // these modes exist for the default (4x4x4 MFMA) family only
 #ifdef LZ_KBENCH
   if constexpr (SCALE != 2 && SCALE != 3 && SCALE != 4) {
-    if (plan.family == 1) {
-      switch (plan.variant) {
-        case 1: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 4, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-        case 2: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 16, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-        case 4: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
-        default: hipLaunchKernelGGL((k_qtw_mfma<SCALE, 8, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;
-      }
-      return hipSuccess;
-    }
+    if (plan.family == 1) return kb_launch_qtw_mfma<SCALE>(V, ldv, len, nrows, j, r, nrm2, beta_slot, plan, part, s);
   }
 #else
   if (plan.family == 1) return hipErrorInvalidValue;  // (lz_set_options refuses LZ_FLAG_QTW_MFMA in the product library)
@@ -950,13 +844,6 @@ static hipError_t launch_qtw_t(double* V, int64_t ldv, int64_t len, int nrows, i
   switch (plan.variant) {
     case 1: hipLaunchKernelGGL((k_qtw_valu<SCALE, 4, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;
     case 7: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 0>), grid, block, lds, s, LZ_QTW_ARGS); break;  // plain (cached) loads
-#ifdef LZ_KBENCH
-    case 31: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 1>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no reductions/stores
-    case 32: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 2>), grid, block, lds, s, LZ_QTW_ARGS); break;  // ascending
-    case 33: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 3>), grid, block, lds, s, LZ_QTW_ARGS); break;  // both
-    case 35: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 5>), grid, block, lds, s, LZ_QTW_ARGS); break;  // no reductions, no LDS
-    case 37: hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2, 1, 7>), grid, block, lds, s, LZ_QTW_ARGS); break;  // all three
-#endif
     default:  // measured best on MI355X (profiles/r01): 8 rows x 2 positions = 16 loads in flight per lane
       if (nrows > 4)
         hipLaunchKernelGGL((k_qtw_valu<SCALE, 8, 2>), grid, block, lds, s, LZ_QTW_ARGS);

@@ -41,9 +41,7 @@ __global__ __launch_bounds__(kTPB) void k_spmv_scalar(const int32_t* __restrict_
 // csr_matvec: sum += a*x, no FMA).  Row blocks are precomputed on the host so
 // that one block's products fit the LDS tile.
 
-// ABL != 0 instantiations are timing-only ablation arms for tools/kbench.py (wrong results on purpose):
-// 1 = no x gather, 2 = no colidx load, 4 = no vals load, 8 = no y store.
-template <int FIXED_K, int ABL = 0>
+template <int FIXED_K>
 __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict__ rowblk, const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ colidx, const double* __restrict__ vals,
                                                      const double* __restrict__ x, const double* __restrict__ xown,
@@ -72,9 +70,8 @@ __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict_
         int p = pb + kTPB * i;
         if (p >= npair) p = pb;  // clamped duplicate, discarded below
         const int k = kk + 2 * p;
-        a[i] = (ABL & 4) ? make_double2(1.0, 2.0) : ld_stream<1>(reinterpret_cast<const double2*>(vals + k));
-        c[i] = (ABL & 2) ? make_int2(k / (K > 0 ? K : 1), (k + 1) / (K > 0 ? K : 1)) : ld_stream<1>(reinterpret_cast<const int2*>(colidx + k));
-        if (ABL & 1) c[i] = make_int2(c[i].x & 1023, c[i].y & 1023);
+        a[i] = ld_stream<1>(reinterpret_cast<const double2*>(vals + k));
+        c[i] = ld_stream<1>(reinterpret_cast<const int2*>(colidx + k));
       }
       double2 xv[NB];
 #pragma unroll
@@ -117,7 +114,7 @@ __global__ __launch_bounds__(kTPB) void k_spmv_stream(const int32_t* __restrict_
         }
         for (; k < b; ++k) sum += prod[k];
       }
-      if (!(ABL & 8)) y[row] = sum;
+      y[row] = sum;
       d += xown[row] * sum;
     }
   } else {
@@ -366,7 +363,7 @@ hipError_t ell_build(CsrDev& A, int variant, hipStream_t s) {
 }
 
 bool ell_usable(const CsrDev& A, int flags) {
-  return A.ell_rb > 0 && !A.ablation && !(flags & (LZ_FLAG_SPMV_SCALAR | LZ_FLAG_SPMV_STREAM)) && !A.pb;
+  return A.ell_rb > 0 && !(flags & (LZ_FLAG_SPMV_SCALAR | LZ_FLAG_SPMV_STREAM)) && !A.pb;
 }
 
 template <int K, int RPT, int VEC>
@@ -401,27 +398,13 @@ int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x
     hipLaunchKernelGGL(k_spmv_scalar, dim3(grid), dim3(kTPB), 0, s, A.rowptr, A.colidx, A.vals, x, x_own, y, A.rows, part);
     return grid;
   }
-  if (A.pb && !(flags & LZ_FLAG_SPMV_STREAM)) return launch_spmv_pb(A, A.pb, x, y, x_own, part, s);  // (A.ablation: kbench arms of phase 2)
-  if (!A.ablation && !(flags & LZ_FLAG_SPMV_STREAM)) {  // A.ablation is always 0 in the product build
+  if (A.pb && !(flags & LZ_FLAG_SPMV_STREAM)) return launch_spmv_pb(A, A.pb, x, y, x_own, part, s);
+  if (!(flags & LZ_FLAG_SPMV_STREAM)) {
     if (A.fixed_k == 5) return launch_spmv_fixed<5>(A, x, y, x_own, part, A.fixed_rb, s);
     if (A.fixed_k == 7) return launch_spmv_fixed<7>(A, x, y, x_own, part, A.fixed_rb, s);
   }
   const int grid = A.n_rowblk;
   const size_t lds = (size_t)(A.blk_nnz_cap + 2) * sizeof(double);
-#ifdef LZ_KBENCH  // timing-only ablation arms (wrong results on purpose): kernel-bench build only
-#define LZ_ABL(n)                                                                                                   \
-  case n:                                                                                                          \
-    hipLaunchKernelGGL((k_spmv_stream<5, n>), dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, \
-                       5, A.blk_nnz_cap, part);                                                                    \
-    return grid;
-  if (A.fixed_k == 5 && A.ablation) {
-    switch (A.ablation) {
-      LZ_ABL(1) LZ_ABL(2) LZ_ABL(3) LZ_ABL(4) LZ_ABL(7) LZ_ABL(8) LZ_ABL(15)
-      default: break;
-    }
-  }
-#undef LZ_ABL
-#endif
   if (A.fixed_k == 5)
     hipLaunchKernelGGL(k_spmv_stream<5>, dim3(grid), dim3(kTPB), lds, s, A.rowblk, A.rowptr, A.colidx, A.vals, x, x_own, y, 5,
                        A.blk_nnz_cap, part);

@@ -311,7 +311,6 @@ struct PbTile {
   double dv[kPbNR];  // the rows' diagonal entries (dvals), 0 without the diagonal split
 };
 
-template <int ABL>
 __device__ __forceinline__ void pb_tile_load(PbTile& t, int4 hd, int2 sg, const int32_t* __restrict__ rowptr,
                                              const uint16_t* __restrict__ perm, const double* __restrict__ T2,
                                              const double* __restrict__ xown, const double* __restrict__ dvals) {
@@ -320,7 +319,7 @@ __device__ __forceinline__ void pb_tile_load(PbTile& t, int4 hd, int2 sg, const 
 #pragma unroll
   for (int i = 0; i < kPbNQ; ++i) {
     const int p = threadIdx.x + i * kPbThreads;
-    if (!(ABL & 1) && p < n2) t.q[i] = ld_stream<1>(src + p);
+    if (p < n2) t.q[i] = ld_stream<1>(src + p);
   }
   const int kbase = hd.z & ~7;  // aligned window of perm: 16-byte loads
   const int n8 = (hd.z + hd.w - kbase + 7) >> 3;
@@ -328,7 +327,7 @@ __device__ __forceinline__ void pb_tile_load(PbTile& t, int4 hd, int2 sg, const 
 #pragma unroll
   for (int i = 0; i < kPbNP; ++i) {
     const int p = threadIdx.x + i * kPbThreads;
-    if (!(ABL & 2) && p < n8) t.pm[i] = __builtin_nontemporal_load(pm8 + p);
+    if (p < n8) t.pm[i] = __builtin_nontemporal_load(pm8 + p);
   }
 #pragma unroll
   for (int i = 0; i < kPbNR; ++i) {
@@ -345,7 +344,6 @@ __device__ __forceinline__ void pb_tile_load(PbTile& t, int4 hd, int2 sg, const 
   }
 }
 
-template <int ABL>  // kernel-bench build: 1 no product loads, 2 no perm loads, 4 no LDS gathers
 __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__ rbhead, const int2* __restrict__ rbseg,
                                                        const int32_t* __restrict__ rowptr, const uint16_t* __restrict__ perm,
                                                        const double* __restrict__ T2, int segcap, int nRB,
@@ -357,7 +355,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
   int4 hd = rbhead[rb];
   int2 sg = rbseg[rb];
   PbTile t;
-  pb_tile_load<ABL>(t, hd, sg, rowptr, perm, T2, xown, dvals);
+  pb_tile_load(t, hd, sg, rowptr, perm, T2, xown, dvals);
   for (;;) {
     // registers -> LDS.  The explicit vmcnt(0) tells the compiler's wait-count pass, on every path, that nothing is
     // outstanding from here on - otherwise the predicated loads below make it wait in the middle of the next prefetch.
@@ -370,14 +368,14 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
 #pragma unroll
       for (int i = 0; i < kPbNQ; ++i) {
         const int p = threadIdx.x + i * kPbThreads;
-        if (!(ABL & 1) && p < n2) dst[p] = t.q[i];
+        if (p < n2) dst[p] = t.q[i];
       }
       const int n8 = (hd.z + hd.w - (hd.z & ~7) + 7) >> 3;
       u4v_t* pd = reinterpret_cast<u4v_t*>(perm_s);
 #pragma unroll
       for (int i = 0; i < kPbNP; ++i) {
         const int p = threadIdx.x + i * kPbThreads;
-        if (!(ABL & 2) && p < n8) pd[p] = t.pm[i];
+        if (p < n8) pd[p] = t.pm[i];
       }
     }
     int ka[kPbNR], kb[kPbNR];
@@ -402,7 +400,7 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
     if (more) {
       hd = rbhead[rb];
       sg = rbseg[rb];
-      pb_tile_load<ABL>(t, hd, sg, rowptr, perm, T2, xown, dvals);
+      pb_tile_load(t, hd, sg, rowptr, perm, T2, xown, dvals);
     }
     double d = 0.0;
 #pragma unroll
@@ -413,14 +411,13 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
         double sum = 0.0;
         int k = a;
         for (; k + 4 <= b; k += 4) {  // four LDS gathers in flight; the adds stay in CSR order, one rounding each
-          const double p0 = (ABL & 4) ? 1.0 : seg[perm_s[k]], p1 = (ABL & 4) ? 1.0 : seg[perm_s[k + 1]], p2 = (ABL & 4) ? 1.0 : seg[perm_s[k + 2]],
-                       p3 = (ABL & 4) ? 1.0 : seg[perm_s[k + 3]];
+          const double p0 = seg[perm_s[k]], p1 = seg[perm_s[k + 1]], p2 = seg[perm_s[k + 2]], p3 = seg[perm_s[k + 3]];
           sum += p0;
           sum += p1;
           sum += p2;
           sum += p3;
         }
-        for (; k < b; ++k) sum += (ABL & 4) ? 1.0 : seg[perm_s[k]];
+        for (; k < b; ++k) sum += seg[perm_s[k]];
         y[rw] = sum;
         d += xo[i] * sum;
       }
@@ -465,12 +462,7 @@ hipError_t pb_raise_lds_limits() {
   up(reinterpret_cast<const void*>(k_pb_products<4, double>));
   up(reinterpret_cast<const void*>(k_pb_products<4, float>));
   up(reinterpret_cast<const void*>(k_pb_products<4, PbConst>));
-  up(reinterpret_cast<const void*>(k_pb_rows<0>));
-#ifdef LZ_KBENCH
-  up(reinterpret_cast<const void*>(k_pb_rows<1>));
-  up(reinterpret_cast<const void*>(k_pb_rows<2>));
-  up(reinterpret_cast<const void*>(k_pb_rows<7>));
-#endif
+  up(reinterpret_cast<const void*>(k_pb_rows));
   if (tracked) done[dev] = e;
   return e;
 }
@@ -725,25 +717,8 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
                        pb->W, pb->T2, 0.0);
   const int grid = std::min(pb->nRB, pb->ncu);  // one segment fills a CU's LDS: one persistent workgroup per CU
   const int segcap = pb->segmax;
-#define LZ_PB_ROWS(abl)                                                                                                        \
-  hipLaunchKernelGGL(k_pb_rows<abl>, dim3(grid), dim3(kPbThreads), pb->lds2, s, pb->rbhead, pb->rbseg, A.rowptr, pb->perm, pb->T2, segcap, \
-                     pb->nRB, x_own, y, part, pb->dvals)
-#ifdef LZ_KBENCH  // timing-only ablation arms (wrong results): 1 no product loads, 2 no perm loads, 7 neither and no LDS gathers
-  if (A.ablation == 1) {
-    LZ_PB_ROWS(1);
-    return pb->nRB;
-  }
-  if (A.ablation == 2) {
-    LZ_PB_ROWS(2);
-    return pb->nRB;
-  }
-  if (A.ablation == 7) {
-    LZ_PB_ROWS(7);
-    return pb->nRB;
-  }
-#endif
-  LZ_PB_ROWS(0);
-#undef LZ_PB_ROWS
+  hipLaunchKernelGGL(k_pb_rows, dim3(grid), dim3(kPbThreads), pb->lds2, s, pb->rbhead, pb->rbseg, A.rowptr, pb->perm, pb->T2, segcap, pb->nRB, x_own, y, part,
+                     pb->dvals);
   return pb->nRB;
 }
 

@@ -194,28 +194,39 @@ def test_plain_c_client_runs(tmp_path):
 
 
 def test_product_library_has_no_ablation_kernels():
-    """The timing-only ablation arms (template parameter ABL != 0: wrong results on purpose) live only in the
-    kernel-bench build (make KBENCH=1 -> liblanczos_kbench.so).  The kernels' mangled names are embedded in the
-    shared library (host stubs + code-object symbol table): none of them may carry a non-zero ABL argument, and
-    lz_set_tuning refuses the knob values that used to select them."""
+    """Round 5 deleted the timing-only ablation arms (kernel template parameter ABL != 0: wrong results on purpose) from the sources
+    of BOTH builds - the hot kernels no longer carry an ABL parameter at all - and moved the retired, bit-identity-tested A/B kernels
+    into kernel-bench-only files (lz_*_kbench.h, lz_small.hip).  The kernels' mangled names are embedded in the shared library (host
+    stubs + code-object symbol table): the product library must hold the live kernels under their ABL-free signatures and none of the
+    retired ones; lz_set_tuning refuses the knob values that used to select either."""
     blob = open(_capi.LIB_PATH, "rb").read()
-    # k_qtw_mfma4<SCALE, U, T, ABL>, k_qtw_valu<SCALE, R, U, NT, ABL>, k_spmv_stream<FIXED_K, ABL>
-    assert re.search(rb"k_qtw_mfma4ILi\d+ELi\d+ELi\d+ELi0EE", blob), "default Q^T w kernel not found - naming changed?"
-    assert not re.search(rb"k_qtw_mfma4ILi\d+ELi\d+ELi\d+ELi[1-9]\d*EE", blob)
-    assert not re.search(rb"k_qtw_valuILi\d+ELi\d+ELi\d+ELi\d+ELi[1-9]\d*EE", blob)
-    assert not re.search(rb"k_spmv_streamILi\d+ELi[1-9]\d*EE", blob)
-    # round 3: the S-in-LDS Ritz kernel's timing-only arms, and the RETIRED A/B arms (measured slower; kernel-bench build only)
-    assert re.search(rb"k_gemm_tn_sl2ILi\d+ELi\d+ELi0ELb[01]EE", blob), "S-in-LDS Ritz kernel not found - naming changed?"
-    assert not re.search(rb"k_gemm_tn_sl2ILi\d+ELi\d+ELi[1-9]", blob)
-    assert not re.search(rb"k_gemm_tn_sregILi\d+ELi\d+ELi[1-9]", blob)
+    # k_qtw_mfma4<SCALE, U, T>, k_qtw_valu<SCALE, R, U, NT>, k_spmv_stream<FIXED_K>, k_gemm_tn_sl2<NT, KS, USE4>, k_gemm_tn_sreg<NT, KS>
+    assert re.search(rb"k_qtw_mfma4ILi\d+ELi\d+ELi\d+EE", blob), "default Q^T w kernel not found - naming changed?"
+    assert not re.search(rb"k_qtw_mfma4ILi\d+ELi\d+ELi\d+ELi\d+EE", blob)
+    assert re.search(rb"k_qtw_valuILi\d+ELi\d+ELi\d+ELi\d+EE", blob) and not re.search(rb"k_qtw_valuILi\d+ELi\d+ELi\d+ELi\d+ELi\d+EE", blob)
+    assert re.search(rb"k_spmv_streamILi\d+EE", blob) and not re.search(rb"k_spmv_streamILi\d+ELi\d+EE", blob)
+    assert re.search(rb"k_gemm_tn_sl2ILi\d+ELi\d+ELb[01]EE", blob), "S-in-LDS Ritz kernel not found - naming changed?"
+    assert not re.search(rb"k_gemm_tn_sl2ILi\d+ELi\d+ELi\d+", blob)
+    assert re.search(rb"k_gemm_tn_sregILi\d+ELi\d+EE", blob) and not re.search(rb"k_gemm_tn_sregILi\d+ELi\d+ELi\d+", blob)
+    assert b"k_pb_rows" in blob and not re.search(rb"k_pb_rowsILi", blob)
     for retired in (rb"k_small_run", rb"k_small_step", rb"k_gemm_tn_persist", rb"k_gemm_tn_ldsI", rb"k_qtw_mfmaILi", rb"k_gemm_tn_slILi"):
         assert retired not in blob, retired
-    if os.path.isfile(_capi.KBENCH_LIB_PATH):  # ... which the kernel-bench build still carries
+    if os.path.isfile(_capi.KBENCH_LIB_PATH):  # ... which the kernel-bench build still carries (without ablation parameters either)
         kblob = open(_capi.KBENCH_LIB_PATH, "rb").read()
-        for retired in (rb"k_small_run", rb"k_gemm_tn_persist", rb"k_gemm_tn_ldsI", rb"k_qtw_mfmaILi"):
+        for retired in (rb"k_small_run", rb"k_gemm_tn_persist", rb"k_gemm_tn_ldsI", rb"k_qtw_mfmaILi", rb"k_gemm_tn_slILi"):
             assert retired in kblob, retired
+        assert not re.search(rb"k_qtw_mfma4ILi\d+ELi\d+ELi\d+ELi\d+EE", kblob) and not re.search(rb"k_pb_rowsILi", kblob)
+    # the sources say the same: no ABL template parameter left anywhere, the retired kernels only in kernel-bench-only files
+    csrc = os.path.join(ROOT, "lanczos_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            src = open(os.path.join(csrc, fn)).read()
+            assert "ABL" not in src, fn
+            if not (fn.endswith("_kbench.h") or fn == "lz_small.hip"):
+                for name in ("k_gemm_tn_persist", "k_gemm_tn_lds", "k_small_run"):
+                    assert ("void " + name) not in src, (fn, name)
     lib = lanczos_amd.load_library()
-    assert lib.lz_set_tuning(None, 1, 21) == -1  # (no handle on a CPU box; with one: tests/test_gpu_kernels.py)
+    assert lib.lz_set_tuning(None, 1, 21) == -1  # (no handle on a CPU box; with one: tests/test_gpu_lanczos.py)
 
 
 def test_two_hip_runtimes_are_detected_and_refused():

@@ -587,7 +587,7 @@ def test_breakdown_status_through_the_c_abi(hip):
 
 def test_ablation_knobs_are_rejected_by_the_product_library(hip, kb):
     h = hip.Handle(0)
-    # timing-only ablations (1 >= 20, 3), out-of-range knobs, and the A/B arms retired in round 3: the one-kernel /
+    # timing-only ablations (1 >= 20, 3, 9 >= 10: deleted from BOTH builds in round 5), out-of-range knobs, and the A/B arms retired in round 3: the one-kernel /
     # one-launch-per-step engines (15 = 2, 3, 5), the persistent / LDS-staged / forced S-stationary Ritz GEMM arms (9 >= 2),
     # the ticket / deferred-fold two-sided links (11 >= 2)
     for idx, val in [(1, 21), (1, 27), (1, 31), (1, 37), (3, 1), (3, 15), (24, 0), (-1, 0), (0, -5),
@@ -599,9 +599,11 @@ def test_ablation_knobs_are_rejected_by_the_product_library(hip, kb):
     assert h.lib.lz_set_options(h._h, hip.FLAG_QTW_MFMA) == -1 and b"retired" in h.lib.lz_last_error(h._h)  # the 16x16x4 Q^T w arm
     assert h.lib.lz_set_options(h._h, hip.FLAG_QTW_VALU | hip.FLAG_FUSED_NORM) == 0  # (the VALU kernel is the fallback for > 5000 basis rows)
     h.close()
-    k = kb.Handle(0)  # the kernel-bench build still takes them
-    for idx, val in [(15, 2), (15, 5), (9, 3), (11, 3), (1, 21)]:
+    k = kb.Handle(0)  # the kernel-bench build still takes the retired (bit-identity-tested) arms ...
+    for idx, val in [(15, 2), (15, 5), (9, 3), (11, 3)]:
         assert k.lib.lz_set_tuning(k._h, idx, val) == 0, (idx, val)
+    for idx, val in [(1, 21), (3, 1), (9, 21), (9, 31)]:  # ... but the timing-only ablation arms are gone from it too
+        assert k.lib.lz_set_tuning(k._h, idx, val) == -1 and b"removed in round 5" in k.lib.lz_last_error(k._h), (idx, val)
     assert k.lib.lz_set_options(k._h, hip.FLAG_QTW_MFMA) == 0
     k.close()
 

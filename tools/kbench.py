@@ -16,7 +16,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lanczos_amd import _capi, synthetic  # noqa: E402
 
-# the kernel-bench build of the library (make -C lanczos_amd/csrc KBENCH=1): the product library has no ablation arms
+# the kernel-bench build of the library (make -C lanczos_amd/csrc KBENCH=1): the retired A/B kernels; the timing-only ablation arms
+# (knob 1 >= 20, knob 3, knob 9 >= 10) of rounds 1-4 no longer exist in either build (deleted in round 5; results in profiles/)
 _KB = os.path.join(os.path.dirname(_capi.LIB_PATH), "liblanczos_kbench.so")
 if os.path.isfile(_KB):
     _capi.LIB_PATH = _KB

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing-only ablations (kernel-bench build of the library) of the two kernels that sit furthest below their estimate:
+"""HISTORICAL (rounds 2-3; the ablation arms it drives were deleted from the sources in round 5, results: profiles/r02/ablate_*.json).
+Timing-only ablations (kernel-bench build of the library) of the two kernels that sit furthest below their estimate:
 phase 2 of the two-phase irregular SpMV (k_pb_rows) and the LDS-staged Ritz GEMM.  Prints one JSON object."""
 import json
 import os
