@@ -139,6 +139,9 @@ int lz_set_options(lz_handle h, int flags);
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
  *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta),
  *       3 device-resident with pass 1's second-stage sums as a kernel of their own (default: pass 1's last block adds them)
+ *   22  irregular (two-phase) SpMV: interleave its two phases over this many groups of row blocks (A/B arm of round 5: the product
+ *       stream of a group could stay in the Infinity Cache between the phases; measured 8-110 % slower - DESIGN.md section 4; kernel-bench
+ *       build only; 0 / 1 = off)
  *   21  Gram matrix: number of K slices (workgroups per unit) of the symmetric kernel; 0 auto (whole residency rounds of 256)
  *   20  one-reduce partial loop (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE): safety factor kappa of the look-ahead sweep
  *       decision (a sweep is due when kappa * max |predicted omega| > sqrt(eps); 0 = the default, 4)
@@ -146,7 +149,7 @@ int lz_set_options(lz_handle h, int flags);
  * liblanczos_kbench.so, loaded by tools/ and by the tests of those arms; sources: lz_small.hip, lz_*_kbench.h): the A/B arms
  * retired in round 3 because they measured slower - the one-kernel and one-launch-per-step engines
  * (15 = 2, 3, 5), the persistent / LDS-staged / 16-row-tile Ritz GEMMs (9 = 2, 3, 4, 6), the ticket / deferred-fold two-sided links
- * (11 = 2, 3), and LZ_FLAG_QTW_MFMA (lz_set_options).  The timing-only ablation arms of rounds 1-4 (kernel variants that computed
+ * (11 = 2, 3), the two-phase SpMV's row-block-group interleaving (22 >= 2), and LZ_FLAG_QTW_MFMA (lz_set_options).  The timing-only ablation arms of rounds 1-4 (kernel variants that computed
  * wrong results on purpose: knob 1 >= 20, knob 3, knob 9 >= 10) were deleted from both builds in round 5. */
 int lz_set_tuning(lz_handle h, int index, int value);
 /* "hip=<path of the libamdhip64 this library is bound to>;rccl=<path of the librccl it dlopened, or empty>".

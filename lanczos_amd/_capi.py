@@ -50,6 +50,7 @@ TUNE_LOOP = 15              # loop structure (0 auto, 1 six launches per step al
 TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 forces it)
 TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto: CSR order, ELL only in the partial loop; 1 never ELL; 2 / 3 ELL always, one / two rows per lane)
 TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel with LDS-staged operands, 1 split-K TN GEMM, 2 the register-ring form)
+TUNE_PB_GROUPS = 22         # two-phase SpMV: phases interleaved over this many row-block groups (A/B arm; 0 = off)
 TUNE_GRAM_SLICES = 21       # Gram matrix: K slices of the symmetric kernel (0 auto)
 TUNE_PARTIAL_LOOKAHEAD = 20 # one-reduce partial loop: safety factor of the look-ahead sweep decision (0 = default 4)
 TUNE_PARTIAL_LOOP = 18      # partial re-orthogonalisation loop (0 device-resident, 1 host-decided, 2 device-resident without the fused scale,

@@ -510,8 +510,8 @@ int lz_set_tuning(lz_handle h, int index, int value) {
 #ifndef LZ_KBENCH
   // Retired A/B arms (built, measured slower, kept bit-identity-tested in the kernel-bench build): the one-kernel /
   // one-launch-per-step engines (15 = 2, 3, 5), the persistent and LDS-staged Ritz GEMMs (9 >= 2), the ticket / deferred-fold
-  // two-sided links (11 >= 2)
-  if ((index == 15 && value >= 2) || (index == 9 && value >= 2) || (index == 11 && value >= 2))
+  // two-sided links (11 >= 2), the row-block-group interleaving of the two-phase SpMV (22 >= 2: round 5, 8-110 % slower)
+  if ((index == 15 && value >= 2) || (index == 9 && value >= 2) || (index == 11 && value >= 2) || (index == 22 && value >= 2))
     return fail(h, LZ_ERR_ARG, "lz_set_tuning: this A/B arm was retired from the product library (build with KBENCH=1)");
 #endif
   if (value < 0) return fail(h, LZ_ERR_ARG, "lz_set_tuning: negative value");

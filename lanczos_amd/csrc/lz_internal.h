@@ -73,7 +73,7 @@ struct CsrDev {
 };
 
 // ---- column-blocked two-phase SpMV (lz_spmv_pb.hip): gathers out of LDS only; y bit-identical to the CSR-stream kernel
-hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob = 0);  // *out == nullptr: not applicable
+hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob = 0, int groups = 0);  // *out == nullptr: not applicable; groups > 1: the A/B arm of knob 22
 void pb_free(PbDev*& pb);
 int pb_num_partials(const PbDev* pb);
 void pb_layout_info(const PbDev* pb, int64_t* np, int* in_bytes_x2, int* diag);

@@ -85,7 +85,7 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   if (A.ell_default && (fixed_k == 5 || fixed_k == 7 || fixed_k == 27)) LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
   const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
-    const hipError_t pe = pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10]);
+    const hipError_t pe = pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10], h->tune[22]);
     A.host_colidx = nullptr;  // (the caller's arrays are only valid during this call)
     A.host_vals = nullptr;
     LZ_HIP(h, pe);

@@ -78,6 +78,12 @@ struct PbDev {
   double cval = 0.0;
   double* dvals = nullptr;     // rows: the diagonal entry of every row (0 where a row has none); nullptr: diagonal not split off
   int maxrows = 0;             // longest row block (rows)
+  // A/B arm of round 5 (knob 22 = G > 1; DESIGN.md section 4, "closed"): the two phases interleaved over G groups of row blocks -
+  // products(g), rows(g), products(g + 1), ... - so that a group's segment of T2 (+ x) may stay in the Infinity Cache between its
+  // two kernels.  grp_rb: G + 1 row-block boundaries (host); grp_ptr[g * nCB + cb]: where group g starts in column block cb's stream.
+  int groups = 0;
+  std::vector<int> grp_rb;
+  int32_t* grp_ptr = nullptr;
   double* T2 = nullptr;        // np products
   int segmax = 0;              // longest padded segment (products)
   int ncu = 256;               // compute units of the device: phase 2's persistent grid
@@ -179,6 +185,16 @@ __global__ __launch_bounds__(256) void k_pb_place(const int32_t* __restrict__ ro
   }
 }
 
+// A/B arm (knob 22): grp_ptr[g * nCB + cb] = stream position where row-block group g starts inside column block cb
+__global__ __launch_bounds__(256) void k_pb_group_ptr(const int32_t* __restrict__ cbptr, const int32_t* __restrict__ toff, int nRB, int nCB, int G,
+                                                     const int32_t* __restrict__ grb, int32_t* __restrict__ grp_ptr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (G + 1) * nCB) return;
+  const int g = i / nCB, cb = i - g * nCB;
+  const int rb = grb[g];
+  grp_ptr[i] = rb < nRB ? cbptr[cb] + toff[(int64_t)rb * nCB + cb] : cbptr[cb + 1];
+}
+
 // ---- phase 1: T2[gdst[t / 8] + t % 8] = pvals[t] * v[columns], column block in LDS.  A lane takes PAIRS of entries (one
 // 16-byte value load, one 4-byte column load, a 16-byte product store); four lanes share a group's destination.
 __device__ __forceinline__ double2 pb_ld_vals(const double* pv, int64_t pair) { return ld_stream<1>(reinterpret_cast<const double2*>(pv) + pair); }
@@ -198,7 +214,7 @@ template <int U, class VT>
 __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __restrict__ cbptr, const VT* __restrict__ pvals,
                                                            const uint16_t* __restrict__ pcol, const uint32_t* __restrict__ gdst,
                                                            const double* __restrict__ x, int64_t ncols, int W,
-                                                           double* __restrict__ T2, double cval) {
+                                                           double* __restrict__ T2, double cval, const int32_t* __restrict__ grp_ptr, int grp) {
   constexpr bool kConst = std::is_same<VT, PbConst>::value;
   extern __shared__ double xs[];
   const int cb = blockIdx.x;
@@ -226,7 +242,11 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_products(const int32_t* __res
     if ((wn & 1) && threadIdx.x == 0) xs[wn - 1] = x[c0 + wn - 1];
   }
   __syncthreads();
-  const int64_t p0 = (int64_t)cbptr[cb] >> 1, p1 = (int64_t)cbptr[cb + 1] >> 1;  // stream positions are multiples of 8
+  // stream positions are multiples of 8.  grp_ptr (A/B arm, knob 22): only the part of this column block's stream that belongs to
+  // row-block group `grp` (a column block's stream is ordered by row block: k_pb_place)
+  const int64_t p0 = (int64_t)(grp_ptr ? grp_ptr[(int64_t)grp * gridDim.x + cb] : cbptr[cb]) >> 1;
+  const int64_t p1 = (int64_t)(grp_ptr ? grp_ptr[(int64_t)(grp + 1) * gridDim.x + cb] : cbptr[cb + 1]) >> 1;
+  if (p1 <= p0) return;  // (uniform over the block; before any barrier-dependent work: the staging above is complete)
   const uint32_t* pc2 = reinterpret_cast<const uint32_t*>(pcol);
   constexpr int64_t B = (int64_t)U * kPbThreads;  // pairs per batch
   // One batch: lane p takes the pairs p, p + 1024, ...: a value pair, a column pair, the destination of its group of 8.
@@ -348,10 +368,10 @@ __global__ __launch_bounds__(kPbThreads) void k_pb_rows(const int4* __restrict__
                                                        const int32_t* __restrict__ rowptr, const uint16_t* __restrict__ perm,
                                                        const double* __restrict__ T2, int segcap, int nRB,
                                                        const double* __restrict__ xown, double* __restrict__ y,
-                                                       double* __restrict__ part, const double* __restrict__ dvals) {
+                                                       double* __restrict__ part, const double* __restrict__ dvals, int rb0) {
   extern __shared__ double seg[];  // per row block: its padded segment of products | one diagonal product per row | the aligned window of its perm entries
   __shared__ double red[kPbThreads / 64];
-  int rb = blockIdx.x;  // the grid is never larger than nRB
+  int rb = rb0 + blockIdx.x;  // row blocks [rb0, nRB): the grid is never larger than their number
   int4 hd = rbhead[rb];
   int2 sg = rbseg[rb];
   PbTile t;
@@ -478,6 +498,7 @@ hipError_t pb_alloc(T*& p, size_t count) {
 }  // namespace
 
 void pb_free(PbDev*& pb) {
+  if (pb) hipFree(pb->grp_ptr);
   if (!pb) return;
   hipFree(pb->rbptr);
   hipFree(pb->rbhead);
@@ -497,7 +518,7 @@ void pb_free(PbDev*& pb) {
 // Build the two-phase layout for the device CSR matrix A.  Returns hipSuccess with *out == nullptr when the matrix does
 // not qualify (a single row longer than the LDS tile).  A.host_colidx / A.host_vals (the caller's arrays, valid during
 // lz_set_csr) switch on the diagonal split and the fp32 value stream where they apply.
-hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob) {
+hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hipStream_t s, int cap_knob, int groups) {
   *out = nullptr;
   if (A.rows <= 0 || A.nnz <= 0) return hipSuccess;
   // Column blocks: as few as phase 1's LDS allows (a tile holds ~cap / nCB products: fewer blocks, longer tiles, less padding).
@@ -682,6 +703,28 @@ hipError_t pb_build(const CsrDev& A, const int32_t* rowptr_host, PbDev** out, hi
     chk(hipGetLastError());
     chk(hipStreamSynchronize(s));
   }
+  if (e == hipSuccess && groups > 1 && nRB >= 2 * groups) {
+    // row-block groups of (nearly) equal segment length
+    pb->groups = groups;
+    pb->grp_rb.assign((size_t)groups + 1, nRB);
+    pb->grp_rb[0] = 0;
+    int b = 0;
+    for (int g = 1; g < groups; ++g) {
+      const int64_t want = np * g / groups;
+      while (b < nRB && seg[(size_t)b].x < want) ++b;
+      pb->grp_rb[(size_t)g] = b;
+    }
+    int32_t* grb = nullptr;
+    chk(pb_alloc(grb, (size_t)groups + 1));
+    chk(pb_alloc(pb->grp_ptr, (size_t)(groups + 1) * nCB));
+    if (e == hipSuccess) chk(hipMemcpyAsync(grb, pb->grp_rb.data(), ((size_t)groups + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_pb_group_ptr, dim3(((groups + 1) * nCB + 255) / 256), dim3(256), 0, s, pb->cbptr, toff, nRB, nCB, groups, grb, pb->grp_ptr);
+      chk(hipGetLastError());
+      chk(hipStreamSynchronize(s));
+    }
+    hipFree(grb);
+  }
   hipFree(len);
   hipFree(toff);
   hipFree(tot);
@@ -706,19 +749,33 @@ int pb_num_partials(const PbDev* pb) { return pb->nRB; }
 // Returns the number of partials.
 int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y, const double* x_own, double* part, hipStream_t s) {
   const size_t lds1 = (size_t)pb->W * sizeof(double);
-  if (pb->constv)
-    hipLaunchKernelGGL((k_pb_products<4, PbConst>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, (const PbConst*)nullptr, pb->pcol, pb->gdst, x,
-                       A.ncols, pb->W, pb->T2, pb->cval);
-  else if (pb->pvals32)
-    hipLaunchKernelGGL((k_pb_products<4, float>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals32, pb->pcol, pb->gdst, x, A.ncols,
-                       pb->W, pb->T2, 0.0);
-  else
-    hipLaunchKernelGGL((k_pb_products<4, double>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, pb->gdst, x, A.ncols,
-                       pb->W, pb->T2, 0.0);
-  const int grid = std::min(pb->nRB, pb->ncu);  // one segment fills a CU's LDS: one persistent workgroup per CU
   const int segcap = pb->segmax;
-  hipLaunchKernelGGL(k_pb_rows, dim3(grid), dim3(kPbThreads), pb->lds2, s, pb->rbhead, pb->rbseg, A.rowptr, pb->perm, pb->T2, segcap, pb->nRB, x_own, y, part,
-                     pb->dvals);
+  auto products = [&](const int32_t* grp_ptr, int g) {
+    if (pb->constv)
+      hipLaunchKernelGGL((k_pb_products<4, PbConst>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, (const PbConst*)nullptr, pb->pcol, pb->gdst, x,
+                         A.ncols, pb->W, pb->T2, pb->cval, grp_ptr, g);
+    else if (pb->pvals32)
+      hipLaunchKernelGGL((k_pb_products<4, float>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals32, pb->pcol, pb->gdst, x, A.ncols,
+                         pb->W, pb->T2, 0.0, grp_ptr, g);
+    else
+      hipLaunchKernelGGL((k_pb_products<4, double>), dim3(pb->nCB), dim3(kPbThreads), lds1, s, pb->cbptr, pb->pvals, pb->pcol, pb->gdst, x, A.ncols,
+                         pb->W, pb->T2, 0.0, grp_ptr, g);
+  };
+  auto rows = [&](int rb0, int rb1) {  // one segment fills a CU's LDS: one persistent workgroup per CU
+    const int grid = std::min(rb1 - rb0, pb->ncu);
+    hipLaunchKernelGGL(k_pb_rows, dim3(grid), dim3(kPbThreads), pb->lds2, s, pb->rbhead, pb->rbseg, A.rowptr, pb->perm, pb->T2, segcap, rb1, x_own, y, part,
+                       pb->dvals, rb0);
+  };
+  if (pb->groups > 1) {  // A/B arm (knob 22): the phases interleaved over groups of row blocks
+    for (int g = 0; g < pb->groups; ++g) {
+      if (pb->grp_rb[(size_t)g + 1] <= pb->grp_rb[(size_t)g]) continue;
+      products(pb->grp_ptr, g);
+      rows(pb->grp_rb[(size_t)g], pb->grp_rb[(size_t)g + 1]);
+    }
+    return pb->nRB;
+  }
+  products(nullptr, 0);
+  rows(0, pb->nRB);
   return pb->nRB;
 }
 

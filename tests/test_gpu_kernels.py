@@ -147,6 +147,30 @@ def test_spmv_two_phase_bit_exact(hip, name):
     h.close()
 
 
+@pytest.mark.parametrize("groups", [2, 3, 7])
+def test_two_phase_row_block_group_arm_in_the_kernel_bench_build(kb, groups):
+    """Round 5 A/B arm (knob 22, kernel-bench build only: measured 8-110 % slower on C3, profiles/r05/ab_c3_row_block_groups.jsonl): the two
+    phases interleaved over G groups of row blocks - products(g), rows(g), ... - on the same layout: the same products into the same slots,
+    the same row sums: y and the alpha partial equal the default's and SciPy's bit for bit."""
+    H = _two_phase_matrices()["graph_60000_real"]  # (dozens of row blocks x 118 column blocks, values that really round)
+    M = H.shape[0]
+    x = np.random.default_rng(1).uniform(-1, 1, M)
+    ref = H * x
+    out = []
+    for g in (0, groups):
+        h = kb.Handle(0)
+        h.set_tuning(_capi.TUNE_SPMV_PLAN, 2)
+        h.set_tuning(_capi.TUNE_PB_GROUPS, g)
+        h.set_csr(M, 0, H.indptr, H.indices, H.data)
+        assert h.spmv_plan() == "two-phase"
+        y = h.spmv_host(x)
+        h.basis_alloc(2)
+        h.basis_set_row(1, x)
+        out.append((y, h.step_spmv(1)))
+        h.close()
+    assert np.array_equal(out[0][0], ref) and np.array_equal(out[1][0], ref) and out[0][1] == out[1][1]
+
+
 def test_two_phase_layout_on_a_second_device(hip):
     """the dynamic-LDS limit of the two-phase kernels is raised per DEVICE (hipFuncSetAttribute applies to the
     current device's function object): a handle on GPU 1 after one on GPU 0 in the same process must still launch with more

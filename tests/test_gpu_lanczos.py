@@ -591,7 +591,7 @@ def test_ablation_knobs_are_rejected_by_the_product_library(hip, kb):
     # one-launch-per-step engines (15 = 2, 3, 5), the persistent / LDS-staged / forced S-stationary Ritz GEMM arms (9 >= 2),
     # the ticket / deferred-fold two-sided links (11 >= 2)
     for idx, val in [(1, 21), (1, 27), (1, 31), (1, 37), (3, 1), (3, 15), (24, 0), (-1, 0), (0, -5),
-                     (15, 2), (15, 3), (15, 5), (9, 2), (9, 3), (9, 4), (9, 5), (9, 6), (9, 21), (11, 2), (11, 3)]:
+                     (15, 2), (15, 3), (15, 5), (9, 2), (9, 3), (9, 4), (9, 5), (9, 6), (9, 21), (11, 2), (11, 3), (22, 2), (22, 5)]:
         assert h.lib.lz_set_tuning(h._h, idx, val) == -1, (idx, val)  # LZ_ERR_ARG
     assert b"lz_set_tuning" in h.lib.lz_last_error(h._h)
     for idx, val in [(1, 0), (1, 10), (1, 13), (8, 2), (7, 8), (13, 1), (13, 0), (15, 0), (15, 1), (9, 0), (9, 1), (11, 0), (11, 1), (16, 4096), (16, 0)]:  # (9, 6) is retired too
@@ -600,7 +600,7 @@ def test_ablation_knobs_are_rejected_by_the_product_library(hip, kb):
     assert h.lib.lz_set_options(h._h, hip.FLAG_QTW_VALU | hip.FLAG_FUSED_NORM) == 0  # (the VALU kernel is the fallback for > 5000 basis rows)
     h.close()
     k = kb.Handle(0)  # the kernel-bench build still takes the retired (bit-identity-tested) arms ...
-    for idx, val in [(15, 2), (15, 5), (9, 3), (11, 3)]:
+    for idx, val in [(15, 2), (15, 5), (9, 3), (11, 3), (22, 4)]:
         assert k.lib.lz_set_tuning(k._h, idx, val) == 0, (idx, val)
     for idx, val in [(1, 21), (3, 1), (9, 21), (9, 31)]:  # ... but the timing-only ablation arms are gone from it too
         assert k.lib.lz_set_tuning(k._h, idx, val) == -1 and b"removed in round 5" in k.lib.lz_last_error(k._h), (idx, val)
