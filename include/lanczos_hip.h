@@ -153,7 +153,7 @@ int lz_set_options(lz_handle h, int flags);
  * wrong results on purpose: knob 1 >= 20, knob 3, knob 9 >= 10) were deleted from both builds in round 5. */
 int lz_set_tuning(lz_handle h, int index, int value);
 /* "hip=<path of the libamdhip64 this library is bound to>;rccl=<path of the librccl it dlopened, or empty>".
- * RCCL is always taken from the directory of that HIP runtime (LZ_RCCL_PATH overrides): see DESIGN.md section 5. */
+ * RCCL is always taken from the directory of that HIP runtime (LZ_RCCL_PATH overrides): see DESIGN.md section 6 and LAB_NOTEBOOK.md section 5. */
 int lz_runtime_info(char* buf, size_t buflen);
 int lz_device_synchronize(lz_handle h);
 int lz_device_name(lz_handle h, char* buf, size_t buflen);
@@ -331,7 +331,7 @@ int lz_last_sweep_misses(lz_handle h, int* misses);
  * 8: LZ_FLAG_ONE_REDUCE | LZ_FLAG_REORTH_PARTIAL (one all-reduce per step, look-ahead sweep decision on the device).
  * 5: a one-reduce run whose cancellation guard fired and that was repeated on the default loop.  1 / 4: the one-kernel and
  * one-launch-per-step engines of the kernel-bench build (retired from the product library in round 3: bit-identical, not
- * faster - DESIGN.md section 4). */
+ * faster - LAB_NOTEBOOK.md section 4). */
 int lz_last_engine(lz_handle h, int* engine);
 /* Host <-> device synchronisations lz_run made between its first and its last launch (the final wait for alpha / beta is not
  * counted).  0 for every loop on one rank and over RCCL - including, since round 4, the partial re-orthogonalisation mode
@@ -344,6 +344,9 @@ int lz_last_host_syncs(lz_handle h, int64_t* syncs);
 /* allocate a zeroed basis of n rows + r (what lz_run does first, Lanczos.py:104-107) */
 int lz_basis_alloc(lz_handle h, int n);
 int lz_basis_set_row(lz_handle h, int j, const double* row_local); /* host -> V[j] */
+/* rows j0 .. j0 + count - 1 in one strided copy; rows_local: count rows of rows_local doubles, ld doubles apart (the (n, M) array
+ * the static Lanczos.reorthogonalize(V, j) is handed, Lanczos.py:233) */
+int lz_basis_set_rows(lz_handle h, int j0, int count, const double* rows_local, int64_t ld);
 int lz_basis_get_row(lz_handle h, int j, double* row_local);       /* V[j] -> host */
 int lz_r_set(lz_handle h, const double* r_local);
 int lz_r_get(lz_handle h, double* r_local);

@@ -132,6 +132,7 @@ SIGNATURES = {
     "lz_last_host_syncs": (C.c_int, [_P, _I64]),
     "lz_basis_alloc": (C.c_int, [_P, C.c_int]),
     "lz_basis_set_row": (C.c_int, [_P, C.c_int, _D]),
+    "lz_basis_set_rows": (C.c_int, [_P, C.c_int, C.c_int, _D, C.c_int64]),
     "lz_basis_get_row": (C.c_int, [_P, C.c_int, _D]),
     "lz_r_set": (C.c_int, [_P, _D]),
     "lz_r_get": (C.c_int, [_P, _D]),
@@ -623,6 +624,12 @@ class Handle:
         row = f64(row)
         assert row.shape == (self.rows,)
         self.check(self.lib.lz_basis_set_row(self._h, int(j), dptr(row)))
+
+    def basis_set_rows(self, j0, rows):
+        """rows j0 .. j0 + len(rows) - 1 of the basis from a C-ordered (count, rows_local) array, in one strided copy"""
+        rows = f64(rows)
+        assert rows.ndim == 2 and rows.shape[1] == self.rows
+        self.check(self.lib.lz_basis_set_rows(self._h, int(j0), int(rows.shape[0]), dptr(rows), int(rows.shape[1])))
 
     def basis_get_row(self, j):
         out = np.empty(self.rows)

@@ -650,8 +650,7 @@ class LanczosBase:
             eye_ptr = np.arange(M + 1, dtype=np.int32)
             h.set_csr(M, 0, eye_ptr, eye_ptr[:-1], np.ones(M))  # length carrier only; no matvec is run
             h.basis_alloc(n)
-            for i in range(n):
-                h.basis_set_row(i, V[i])
+            h.basis_set_rows(0, V)  # one strided copy (row by row until round 5: n synchronous copies per call)
             h.step_reorth(j, n, scale=False)
             V[j] = h.basis_get_row(j)
         finally:

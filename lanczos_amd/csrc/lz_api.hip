@@ -676,6 +676,19 @@ int lz_basis_set_row(lz_handle h, int j, const double* row_local) {
   return LZ_OK;
 }
 
+int lz_basis_set_rows(lz_handle h, int j0, int count, const double* rows_local, int64_t ld) {
+  if (!h || !rows_local) return LZ_ERR_ARG;
+  if (count < 1 || ld < h->rows) return fail(h, LZ_ERR_ARG, "lz_basis_set_rows: need count >= 1 and ld >= rows_local");
+  LZ_TRY(require_basis(h, j0));
+  LZ_TRY(require_basis(h, j0 + count - 1));
+  LZ_HIP(h, hipSetDevice(h->dev));
+  // one strided copy for all rows (the static Lanczos.reorthogonalize(V, j) used to upload V row by row: n synchronous copies)
+  LZ_TRY(upload2d(h, h->d_V + (int64_t)j0 * h->ldv, (size_t)h->ldv * sizeof(double), rows_local, (size_t)ld * sizeof(double), (size_t)h->rows * sizeof(double),
+                  (size_t)count));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
 int lz_basis_get_row(lz_handle h, int j, double* row_local) {
   if (!h || !row_local) return LZ_ERR_ARG;
   LZ_TRY(require_basis(h, j));

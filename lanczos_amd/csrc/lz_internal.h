@@ -174,7 +174,8 @@ inline size_t omega_state_doubles(int n) { return (size_t)2 + (n + 2) + 3 * (siz
 inline size_t omega_state_ints(int n) { return (size_t)2 + n + 1; }
 // Prepares the decision for step jn (called after step jn - 1 has left alpha[jn-1] and ||r||^2; jn == 0: after the warm-up).
 // part != nullptr: first nrm2[0] = sum(part[0..np)) in k_final_sum's order (single rank: one launch for both).
-void launch_omega(const double* part, int np, double* nrm2, const double* alpha, int jn, int n, double* st, int* ist, hipStream_t s);
+void launch_omega(const double* part, int np, double* nrm2, const double* alpha, int jn, int n, double* st, int* ist, hipStream_t s,
+                  double* c_clear = nullptr);  // c_clear: jn + 1 coefficients zeroed when step jn does not sweep (partitioned runs)
 // The post-reduce kernel of the one-reduce partial loop (k_partial_onered_post, lz_reorth.hip): finishes the all-reduced buffer,
 // advances the omega-recurrence, takes the look-ahead sweep decision of step j + 1, clears the next step's buffer.  j < 0: initialises
 // the gates (ist: omega_onered_ints(n) ints).

@@ -577,7 +577,7 @@ int run_loop_partial_device(lz_handle h, int n) {
     LZ_TRY(check_launch(h, "final_sum(nrm2)"));
     LZ_TRY(comm_allreduce(h, h->d_nrm2, 1));
     if (decide) {
-      launch_omega(nullptr, 0, h->d_nrm2, h->d_alpha, jn, n, h->d_om, h->d_omi, h->stream);
+      launch_omega(nullptr, 0, h->d_nrm2, h->d_alpha, jn, n, h->d_om, h->d_omi, h->stream, h->d_c);  // (d_c: zero unless step jn sweeps - it is all-reduced every step)
       LZ_TRY(check_launch(h, "omega"));
     }
     return LZ_OK;

@@ -65,9 +65,12 @@ __global__ __launch_bounds__(kFinalThreads) void k_final_sum(const double* __res
 // -ffp-contract=off, IEEE sqrt and division), every k is independent and the maximum does not depend on the order, so the
 // decisions - and with them every coefficient - are bit-identical to the host-decided run (tests/test_gpu_lanczos.py).
 // State layout: see omega_state_doubles (lz_internal.h).
+// c_clear (row-block partition): the coefficient buffer the host all-reduces EVERY step (it cannot skip a collective the device may
+// need) is zeroed when the coming step does not sweep - stale coefficients would otherwise be summed over the ranks again and again
+// (x world per step: inf after a few hundred steps; never read, but a trap for any later consumer - ADVICE r4).
 __global__ __launch_bounds__(kFinalThreads) void k_omega(const double* __restrict__ part, int np, double* __restrict__ nrm2,
                                                         const double* __restrict__ alpha, int jn, int n, double* __restrict__ st,
-                                                        int* __restrict__ ist) {
+                                                        int* __restrict__ ist, double* __restrict__ c_clear) {
   __shared__ double sm[kFinalThreads / 64];
   __shared__ double s_nrm2;
   __shared__ int s_sweep;
@@ -154,9 +157,11 @@ __global__ __launch_bounds__(kFinalThreads) void k_omega(const double* __restric
   __syncthreads();
   if (s_sweep)
     for (int k = threadIdx.x; k < jn; k += kFinalThreads) nw[k] = eps;
+  else if (c_clear)
+    for (int k = threadIdx.x; k <= jn; k += kFinalThreads) c_clear[k] = 0.0;
 }
-void launch_omega(const double* part, int np, double* nrm2, const double* alpha, int jn, int n, double* st, int* ist, hipStream_t s) {
-  hipLaunchKernelGGL(k_omega, dim3(1), dim3(kFinalThreads), 0, s, part, np, nrm2, alpha, jn, n, st, ist);
+void launch_omega(const double* part, int np, double* nrm2, const double* alpha, int jn, int n, double* st, int* ist, hipStream_t s, double* c_clear) {
+  hipLaunchKernelGGL(k_omega, dim3(1), dim3(kFinalThreads), 0, s, part, np, nrm2, alpha, jn, n, st, ist, c_clear);
 }
 
 // ---- the same decision for the loop with ONE all-reduce per step (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE) --------------

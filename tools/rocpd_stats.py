@@ -19,6 +19,22 @@ for db in dbs:
             a = rows.setdefault(name, [0, 0])
             a[0] += n
             a[1] += tot
+def demangle(names):
+    """kernel symbols -> readable names (llvm-cxxfilt from the ROCm tree; the '.kd' suffix of a kernel descriptor dropped)"""
+    import shutil
+    import subprocess
+
+    tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "c++filt"
+    clean = [n[:-3] if n.endswith(".kd") else n for n in names]
+    try:
+        out = subprocess.run([tool], input="\n".join(clean), capture_output=True, text=True, check=True).stdout.split("\n")
+        return dict(zip(names, out[: len(names)]))
+    except Exception:
+        return dict(zip(names, clean))
+
+
+pretty = demangle(list(rows))
+rows = {pretty[k]: v for k, v in rows.items()}
 total = sum(v[1] for v in rows.values()) or 1
 csv = len(sys.argv) > 2 and sys.argv[2] == "csv"
 print("Name,Calls,TotalDurationNs,AverageNs,Percentage" if csv else f"{'kernel':90s} {'calls':>7s} {'avg us':>10s} {'share':>7s}")

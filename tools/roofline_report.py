@@ -8,7 +8,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-stats = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04", "headline_kernel_stats.csv")
+stats = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05", "headline_kernel_stats.csv")
 M = float(sys.argv[2]) if len(sys.argv) > 2 else 1e7
 nnz = float(sys.argv[3]) if len(sys.argv) > 3 else 5e7
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 200
