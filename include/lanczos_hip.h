@@ -316,6 +316,10 @@ int lz_get_timings(lz_handle h, lz_timings* out);
 int lz_comm_counts(lz_handle h, int64_t* allreduces, int64_t* exchanges);
 /* number of steps of the last lz_run that ran the re-orthogonalisation sweep (== n without LZ_FLAG_REORTH_PARTIAL) */
 int lz_last_sweeps(lz_handle h, int* sweeps);
+/* log[j] = 1 if step j of the last lz_run ran the sweep, j < n <= its number of steps (all 1 for the full-sweep loops; the device's own
+ * record for the device-decided partial loops, engines 7 and 8; LZ_ERR_ARG after the host-decided loop of knob 18 = 1, which keeps none).
+ * tests/ replay Simon's recurrence (and the look-ahead of engine 8) on the host from alpha / beta and hold the device to it. */
+int lz_last_sweep_log(lz_handle h, int* log, int n);
 /* LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE only (else 0): vectors of the last lz_run whose exact omega-recurrence estimate
  * exceeded sqrt(eps) although the one-step look-ahead gate had not swept them (lz_set_tuning(h, 20, kappa) sets the look-ahead's
  * safety factor, default 4). */

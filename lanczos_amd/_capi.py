@@ -127,6 +127,7 @@ SIGNATURES = {
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
     "lz_last_sweeps": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_last_sweep_misses": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "lz_last_sweep_log": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
     "lz_comm_counts": (C.c_int, [_P, _I64, _I64]),
     "lz_last_engine": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_last_host_syncs": (C.c_int, [_P, _I64]),
@@ -577,6 +578,13 @@ class Handle:
         k = C.c_int()
         self.check(self.lib.lz_last_sweeps(self._h, C.byref(k)))
         return k.value
+
+    def last_sweep_log(self, n=None):
+        """per step of the last run: True where the re-orthogonalisation sweep ran (the device's own record for the partial loops)"""
+        n = int(self.n if n is None else n)
+        buf = (C.c_int * n)()
+        self.check(self.lib.lz_last_sweep_log(self._h, buf, n))
+        return np.array(buf[:], dtype=bool)
 
     def last_sweep_misses(self):
         """one-reduce partial loop: vectors the look-ahead gate should have swept and did not (swept one step late)"""

@@ -2,6 +2,7 @@
 // points; plus the helpers every part shares (error reporting, per-launch profiling scope, collectives).  The run loops are
 // in lz_loops.hip, matrix setup in lz_matrix.hip, Ritz vectors / Gram / quality in lz_ritz.hip, the two-sided variant in
 // lz_twosided_api.hip.  See include/lanczos_hip.h for the contract and the reference call sites each entry point replaces.
+#include <atomic>
 #include <unordered_map>
 
 #include "lz_context.h"
@@ -179,6 +180,7 @@ struct BigBuf {
 };
 std::mutex g_big_mu;
 std::unordered_map<void*, BigBuf> g_big;
+std::atomic<bool> g_vmm_off{false};  // set by lz_comm_init_rccl(world > 1), see there
 constexpr size_t kBigChunk = (size_t)2 << 30;
 constexpr size_t kBigAlign = (size_t)2 << 20;
 
@@ -196,7 +198,7 @@ void big_release(void* va, BigBuf& b) {
 hipError_t big_alloc(int dev, void** out, size_t bytes) {
   *out = nullptr;
   static const bool no_vmm = getenv("LZ_NO_VMM") != nullptr;
-  if (!no_vmm && bytes >= kBigMinBytes) {
+  if (!no_vmm && !g_vmm_off.load() && bytes >= kBigMinBytes) {
     const size_t total = (bytes + kBigAlign - 1) / kBigAlign * kBigAlign;
     hipMemAllocationProp prop;
     memset(&prop, 0, sizeof prop);
@@ -247,6 +249,8 @@ hipError_t big_alloc(int dev, void** out, size_t bytes) {
   }
   return hipMalloc(out, bytes);
 }
+
+void big_vmm_disable() { g_vmm_off.store(true); }
 
 hipError_t big_free(void* p) {
   if (!p) return hipSuccess;
@@ -572,6 +576,10 @@ int lz_comm_init_rccl(lz_handle h, int world, int rank, const void* id, size_t i
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
   LZ_NCCL(h, g_rccl.CommInitRank(&h->comm, world, uid, rank));
+  // A multi-rank RCCL run hands slices of the basis to ncclSend / ncclRecv / ncclAllGather as user buffers.  RCCL with N > 1 ranks has
+  // never executed on this one-GPU pool, and neither has RCCL on reserve + map (VMM) ranges: such runs keep plain hipMalloc for their
+  // large buffers (the occasional allocator stall costs setup time, never the timed region) until a multi-GPU node has shown otherwise.
+  if (world > 1) big_vmm_disable();
   h->world = world;
   h->rank = rank;
   h->comm_kind = 1;
@@ -774,6 +782,13 @@ int lz_last_host_syncs(lz_handle h, int64_t* syncs) {
 int lz_last_sweeps(lz_handle h, int* sweeps) {
   if (!h || !sweeps) return LZ_ERR_ARG;
   *sweeps = h->last_sweeps;
+  return LZ_OK;
+}
+
+int lz_last_sweep_log(lz_handle h, int* log, int n) {
+  if (!h || !log || n < 0) return LZ_ERR_ARG;
+  if ((size_t)n > h->sweep_log.size()) return fail(h, LZ_ERR_ARG, "lz_last_sweep_log: the last lz_run had fewer steps (or none was run, or it was the host-decided loop)");
+  for (int j = 0; j < n; ++j) log[j] = h->sweep_log[(size_t)j];
   return LZ_OK;
 }
 

@@ -135,6 +135,7 @@ struct lz_context {
   hipEvent_t run_a = nullptr, run_b = nullptr;
   bool run_timed = false;
   int last_sweeps = 0;
+  std::vector<int> sweep_log;  // per step of the last lz_run: 1 = the re-orthogonalisation sweep ran (lz_last_sweep_log; device-decided loops only, else all 1)
   int last_misses = 0;  // one-reduce partial loop: vectors whose exact omega exceeded sqrt(eps) although the look-ahead gate had not swept them
   int last_engine = 0;  // which loop ran last (enum Loop)
   int r_state = 0;      // what d_r holds after the last run: 0 nothing usable, 1 the residual entering step n, 2 y = A v_{n-1} (three-term pending)
@@ -193,6 +194,7 @@ int check_launch(lz_handle h, const char* what);
 constexpr size_t kBigMinBytes = (size_t)256 << 20;
 hipError_t big_alloc(int dev, void** out, size_t bytes);
 hipError_t big_free(void* p);
+void big_vmm_disable();  // from now on big_alloc uses hipMalloc (process-wide)
 
 template <class T>
 inline int dev_free(lz_handle h, T*& p) {

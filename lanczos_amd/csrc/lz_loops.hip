@@ -939,10 +939,16 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
   }
   LZ_HIP(h, hipStreamSynchronize(h->stream));
   h->last_misses = 0;
-  if (loop == LOOP_PARTIAL_DEVICE) account_partial_device(h, n, sweep_log, &h->last_sweeps);
+  h->sweep_log.assign((size_t)n, 1);  // which steps ran the sweep (lz_last_sweep_log): all of them unless a partial loop says otherwise
+  if (loop == LOOP_SIX && (h->flags & LZ_FLAG_REORTH_PARTIAL)) h->sweep_log.clear();  // (the host-decided loop keeps no per-step record)
+  if (loop == LOOP_PARTIAL_DEVICE) {
+    account_partial_device(h, n, sweep_log, &h->last_sweeps);
+    for (int j = 0; j < n; ++j) h->sweep_log[(size_t)j] = sweep_log[(size_t)2 + j] != 0;
+  }
   if (loop == LOOP_PARTIAL_ONE_REDUCE) {
     account_partial_device(h, n, sweep_log, &h->last_sweeps, 4);
     h->last_misses = sweep_log[3];
+    for (int j = 0; j < n; ++j) h->sweep_log[(size_t)j] = sweep_log[(size_t)4 + j] != 0;
   }
   if (one_reduce && onered_bad != 0.0) {
     // cancellation guard of the one-reduce loop (k_onereduce_prepare): |r|^2 = r''.r'' - 2 alpha u.r'' + alpha^2 u.u lost too

@@ -1,0 +1,80 @@
+"""The sweep DECISIONS of the opt-in partial re-orthogonalisation loops against `oracle/partial_gates.py`, a plain-Python restatement
+of Simon's omega-recurrence as `k_omega` advances it (engine 7) and of the one-step look-ahead of `k_partial_onered_post` (engine 8: one
+all-reduce per step).  The reference has only the full sweep (Lanczos.py:233-251), so this pins the build's own device logic: the device's
+per-step record (`lz_last_sweep_log`) must equal the replay of the very coefficients the run delivered."""
+import numpy as np
+import pytest
+
+from lanczos_amd import synthetic
+from oracle import lanczos_ref as oracle
+from oracle import partial_gates as pg
+
+
+def test_replay_properties_on_the_cpu():
+    """No device: the two restatements on the oracle's own coefficients - step 0 always sweeps (the reference's one-row sweep), sweeps
+    come in Simon's pairs, the look-ahead triggers no later than the exact test and never misses, a huge safety factor sweeps (nearly)
+    everything, kappa -> 0 leaves only what the exact row forces (misses, swept one step late)."""
+    H = synthetic.laplacian_3d_7pt(10, 9, 8).to_scipy()
+    n = 60
+    a, b, _ = oracle.execute_lanczos(H, n, economy=True)
+    v0 = oracle.start_vector(H.shape[0], 99, None)
+    hb = [pg.warmup_norm(H, v0)] + list(b)
+    g = pg.simon_gates(list(a), hb)
+    gl, misses = pg.lookahead_gates(list(a), hb)
+    assert g[0] and gl[0] and len(g) == len(gl) == n and misses == 0
+    first = lambda x: next(i for i in range(1, n) if x[i])  # noqa: E731
+    assert 1 < first(gl) <= first(g) < n - 1
+    for gates in (g, gl):  # a swept vector (other than v_0) has a swept neighbour
+        for j in range(1, n):
+            if gates[j]:
+                assert gates[j - 1] or (j + 1 < n and gates[j + 1]), j
+    g_big, m_big = pg.lookahead_gates(list(a), hb, kappa=1e12)
+    assert m_big == 0 and sum(g_big) > n // 2
+    g_zero, m_zero = pg.lookahead_gates(list(a), hb, kappa=0.0)
+    assert m_zero >= 1 and sum(g_zero) >= 1 + 2 * m_zero - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("build,n", [(lambda: synthetic.laplacian_3d_7pt(20, 18, 16), 150), (lambda: synthetic.laplacian_2d_5pt(96, 80), 60),
+                                     (lambda: synthetic.random_graph_laplacian(50000, 175000, seed=3), 150),
+                                     (lambda: synthetic.laplacian_3d_7pt(14, 12, 10), 120)])
+def test_device_decisions_equal_the_replay(hip, build, n):
+    A = build()
+    H = A.to_scipy()
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    hb0 = pg.warmup_norm(H, v0)
+    for flags, replay in ((hip.FLAG_REORTH_PARTIAL, lambda a, hb: (pg.simon_gates(a, hb), 0)),
+                          (hip.FLAG_REORTH_PARTIAL | hip.FLAG_ONE_REDUCE, pg.lookahead_gates)):
+        h = hip.Handle(0)
+        h.set_options(flags)
+        h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+        a, b = h.run(n, v0)
+        log, sweeps, misses = h.last_sweep_log(), h.last_sweeps(), h.last_sweep_misses()
+        h.close()
+        gates, m = replay([float(x) for x in a], [hb0] + [float(x) for x in b])
+        assert log.sum() == sweeps and 1 <= sweeps < n
+        assert list(log) == [bool(x) for x in gates], (flags, np.nonzero(log)[0], [i for i, x in enumerate(gates) if x])
+        assert misses == m
+
+
+@pytest.mark.gpu
+def test_sweep_log_of_the_other_loops(hip):
+    """all ones after a full-sweep loop; no record (LZ_ERR_ARG) after the host-decided loop of knob 18 = 1"""
+    A = synthetic.laplacian_2d_5pt(40, 30)
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    h = hip.Handle(0)
+    h.set_options(hip.FLAG_FUSED_NORM)
+    h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    h.run(20, v0)
+    assert h.last_sweep_log().all() and h.last_sweeps() == 20
+    h.set_options(hip.FLAG_REORTH_PARTIAL)
+    h.set_tuning(hip.TUNE_PARTIAL_LOOP, 1)
+    h.run(20, v0)
+    assert h.last_engine() == "kernels"
+    with pytest.raises(hip.LanczosHipError):
+        h.last_sweep_log()
+    h.close()
