@@ -156,6 +156,9 @@ int lz_set_tuning(lz_handle h, int index, int value);
  * RCCL is always taken from the directory of that HIP runtime (LZ_RCCL_PATH overrides): see DESIGN.md section 6 and LAB_NOTEBOOK.md section 5. */
 int lz_runtime_info(char* buf, size_t buflen);
 int lz_device_synchronize(lz_handle h);
+/* free / total device memory of the handle's GPU as the runtime reports it (hipMemGetInfo): the figure the resident-versus-chunked
+ * decision of lz_ritz_vectors is taken on; tests use it to see that lz_destroy gives everything back */
+int lz_device_memory(lz_handle h, int64_t* free_bytes, int64_t* total_bytes);
 int lz_device_name(lz_handle h, char* buf, size_t buflen);
 /* vectors are padded to 256-byte multiples on the device; in halo mode the ghost
  * entries of the extended local vector start at index lz_padded_rows(rows_local). */

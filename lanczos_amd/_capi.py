@@ -94,6 +94,7 @@ SIGNATURES = {
     "lz_set_tuning": (C.c_int, [_P, C.c_int, C.c_int]),
     "lz_runtime_info": (C.c_int, [C.c_char_p, C.c_size_t]),
     "lz_device_synchronize": (C.c_int, [_P]),
+    "lz_device_memory": (C.c_int, [_P, _I64, _I64]),
     "lz_device_name": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "lz_padded_rows": (C.c_int64, [C.c_int64]),
     "lz_comm_load": (C.c_int, []),
@@ -578,6 +579,12 @@ class Handle:
         k = C.c_int()
         self.check(self.lib.lz_last_sweeps(self._h, C.byref(k)))
         return k.value
+
+    def device_memory(self):
+        """(free, total) bytes of the handle's GPU"""
+        f, t = C.c_int64(), C.c_int64()
+        self.check(self.lib.lz_device_memory(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def last_sweep_log(self, n=None):
         """per step of the last run: True where the re-orthogonalisation sweep ran (the device's own record for the partial loops)"""

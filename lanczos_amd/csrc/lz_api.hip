@@ -431,42 +431,42 @@ int lz_destroy(lz_handle h) {
   hipSetDevice(h->dev);
   hipStreamSynchronize(h->stream);
   if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
-  hipFree(h->csr.rowptr);
-  hipFree(h->csr.colidx);
-  hipFree(h->csr.vals);
-  hipFree(h->csr.rowblk);
+  big_free(h->csr.rowptr);
+  big_free(h->csr.colidx);
+  big_free(h->csr.vals);
+  big_free(h->csr.rowblk);
   pb_free(h->csr.pb);
   pb_free(h->csrT.pb);
   ell_free(h->csr);
   ell_free(h->csrT);
   big_free(h->d_dense);
   big_free(h->d_V);
-  hipFree(h->d_r);
-  hipFree(h->d_r2);
-  hipFree(h->d_alpha);
-  hipFree(h->d_beta);
-  hipFree(h->d_c);
-  hipFree(h->d_nrm2);
-  hipFree(h->d_part);
-  hipFree(h->csrT.rowptr);
-  hipFree(h->csrT.colidx);
-  hipFree(h->csrT.vals);
-  hipFree(h->csrT.rowblk);
+  big_free(h->d_r);
+  big_free(h->d_r2);
+  big_free(h->d_alpha);
+  big_free(h->d_beta);
+  big_free(h->d_c);
+  big_free(h->d_nrm2);
+  big_free(h->d_part);
+  big_free(h->csrT.rowptr);
+  big_free(h->csrT.colidx);
+  big_free(h->csrT.vals);
+  big_free(h->csrT.rowblk);
   big_free(h->d_B3);
-  hipFree(h->d_s);
-  hipFree(h->d_gamma);
-  hipFree(h->d_bi);
-  hipFree(h->d_xtmp);
+  big_free(h->d_s);
+  big_free(h->d_gamma);
+  big_free(h->d_bi);
+  big_free(h->d_xtmp);
   big_free(h->d_Y);
-  hipFree(h->d_S);
-  hipFree(h->d_rclk);
-  hipFree(h->d_gram);
-  hipFree(h->d_gclk);
-  hipFree(h->d_send_idx);
-  hipFree(h->d_sendbuf);
-  hipFree(h->d_xfull);
-  hipFree(h->d_om);
-  hipFree(h->d_omi);
+  big_free(h->d_S);
+  big_free(h->d_rclk);
+  big_free(h->d_gram);
+  big_free(h->d_gclk);
+  big_free(h->d_send_idx);
+  big_free(h->d_sendbuf);
+  big_free(h->d_xfull);
+  big_free(h->d_om);
+  big_free(h->d_omi);
   big_free(h->res_V);
   big_free(h->res_Y);
   if (h->h_pinned) hipHostFree(h->h_pinned);
@@ -536,6 +536,16 @@ int lz_device_synchronize(lz_handle h) {
   if (!h) return LZ_ERR_ARG;
   LZ_HIP(h, hipSetDevice(h->dev));
   LZ_HIP(h, hipDeviceSynchronize());
+  return LZ_OK;
+}
+
+int lz_device_memory(lz_handle h, int64_t* free_bytes, int64_t* total_bytes) {
+  if (!h || !free_bytes || !total_bytes) return LZ_ERR_ARG;
+  LZ_HIP(h, hipSetDevice(h->dev));
+  size_t f = 0, t = 0;
+  LZ_HIP(h, hipMemGetInfo(&f, &t));
+  *free_bytes = (int64_t)f;
+  *total_bytes = (int64_t)t;
   return LZ_OK;
 }
 

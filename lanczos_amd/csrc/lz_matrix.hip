@@ -262,7 +262,7 @@ int lz_build_stencil3d_block(lz_handle h, int Nx, int Ny, int Nz, int points, do
   launch_build_stencil3d(a, points, dpot, A.rowptr, A.colidx, A.vals, h->stream);
   int rc = check_launch(h, "build_stencil3d");
   hipError_t e = hipStreamSynchronize(h->stream);
-  if (dpot) hipFree(dpot);
+  if (dpot) big_free(dpot);
   if (rc != LZ_OK) return rc;
   if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_build_stencil3d_block: ") + hipGetErrorString(e));
   std::vector<int32_t> rowptr((size_t)rows_local + 1);

@@ -306,7 +306,7 @@ int lz_ritz_quality(lz_handle h, double* out) {
     if (!h->d_V || h->n < 1 || h->y_rows != h->rows) rc = fail(h, LZ_ERR_STATE, "lz_ritz_quality: the basis of the run is gone");
     if (rc == LZ_OK && (size_t)2 * n > (size_t)2 * qtw_ldp(h->n + 2) + 8) rc = fail(h, LZ_ERR_STATE, "lz_ritz_quality: coefficient buffer too small");
     if (rc != LZ_OK) {
-      hipFree(Yb);
+      big_free(Yb);
       return rc;
     }
     double* v0 = h->d_V;
@@ -338,7 +338,7 @@ int lz_ritz_quality(lz_handle h, double* out) {
     if (rc == LZ_OK) rc = comm_allreduce(h, h->d_c, 2 * n);
     if (rc == LZ_OK && e == hipSuccess) e = hipMemcpyAsync(sums.data(), h->d_c, sums.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(Yb);
+    big_free(Yb);
     if (rc != LZ_OK) return rc;
     if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
     for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];
@@ -348,7 +348,7 @@ int lz_ritz_quality(lz_handle h, double* out) {
   double* part = nullptr;
   rc = dev_alloc(h, part, (nblk + 1) * 2 * (size_t)nb);
   if (rc != LZ_OK) {
-    hipFree(Yb);
+    big_free(Yb);
     return rc;
   }
   double* dSums = part + nblk * 2 * (size_t)nb;
@@ -374,8 +374,8 @@ int lz_ritz_quality(lz_handle h, double* out) {
       sums[(size_t)n + c0 + i] = two[(size_t)nc + i];
     }
   }
-  hipFree(part);
-  hipFree(Yb);
+  big_free(part);
+  big_free(Yb);
   if (rc != LZ_OK) return rc;
   if (e != hipSuccess) return fail(h, LZ_ERR_HIP, std::string("lz_ritz_quality: ") + hipGetErrorString(e));
   for (int i = 0; i < n; ++i) out[i] = sums[i] * sums[i] / sums[n + i];

@@ -966,3 +966,38 @@ def test_large_results_come_back_through_the_staged_copy_unchanged():
     for r0 in (lo, 600_000, hi - 1000):  # small windows: plain path
         assert np.array_equal(h.ritz_fetch_rows(r0, r0 + 1000), Y[r0:r0 + 1000])
     h.close()
+
+
+def test_closing_a_handle_gives_the_device_memory_back(hip):
+    """Round 5: buffers of 256 MB and more are VMM ranges (reserve + create + map), everything else hipMalloc; `lz_destroy` must
+    release both kinds - a plain hipFree of a mapped range fails silently and would leak it.  Several handles with a 400 MB basis,
+    400 MB Ritz vectors, a 300 MB dense matrix and 320 MB work vectors are created, run and closed; the device's free memory comes
+    back to where it started."""
+    probe = hip.Handle(0)
+    free0, total = probe.device_memory()
+    rng = np.random.default_rng(0)
+    for round_ in range(3):
+        # (a) CSR problem with big basis / Ritz vectors (M = 2e6, n = 25: 400 MB each)
+        A = synthetic.laplacian_2d_5pt(2000, 1000)
+        M = A.shape[0]
+        v0 = synthetic.reference_start_vector(M)
+        v0 /= np.linalg.norm(v0)
+        h = hip.Handle(0)
+        h.set_options(hip.FLAG_FUSED_NORM)
+        h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+        a, b = h.run(25, v0)
+        S = np.linalg.eigh(np.diag(a) + np.diag(b, 1) + np.diag(b, -1))[1]
+        h.ritz_vectors(S, fetch=False)
+        h.ritz_gram()
+        used = free0 - h.device_memory()[0]
+        assert used > 700 << 20  # the big buffers really are on the device now
+        h.close()
+        # (b) a dense matrix of 300 MB
+        D = synthetic.dense_symmetric(6200, seed=round_)
+        h = hip.Handle(0)
+        h.set_dense(D)
+        h.run(10, rng.standard_normal(6200) / 80.0)
+        h.close()
+    free1, _ = probe.device_memory()
+    probe.close()
+    assert abs(free1 - free0) < 96 << 20, (free0, free1)
