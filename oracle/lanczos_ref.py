@@ -235,6 +235,101 @@ def execute_lanczos_partitioned(H, n, bounds, seed=99, v0=None, allreduce=None, 
     return alpha, beta, V
 
 
+def execute_lanczos_one_reduce(H, n, bounds, seed=99, v0=None, allreduce=None, spmv_local=None, partial=False, kappa=4.0):
+    """The build's ONE-collective-per-step loops, restated (test infrastructure; nothing in the reference to mirror beyond the
+    recurrence of Lanczos.py:104-119 they compute): LZ_FLAG_ONE_REDUCE (``partial=False``, run_loop_onereduce) and
+    LZ_FLAG_ONE_REDUCE | LZ_FLAG_REORTH_PARTIAL (``partial=True``, run_loop_partial_onereduce, lanczos_amd/csrc/lz_loops.hip).
+
+    State entering step j: r'' = A u - beta v_{j-2} with u = v_{j-1} (j = 0: r'' = A v0, u = v0) and the local partial of
+    alpha = u.(A u).  ONE all-reduce carries [p_i = V_i.r'' (i < j), r''.r'' | q_i = V_i.u, u.u, u.r'', alpha]; then
+    alpha, |r|^2 = (r''.r'' - 2 alpha u.r'') + alpha^2 u.u, w = (r'' - alpha u) / beta and - when the step sweeps - c_i = (p_i - alpha
+    q_i) / beta, c_j = |r|^2 / beta^2, V[j] = 2 w - sum_{i<=j} c_i V_i (row j being w); else V[j] = w.  With ``partial`` the sweep runs
+    only where the look-ahead gate (oracle/partial_gates.LookaheadGate: engine 8's device logic) says so, and p, q are zero otherwise.
+    Calling convention as ``execute_lanczos_partitioned``.  Returns ``(alpha, beta, V, gates, allreduce_calls)``."""
+    from . import partial_gates as pg
+
+    H = as_operator(H).tocsr()
+    M = H.shape[0]
+    if n > M:
+        raise ValueError("n cannot be larger than M!")
+    v0g = start_vector(M, seed, v0)
+    calls = [0]
+    if allreduce is not None:
+        lo, hi = bounds
+        parts = [(lo, hi)]
+        ar0 = allreduce
+
+        def allreduce(x):
+            calls[0] += 1
+            return ar0(x)
+    else:
+        parts = [(bounds[p], bounds[p + 1]) for p in range(len(bounds) - 1)]
+
+        def allreduce(x):
+            calls[0] += 1
+            return x
+
+    def gsum(partials):
+        s_ = partials[0]
+        for p_ in partials[1:]:
+            s_ = s_ + p_
+        return allreduce(np.atleast_1d(np.asarray(s_, dtype=np.float64)))
+
+    if spmv_local is None:
+        blocks = [H[lo:hi] for lo, hi in parts]
+
+        def matvec(xs):
+            x = np.concatenate(xs)
+            return [B * x for B in blocks]
+    else:
+        def matvec(xs):
+            return [spmv_local(xs[0])]
+
+    Vs = [np.zeros((n, hi - lo)) for lo, hi in parts]
+    for V, (lo, hi) in zip(Vs, parts):
+        V[0] = v0g[lo:hi]
+    alpha = np.zeros(n)
+    beta = np.zeros(n - 1)
+    gate = pg.LookaheadGate(n, kappa) if partial else None
+    rs = matvec([V[0] for V in Vs])  # r'' = A v0
+    apart = [np.dot(r, V[0]) for r, V in zip(rs, Vs)]
+    for j in range(n):
+        m, urow = j, (j - 1 if j > 0 else 0)
+        sweep = gate.gates[j] if partial else True
+        us = [V[urow].copy() for V in Vs]
+        loc = []
+        for V, r, u, ap in zip(Vs, rs, us, apart):
+            p_ = V[:m] @ r if sweep else np.zeros(m)
+            q_ = V[:m] @ u if sweep else np.zeros(m)
+            loc.append(np.concatenate([p_, [np.dot(r, r)], q_, [np.dot(u, u), np.dot(u, r), ap]]))
+        buf = gsum(loc)  # THE collective of this iteration
+        p_, rr, q_, uu, ur, a = buf[:m], buf[m], buf[m + 1:2 * m + 1], buf[2 * m + 1], buf[2 * m + 2], buf[2 * m + 3]
+        alpha[urow] = a
+        vv = (rr - 2.0 * a * ur) + a * a * uu
+        bj = np.sqrt(vv)
+        beta[j - 1] = bj
+        for V, r, u in zip(Vs, rs, us):
+            w = (r - u * a) / bj
+            if sweep:
+                c = np.concatenate([(p_ - a * q_) / bj, [vv / (bj * bj)]])
+                V[j] = w
+                V[j] = 2 * w - np.sum(c[:, None] * V[: j + 1], axis=0)
+            else:
+                V[j] = w
+        if partial:
+            gate.step(j, a, float(bj))
+        rs = matvec([V[j] for V in Vs])
+        apart = [np.dot(V[j], r) for r, V in zip(rs, Vs)]
+        if j == n - 1:
+            alpha[j] = gsum(apart)[0]  # the last alpha has no pass to ride on
+            break
+        if j > 0:
+            rs = [r - V[j - 1] * bj for r, V in zip(rs, Vs)]
+    V = Vs[0] if len(Vs) == 1 else np.concatenate(Vs, axis=1)
+    gates = list(gate.gates) if partial else [True] * n
+    return alpha, beta, V, gates, calls[0]
+
+
 # --------------------------------------------------------------------------
 # Conditioning probe.  Late Lanczos coefficients are ill-conditioned functions
 # of the start vector once Ritz values converge or the Krylov space is nearly

@@ -69,43 +69,62 @@ def simon_gates(alpha, hb):
     return gates
 
 
+class LookaheadGate:
+    """engine 8's decision, one step at a time (what `k_partial_onered_post` does right after the all-reduce of step j): feed
+    ``step(j, a, hbj)`` with a = alpha_{j-1} and hbj = the norm that forms v_j; read ``gates[j + 1]``.  ``alpha`` / ``hb`` are the
+    coefficient lists so far (the instance appends to them)."""
+
+    def __init__(self, n, kappa=4.0):
+        self.n, self.kappa = n, kappa
+        self.W = [_row(n), _row(n), _row(n)]
+        self.W[0][0] = 1.0
+        self.gates = [True] + [False] * (n - 1)
+        self.normA, self.st1, self.misses = 0.0, False, 0
+        self.alpha, self.hb = [0.0] * n, [0.0] * n
+
+    def step(self, j, a, hbj):
+        n = self.n
+        self.hb[j] = hbj
+        if j == 0:
+            return
+        self.alpha[j - 1] = a
+        g = self.gates[j]
+        self.normA = max(self.normA, abs(a) + self.hb[j - 1] + hbj)
+        nw, worst = _advance(self.W, self.alpha, self.hb, j, a, hbj, self.normA, n)
+        if g:
+            for k in range(j):
+                nw[k] = EPS
+        miss = (not g) and worst > THRESH
+        self.misses += miss
+        cur = self.W[(j + 2) % 3]
+        wp = 0.0
+        if j + 1 < n:
+            for k in range(0, j):
+                ak = a if k == j - 1 else self.alpha[k]
+                hk1 = hbj if k + 1 == j else self.hb[k + 1]
+                t = hk1 * nw[k + 1] + (ak - a) * nw[k] - hbj * cur[k]
+                if k > 0:
+                    t += self.hb[k] * nw[k - 1]
+                t += (-1.0 if t < 0 else 1.0) * 2.0 * EPS * self.normA
+                wp = max(wp, abs(t / hbj))
+        self.W[j % 3] = nw
+        due = self.kappa * wp > THRESH or miss
+        gn = due or self.st1
+        self.st1 = due and not g
+        if j + 1 < n:
+            self.gates[j + 1] = gn
+
+
 def lookahead_gates(alpha, hb, kappa=4.0):
     """-> (gates, misses): engine 8's decisions - the gate of step j + 1 is taken right after the all-reduce of step j from the exact
     row j and a PREDICTED row j + 1 (unknown alpha_j ~ alpha_{j-1}, beta_{j+1} ~ beta_j); a vector whose exact omega exceeds sqrt(eps)
     although it was not swept is a miss (and forces the next two)."""
     n = len(alpha)
-    W = [_row(n), _row(n), _row(n)]
-    W[0][0] = 1.0
-    gates = [True] + [False] * (n - 1)
-    normA, st1, misses = 0.0, False, 0
+    lg = LookaheadGate(n, kappa)
+    lg.step(0, 0.0, hb[0])
     for j in range(1, n):
-        g = gates[j]
-        a, hbj = alpha[j - 1], hb[j]
-        normA = max(normA, abs(a) + hb[j - 1] + hbj)
-        nw, worst = _advance(W, alpha, hb, j, a, hbj, normA, n)
-        if g:  # this vector is being swept
-            for k in range(j):
-                nw[k] = EPS
-        miss = (not g) and worst > THRESH
-        misses += miss
-        cur = W[(j + 2) % 3]  # omega_{j-1,:}
-        wp = 0.0
-        if j + 1 < n:
-            for k in range(0, j):  # k + 2 <= j + 1
-                ak = a if k == j - 1 else alpha[k]
-                hk1 = hbj if k + 1 == j else hb[k + 1]
-                t = hk1 * nw[k + 1] + (ak - a) * nw[k] - hbj * cur[k]
-                if k > 0:
-                    t += hb[k] * nw[k - 1]
-                t += (-1.0 if t < 0 else 1.0) * 2.0 * EPS * normA
-                wp = max(wp, abs(t / hbj))
-        W[j % 3] = nw
-        due = kappa * wp > THRESH or miss
-        gn = due or st1
-        st1 = due and not g  # Simon's pair: the vector after a newly due one is swept too
-        if j + 1 < n:
-            gates[j + 1] = gn
-    return gates, misses
+        lg.step(j, alpha[j - 1], hb[j])
+    return lg.gates, lg.misses
 
 
 def warmup_norm(H, v0):

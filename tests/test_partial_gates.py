@@ -78,3 +78,32 @@ def test_sweep_log_of_the_other_loops(hip):
     with pytest.raises(hip.LanczosHipError):
         h.last_sweep_log()
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("build,n", [(lambda: synthetic.laplacian_3d_7pt(20, 18, 16), 120), (lambda: synthetic.laplacian_2d_5pt(96, 80), 40),
+                                     (lambda: synthetic.random_graph_laplacian(6000, 20000, seed=4), 30)])
+@pytest.mark.parametrize("partial", [False, True])
+def test_one_collective_loops_against_their_restatement(hip, build, n, partial):
+    """`oracle.execute_lanczos_one_reduce` restates what the one-collective loops compute (the two-column pass, the three-sum |r|^2, the
+    subtraction order, the look-ahead gate): the device loops (engines 6 and 8) must deliver its coefficients to 1e-11 of the scale on
+    these well-conditioned runs - and, for the partial loop, the same sweep schedule."""
+    A = build()
+    H = A.to_scipy()
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    ao, bo, Vo, gates, calls = oracle.execute_lanczos_one_reduce(H, n, [0, M], v0=v0, partial=partial)
+    assert calls == n + 1
+    h = hip.Handle(0)
+    h.set_options(hip.FLAG_ONE_REDUCE | (hip.FLAG_REORTH_PARTIAL if partial else hip.FLAG_FUSED_NORM))
+    h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    a, b = h.run(n, v0)
+    assert h.last_engine() == ("partial-one-reduce" if partial else "one-reduce")
+    scale = max(np.abs(ao).max(), np.abs(bo).max())
+    assert np.abs(a - ao).max() <= 1e-11 * scale and np.abs(b - bo).max() <= 1e-11 * scale
+    V = h.get_basis()
+    assert np.abs(V[:8] - Vo[:8]).max() <= 1e-10 * np.abs(Vo[:8]).max()
+    if partial:
+        assert list(h.last_sweep_log()) == [bool(x) for x in gates] and h.last_sweep_misses() == 0
+    h.close()

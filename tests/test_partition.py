@@ -129,6 +129,14 @@ WORKER = textwrap.dedent('''
         a, b, V = oracle.execute_lanczos_partitioned(S, n, (lo, hi), allreduce=lambda v: boot.allreduce_sum(np.array(v, dtype=np.float64)), spmv_local=spmv_local)
         a1, b1, V1 = oracle.execute_lanczos(S, n, economy=True)
         out[name] = (float(np.abs(a - a1).max()), float(np.abs(b - b1).max()), float(np.abs(V[:8] - V1[:8, lo:hi]).max()), plan.mode)
+        # the ONE-collective-per-step loops (round 5: LZ_FLAG_ONE_REDUCE, and with LZ_FLAG_REORTH_PARTIAL the look-ahead gate) on the same
+        # partition: every rank must take the same sweep decisions (they come from reduced sums) and issue n + 1 all-reduces
+        for partial in (False, True):
+            ao, bo, Vo, gates, calls = oracle.execute_lanczos_one_reduce(S, n, (lo, hi), allreduce=lambda v: boot.allreduce_sum(np.array(v, dtype=np.float64)),
+                                                                         spmv_local=spmv_local, partial=partial)
+            a2, b2, V2, g2, c2 = oracle.execute_lanczos_one_reduce(S, n, [0, M], partial=partial)  # the same loop on one rank
+            out[name + ("_partial_onereduce" if partial else "_onereduce")] = (
+                float(np.abs(ao - a1).max()), float(np.abs(bo - b1).max()), float(np.abs(ao - a2).max()), [int(x) for x in gates], [int(x) for x in g2], calls, n)
     res = boot.allgather_obj(out)
     if rank == 0:
         import json
@@ -156,6 +164,12 @@ def test_two_rank_gloo_partitioned_lanczos(tmp_path):
         for name in ("lap2d", "graph"):
             da, db, dv, _ = per_rank[name]
             assert da < 1e-11 and db < 1e-11 and dv < 1e-9, (name, per_rank[name])
+            for suffix in ("_onereduce", "_partial_onereduce"):
+                da, db, d1, gates, gates1, calls, n = per_rank[name + suffix]
+                assert da < 1e-11 and db < 1e-11 and d1 < 1e-11, (name + suffix, da, db, d1)
+                assert calls == n + 1  # ONE all-reduce per step + the last alpha
+                assert gates == gates1 == res[0][name + suffix][3]  # the same decisions on every rank, and as on one rank
+                assert gates[0] == 1 and (sum(gates) == n if suffix == "_onereduce" else sum(gates) < n)
 
 
 def _sock_worker(rank, world, key, q):
