@@ -7,7 +7,8 @@ tell.  One rank's share (`lap2d_5pt_M1.25e6_k200`: 4000 x 3
 (b) - (a) is what the calls cost in launch + kernel + stream-order overhead with ZERO link latency: a lower bound of the real
 per-iteration communication cost.  The projection to 8 GPUs adds an assumed per-collective xGMI latency on top and is labelled as
 such; nothing here measures a second device.
-usage: python tools/collective_budget.py [out.json]"""
+usage: python tools/collective_budget.py [out.json] [c4]      (c4: one rank's slab of BASELINE config C4 instead - 500 x 500 x 50 of the
+500 x 500 x 400 7-point grid, M = 1.25e7 per rank, two faces of 250 000 doubles = 2 MB each, k = 200)"""
 import json
 import os
 import sys
@@ -17,8 +18,14 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lanczos_amd import _capi, synthetic  # noqa: E402
 
-nx, ny, n = 4000, 313, 200
-A = synthetic.laplacian_2d_5pt(nx, ny)
+C4 = len(sys.argv) > 2 and sys.argv[2] == "c4"
+if C4:
+    gx, gy, gz, n = 500, 500, 50, 200
+    A = synthetic.laplacian_3d_7pt(gx, gy, gz)
+    nx = gx * gy  # a face = one xy plane
+else:
+    nx, ny, n = 4000, 313, 200
+    A = synthetic.laplacian_2d_5pt(nx, ny)
 M = A.shape[0]
 v0 = np.random.RandomState(99).uniform(-1, 1, M)
 v0 /= np.linalg.norm(v0)
@@ -31,7 +38,8 @@ col[wrap] = rows_pad + np.searchsorted(ghost_cols, A.colidx[wrap])
 
 F, P, O, V = _capi.FLAG_FUSED_NORM, _capi.FLAG_REORTH_PARTIAL, _capi.FLAG_ONE_REDUCE, _capi.FLAG_OVERLAP_HALO
 LOOPS = [("full_default", F), ("full_one_reduce", F | O), ("full_overlap_halo", F | V), ("partial_device", P), ("partial_one_reduce", P | O)]
-out = {"workload": "lap2d_5pt_M1.25e6_k200 (one rank's share of the headline at N = 8)", "M": M, "k": n, "face_doubles": nx, "loops": {}}
+out = {"workload": ("lap3d_7pt 500x500x50 slab, k200 (one rank's share of BASELINE C4 at N = 8)" if C4 else "lap2d_5pt_M1.25e6_k200 (one rank's share of the headline at N = 8)"),
+       "M": M, "k": n, "face_doubles": nx, "loops": {}}
 for name, flags in LOOPS:
     rec = {}
     for comm in (False, True):
@@ -50,7 +58,7 @@ for name, flags in LOOPS:
         h.run(20, v0)
         h.timings()
         runs = []
-        for _ in range(7):
+        for _ in range(3 if C4 else 7):
             a, b = h.run(n, v0)
             t = h.timings()
             runs.append(t["total_ms"])
