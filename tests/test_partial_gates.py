@@ -107,3 +107,23 @@ def test_one_collective_loops_against_their_restatement(hip, build, n, partial):
     if partial:
         assert list(h.last_sweep_log()) == [bool(x) for x in gates] and h.last_sweep_misses() == 0
     h.close()
+
+
+@pytest.mark.gpu
+def test_one_collective_partial_loop_on_awkward_shapes():
+    """`tools/partial_onered_stress.py`: engine 8 on 24 random shapes (stencils whose row count is no multiple of any block size, ragged
+    CSR, dense, n = 2 .. 80, some with a nearly exhausted Krylov space) - finite coefficients, the loop itself or its guarded repeat, no
+    look-ahead miss, the device's sweep log equal to the host replay, a semi-orthogonal basis."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "partial_onered_stress.py"), "7", "24"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    rows = [l for l in p.stdout.splitlines() if " engine=" in l]
+    assert len(rows) == 24 and "failures: 0" in p.stdout
+    for l in rows:
+        assert "misses=0" in l and "replay=False" not in l, l
+        assert float(re.search(r"orth=([0-9.e+-]+)", l).group(1)) < 1e-6, l
