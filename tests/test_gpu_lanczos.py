@@ -370,7 +370,20 @@ def test_headline_full_size_properties():
     assert np.abs(np.diag(p.H_eff, 1) - gold["beta"])[st_b].max() <= 1e-10 * 8
     assert np.abs(p.H_eigvals - theta).max() <= 1e-10 * 8
     assert np.abs(hp.ritz_gram() - np.eye(n)).max() < 1e-7
-    for obj in (s, s2, p):
+    s2.close()
+    # ... and the same with ONE all-reduce per step (round 5, engine 8: look-ahead sweep decision; on one GPU the collective is a no-op,
+    # the arithmetic - two-column dots, three-sum |r|^2 - is the partitioned run's): all 200 coefficients against the reference's own
+    # full-size run at the north-star bar, no look-ahead miss, no host synchronisation
+    q = Lanczos(H)
+    q.reorth = "partial"
+    q.options = _capi.FLAG_ONE_REDUCE
+    q.execute_Lanczos(n)
+    hq = q._get_handle()
+    assert hq.last_engine() == "partial-one-reduce" and hq.last_host_syncs() == 0 and hq.last_sweep_misses() == 0 and q.sweeps == 1
+    assert np.abs(np.diag(q.H_eff) - gold["alpha"])[st_a].max() <= 1e-10 * 8
+    assert np.abs(np.diag(q.H_eff, 1) - gold["beta"])[st_b].max() <= 1e-10 * 8
+    assert np.abs(q.H_eigvals - theta).max() <= 1e-10 * 8
+    for obj in (s, p, q):
         obj.close()
 
 
