@@ -1,6 +1,6 @@
 """Randomised run of the one-collective partial loop (engine 8) over awkward shapes - stencils whose row count is no multiple of any
 block size, ragged CSR, dense, n from 2 to 80 - against the full sweep: engine, look-ahead misses, sweep log vs the host replay
-(oracle/partial_gates.py), coefficient and Ritz-value differences.   python tools/partial_onered_stress.py SEED TRIALS"""
+(oracle/partial_gates.py), coefficient and Ritz-value differences.   python tests/stress_partial_onered.py SEED TRIALS"""
 import os
 import sys
 
@@ -9,7 +9,7 @@ import scipy.sparse
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lanczos_amd import _capi, synthetic  # noqa: E402
-from oracle import partial_gates as pg  # noqa: E402  (a tool, not the product: the oracle is the checker here)
+from oracle import partial_gates as pg  # noqa: E402  (test infrastructure: the oracle is the checker here)
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 24

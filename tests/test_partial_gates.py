@@ -111,7 +111,7 @@ def test_one_collective_loops_against_their_restatement(hip, build, n, partial):
 
 @pytest.mark.gpu
 def test_one_collective_partial_loop_on_awkward_shapes():
-    """`tools/partial_onered_stress.py`: engine 8 on 24 random shapes (stencils whose row count is no multiple of any block size, ragged
+    """`tests/stress_partial_onered.py`: engine 8 on 24 random shapes (stencils whose row count is no multiple of any block size, ragged
     CSR, dense, n = 2 .. 80, some with a nearly exhausted Krylov space) - finite coefficients, the loop itself or its guarded repeat, no
     look-ahead miss, the device's sweep log equal to the host replay, a semi-orthogonal basis."""
     import os
@@ -120,7 +120,7 @@ def test_one_collective_partial_loop_on_awkward_shapes():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "partial_onered_stress.py"), "7", "24"], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "stress_partial_onered.py"), "7", "24"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     rows = [l for l in p.stdout.splitlines() if " engine=" in l]
     assert len(rows) == 24 and "failures: 0" in p.stdout
