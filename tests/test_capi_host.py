@@ -64,6 +64,16 @@ def test_product_never_imports_the_oracle_or_torch():
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
             if fn != "distributed.py":
                 assert "import torch" not in src, fn
+    # ... and nothing outside tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg touches oracle/ at all (tools/, examples/)
+    for sub in ("tools", os.path.join("tools", "runs"), "examples"):
+        d = os.path.join(ROOT, sub)
+        for fn in os.listdir(d):
+            if fn.endswith((".py", ".sh")):
+                src = open(os.path.join(d, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) and "oracle/" not in src.replace("oracle/gen_golden", ""), (sub, fn)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    hits = [m.start() for m in re.finditer(r"^\s*(?:from|import)\s+oracle\b", bench, flags=re.M)]
+    assert len(hits) == 1 and bench[: hits[0]].rsplit("\ndef ", 1)[1].startswith("cpu_baseline(")
 
 
 def test_call_surface_matches_reference():
