@@ -167,7 +167,7 @@ Scope::~Scope() {
 // ---- large device buffers (the Krylov basis, the Ritz vectors): virtual range + physical chunks -------------------------------
 // hipMalloc of the headline's 16 GB basis is what the first execute_Lanczos of an object used to wait for: 0.2 ms most of the
 // time, but 0.1 - 4.3 s every few calls on this pool (tools/probes/alloc_pattern_probe.hip, profiles/r05/alloc_pattern_probe.jsonl:
-// 3 of 17 hipMallocs of 16 GB stalled for 1 - 4 s, none of 8 reserve + create + map sequences took more than 0.5 ms, first and
+// 4 of 18 hipMallocs of 16 GB stalled for 1 - 4 s, none of 11 reserve + create + map sequences took more than 3 ms, first and
 // second touch of the mapped range at the same rate as hipMalloc'ed memory).  So buffers of 256 MB and more are a reserved virtual
 // range backed by 2 GB physical chunks (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess); kernels see one
 // contiguous pointer.  Any failure on that path falls back to hipMalloc (LZ_NO_VMM=1 forces that).  A registry maps the base
