@@ -269,6 +269,14 @@ int lz_run(lz_handle h, int n, const double* v0_local, double* alpha_out, double
  * structure produces the same bits), so alpha_out[n], beta_out[n-1] and the basis equal those of an uninterrupted
  * lz_run(h, n, ...) BIT FOR BIT (same options).  Not with LZ_FLAG_REORTH_PARTIAL / LZ_FLAG_ONE_REDUCE (LZ_ERR_STATE). */
 int lz_get_residual(lz_handle h, double* r_local);
+/* The same for LZ_FLAG_REORTH_PARTIAL's device-decided loop (engine 7; round 5): its checkpoint also carries the omega-recurrence
+ * state - lz_get_omega_state after a run of j0 steps: 2 + (j0 + 2) + 3 (j0 + 1) doubles [||A|| estimate, "sweep the next vector too",
+ * the norms hb[k] that formed V[k], three rows of omega] - and lz_run_resume_partial continues from it (j0 >= 2): the decision of step j0
+ * is taken from the refreshed ||r||^2 exactly as the uninterrupted run took it, so coefficients, basis and sweep schedule of the
+ * continued run equal an uninterrupted n-step run bit for bit.  lz_last_sweeps / lz_last_sweep_log then cover the steps j0 .. n-1. */
+int lz_get_omega_state(lz_handle h, double* out, int64_t count);
+int lz_run_resume_partial(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_in, const double* r_local, const double* alpha_in,
+                          const double* beta_in, const double* omega_state, double* alpha_out, double* beta_out);
 int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_in, const double* r_local, const double* alpha_in,
                   const double* beta_in, double* alpha_out, double* beta_out);
 /* Krylov basis, row-major (n, rows_local): basis vector j is row j

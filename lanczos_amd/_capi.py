@@ -128,6 +128,8 @@ SIGNATURES = {
     "lz_get_timings": (C.c_int, [_P, C.POINTER(LzTimings)]),
     "lz_last_sweeps": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "lz_last_sweep_misses": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "lz_get_omega_state": (C.c_int, [_P, _D, C.c_int64]),
+    "lz_run_resume_partial": (C.c_int, [_P, C.c_int, C.c_int, _D, C.c_int64, _D, _D, _D, _D, _D, _D]),
     "lz_last_sweep_log": (C.c_int, [_P, C.POINTER(C.c_int), C.c_int]),
     "lz_comm_counts": (C.c_int, [_P, _I64, _I64]),
     "lz_last_engine": (C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -504,8 +506,16 @@ class Handle:
         self.check(self.lib.lz_get_residual(self._h, dptr(r)))
         return r
 
-    def run_resume(self, n, V_rows, r, alpha, beta):
-        """continue a run of j0 = len(V_rows) completed steps to n steps in total; returns the full alpha (n), beta (n - 1)"""
+    def get_omega_state(self):
+        """the omega-recurrence state the device-decided partial loop (engine 7) left behind: part of its checkpoint"""
+        n = int(self.n)
+        out = np.empty(2 + (n + 2) + 3 * (n + 1))
+        self.check(self.lib.lz_get_omega_state(self._h, dptr(out), out.size))
+        return out
+
+    def run_resume(self, n, V_rows, r, alpha, beta, omega_state=None):
+        """continue a run of j0 = len(V_rows) completed steps to n steps in total; returns the full alpha (n), beta (n - 1).
+        ``omega_state`` (from ``get_omega_state`` of the j0-step run): continue the device-decided partial loop."""
         V_rows, r, alpha, beta = f64(V_rows), f64(r), f64(alpha), f64(beta)
         j0 = V_rows.shape[0]
         if V_rows.shape != (j0, self.rows) or r.shape != (self.rows,) or alpha.shape != (j0,) or beta.shape != (max(j0 - 1, 0),):
@@ -513,7 +523,14 @@ class Handle:
         a_out, b_out = np.zeros(n), np.zeros(max(n - 1, 1))
         if beta.size == 0:
             beta = np.zeros(1)
-        st = self.lib.lz_run_resume(self._h, int(n), int(j0), dptr(V_rows), self.rows, dptr(r), dptr(alpha), dptr(beta), dptr(a_out), dptr(b_out))
+        if omega_state is not None:
+            om = f64(omega_state)
+            if om.shape != (2 + (j0 + 2) + 3 * (j0 + 1),):
+                raise ValueError("omega_state does not belong to a run of %d steps" % j0)
+            st = self.lib.lz_run_resume_partial(self._h, int(n), int(j0), dptr(V_rows), self.rows, dptr(r), dptr(alpha), dptr(beta), dptr(om), dptr(a_out),
+                                                dptr(b_out))
+        else:
+            st = self.lib.lz_run_resume(self._h, int(n), int(j0), dptr(V_rows), self.rows, dptr(r), dptr(alpha), dptr(beta), dptr(a_out), dptr(b_out))
         self.breakdown = st == LZ_WARN_BREAKDOWN
         if not self.breakdown:
             self.check(st)

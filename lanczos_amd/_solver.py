@@ -473,15 +473,20 @@ class LanczosBase:
     # ------------------------------------------------------------------ checkpoint / resume (extension; SURVEY.md section 5 hook)
     def checkpoint(self):
         """The state a finished run of n steps leaves behind - enough to continue it later with ``resume_Lanczos``:
-        ``{"alpha" (n), "beta" (n - 1), "V" (n, M) row-major, "r" (M), "M", "fused_norm"}``.  With ``devices`` the ranks write
-        their rows into one host array, so a checkpoint does not depend on the partition that made it."""
+        ``{"alpha" (n), "beta" (n - 1), "V" (n, M) row-major, "r" (M), "M", "fused_norm"}`` (+ ``"omega_state"`` after a
+        ``reorth="partial"`` run on one device).  With ``devices`` the ranks write their rows into one host array, so a checkpoint does
+        not depend on the partition that made it."""
         if not self.Lanczos_has_been_executed:
             raise ValueError(_NOT_EXECUTED)
         h = self._device()
-        return {"alpha": self._alpha.copy(), "beta": self._beta.copy(), "V": np.array(h.get_basis()), "r": h.get_residual(), "M": self.M,
-                "fused_norm": bool(self.fused_norm), "options": int(self.options), "reorth": str(self.reorth),
-                # what the run was made WITH: resume refuses a different operator of the same size (hash of its canonical CSR form)
-                "matrix_key": _canonical_key(self.H)}
+        ck = {"alpha": self._alpha.copy(), "beta": self._beta.copy(), "V": np.array(h.get_basis()), "r": h.get_residual(), "M": self.M,
+              "fused_norm": bool(self.fused_norm), "options": int(self.options), "reorth": str(self.reorth),
+              # what the run was made WITH: resume refuses a different operator of the same size (hash of its canonical CSR form)
+              "matrix_key": _canonical_key(self.H)}
+        if self.reorth == "partial" and h.last_engine() == "partial-device" and hasattr(h, "get_omega_state"):
+            # the omega-recurrence of the device-decided selective loop: with it the continued run takes the same sweep decisions
+            ck["omega_state"] = h.get_omega_state()
+        return ck
 
     def save_checkpoint(self, path):
         np.savez(path, **self.checkpoint())
@@ -498,17 +503,25 @@ class LanczosBase:
             raise ValueError("n cannot be larger than M!")
         if n <= j0:
             raise ValueError("resume_Lanczos: n must exceed the %d steps already in the checkpoint" % j0)
-        if self.reorth != "full":
-            raise NotImplementedError("resume needs reorth='full' (the partial mode's omega-recurrence state is not part of the checkpoint)")
-        if "reorth" in ck and str(ck["reorth"]) != "full":
-            raise ValueError("the checkpoint was written by a reorth='%s' run" % str(ck["reorth"]))
+        if self.reorth not in ("full", "partial"):
+            raise NotImplementedError("resume needs reorth='full' or 'partial'")
+        if "reorth" in ck and str(ck["reorth"]) != self.reorth:
+            raise ValueError("the checkpoint was written by a reorth='%s' run, this object has reorth='%s'" % (str(ck["reorth"]), self.reorth))
+        omega_state = None
+        if self.reorth == "partial":
+            if "omega_state" not in ck:
+                raise NotImplementedError("this checkpoint of a reorth='partial' run carries no omega-recurrence state (written by the "
+                                          "one-reduce arm, on several devices, or before round 5): it cannot be continued")
+            if self.devices is not None and len(self.devices) > 1:
+                raise NotImplementedError("resume of a reorth='partial' run: one device only")
+            omega_state = ck["omega_state"]
         if "options" in ck and int(ck["options"]) & ~_capi.FLAG_PROFILE != int(self.options) & ~_capi.FLAG_PROFILE:
             raise ValueError("the checkpoint was written with options=%d, this object has options=%d" % (int(ck["options"]), int(self.options)))
         self._say("+++ Executing Lanczos algorithm")
         self.n = n
         fused = bool(ck["fused_norm"])  # the norm order of the run being continued (this object's own setting is left alone)
         h = self._get_handle()
-        h.set_options(self.options | (_capi.FLAG_FUSED_NORM if fused else 0))
+        h.set_options(self.options | (_capi.FLAG_REORTH_PARTIAL if self.reorth == "partial" else 0) | (_capi.FLAG_FUSED_NORM if fused else 0))
         self._upload_matrix(h)
         stored = str(ck["matrix_key"]) if "matrix_key" in ck else ""
         if stored.startswith(("csr-blake2b:", "stencil:")):
@@ -522,7 +535,10 @@ class LanczosBase:
 
             warnings.warn("the checkpoint's matrix key is in the pre-round-5 format and does not match this object's H as held now; "
                           "resuming on the caller's word that it is the same operator", RuntimeWarning, stacklevel=2)
-        alpha, beta = h.run_resume(n, ck["V"], ck["r"], ck["alpha"], ck["beta"])
+        if omega_state is not None:
+            alpha, beta = h.run_resume(n, ck["V"], ck["r"], ck["alpha"], ck["beta"], omega_state=omega_state)
+        else:
+            alpha, beta = h.run_resume(n, ck["V"], ck["r"], ck["alpha"], ck["beta"])
         if h.breakdown:
             import warnings
 

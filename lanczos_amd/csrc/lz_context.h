@@ -144,6 +144,7 @@ struct lz_context {
   double* d_om = nullptr;      // device-resident partial re-orthogonalisation: omega-recurrence state (omega_state_doubles)
   int* d_omi = nullptr;        //   ... gate of the coming step, sweep count, per-step sweep log (omega_state_ints)
   int om_n = 0;
+  int om_run_n = 0;            // n of the last device-decided partial run: the layout of d_om (lz_get_omega_state)
   int64_t host_syncs = 0;      // host <-> device synchronisations between the first and the last launch of the last lz_run
   // lz_reserve (may be called from a second host thread while this one prepares the matrix): device buffers for the basis and
   // the Ritz vectors of the coming run, adopted by basis_alloc / lz_ritz_vectors.  Only these fields are touched by it.

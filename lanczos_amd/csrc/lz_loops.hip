@@ -541,12 +541,32 @@ int run_loop_six(lz_handle h, int n, int* sweeps_out, int j0 = 0) {
 // v_j = r / beta itself wherever it reads x (k_spmv_ell<.., SC>: the separate 16M-byte scale pass is gone; r and y
 // ping-pong between two buffers), and the three-term kernel.  Other matrices keep the (gated) scale kernel.
 // Decisions, coefficients and basis are bit-identical to the host-decided loop (tests/test_gpu_lanczos.py).
-int run_loop_partial_device(lz_handle h, int n) {
+// j0 > 0 (lz_run_resume_partial): steps 0 .. j0-1 are in the basis, r is the residual entering step j0 and `state_j0` the omega state a
+// run of j0 steps left behind (lz_get_omega_state: its layout is that of a j0-step run).
+int run_loop_partial_device(lz_handle h, int n, int j0 = 0, const double* state_j0 = nullptr) {
   const double M = (double)h->rows;
   if (h->om_n < n) {
     LZ_TRY(dev_alloc(h, h->d_om, omega_state_doubles(n)));
     LZ_TRY(dev_alloc(h, h->d_omi, omega_state_ints(n) + 1));  // (+ the ticket of pass 1's folded second stage)
     h->om_n = n;
+  }
+  h->om_run_n = n;
+  if (j0 > 0) {
+    // the state of the j0-step run, re-laid for n steps: [normA, force | hb[0 .. n + 2) | three rows of n + 1]; entries past j0 are zero,
+    // exactly what an uninterrupted n-step run holds there at this point
+    std::vector<double> st(omega_state_doubles(n), 0.0);
+    st[0] = state_j0[0];
+    st[1] = state_j0[1];
+    const double* hb_s = state_j0 + 2;
+    const double* W_s = hb_s + (j0 + 2);
+    double* hb_d = st.data() + 2;
+    double* W_d = hb_d + (n + 2);
+    for (int k = 0; k < j0 + 2; ++k) hb_d[k] = hb_s[k];
+    for (int r = 0; r < 3; ++r)
+      for (int k = 0; k <= j0; ++k) W_d[(size_t)r * (n + 1) + k] = W_s[(size_t)r * (j0 + 1) + k];
+    LZ_HIP(h, hipMemcpyAsync(h->d_om, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LZ_HIP(h, hipMemsetAsync(h->d_omi, 0, (omega_state_ints(n) + 1) * sizeof(int), h->stream));
+    LZ_HIP(h, hipStreamSynchronize(h->stream));  // (`st` is a local)
   }
   LZ_HIP(h, hipMemsetAsync(h->d_omi + omega_state_ints(n), 0, sizeof(int), h->stream));
   const int* gate = h->d_omi;
@@ -559,7 +579,7 @@ int run_loop_partial_device(lz_handle h, int n) {
     LZ_HIP(h, ell_build(h->csr, 0, h->stream));
   const bool fuse_scale = one_rank && h->kind == 1 && ell_usable(h->csr, h->flags) && h->tune[18] != 2;
   // warm-up (Lanczos.py:108-110): r = A v0; alpha0 = r.v0; r = r - alpha0 v0; ||r||^2
-  LZ_TRY(step_spmv(h, 0));
+  if (j0 == 0) LZ_TRY(step_spmv(h, 0));
   int np = 0;
   auto three_term_and_decide = [&](int j, int jm1, const double* d_alpha, const double* d_beta, double* r, bool decide, int jn) -> int {
     {
@@ -582,11 +602,18 @@ int run_loop_partial_device(lz_handle h, int n) {
     }
     return LZ_OK;
   };
-  LZ_TRY(three_term_and_decide(0, -1, h->d_alpha, nullptr, h->d_r, true, 0));
+  if (j0 == 0) {
+    LZ_TRY(three_term_and_decide(0, -1, h->d_alpha, nullptr, h->d_r, true, 0));
+  } else {
+    // resumed: r = r - 0 * V[0] leaves r unchanged bit for bit, refreshes ||r||^2 with the very kernel (and summation) that produced it
+    // in the uninterrupted run, and k_omega takes the decision of step j0 from it
+    LZ_HIP(h, hipMemsetAsync(h->d_c + n, 0, sizeof(double), h->stream));
+    LZ_TRY(three_term_and_decide(0, -1, h->d_c + n, nullptr, h->d_r, true, j0));
+  }
   const int pstride = h->tune[7] > 1 ? h->tune[7] : 1;
   double* rcur = h->d_r;   // the residual entering the step
   double* rnext = h->d_r2; // where the fused SpMV writes y (it reads r through its gathers: not in place)
-  for (int j = 0; j < n; ++j) {
+  for (int j = j0; j < n; ++j) {
     h->prof_iter = (j % pstride) == pstride / 2;
     const int bidx = (j + n - 2) % (n - 1);
     double* vj = h->d_V + (int64_t)j * h->ldv;
@@ -996,6 +1023,57 @@ int lz_get_residual(lz_handle h, double* r_local) {
   return LZ_OK;
 }
 
+int lz_get_omega_state(lz_handle h, double* out, int64_t count) {
+  if (!h || !out) return LZ_ERR_ARG;
+  if (h->last_engine != LOOP_PARTIAL_DEVICE || !h->d_om || h->om_run_n < 2)
+    return fail(h, LZ_ERR_STATE, "lz_get_omega_state: the last run was not the device-decided partial re-orthogonalisation loop (engine 7)");
+  if (count != (int64_t)omega_state_doubles(h->om_run_n)) return fail(h, LZ_ERR_ARG, "lz_get_omega_state: count must be 2 + (n + 2) + 3 (n + 1) for the n of the last run");
+  LZ_HIP(h, hipSetDevice(h->dev));
+  LZ_HIP(h, hipMemcpyAsync(out, h->d_om, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  return LZ_OK;
+}
+
+int lz_run_resume_partial(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_in, const double* r_local, const double* alpha_in,
+                          const double* beta_in, const double* omega_state, double* alpha_out, double* beta_out) {
+  if (!h) return LZ_ERR_ARG;
+  if (!V_rows || !r_local || !alpha_in || !beta_in || !omega_state || !alpha_out || !beta_out) return fail(h, LZ_ERR_ARG, "lz_run_resume_partial: NULL buffer");
+  if (j0 < 2 || n <= j0) return fail(h, LZ_ERR_ARG, "lz_run_resume_partial: need 2 <= j0 < n (j0 completed steps, n in total)");
+  if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run_resume_partial: n cannot be larger than M");
+  if (ldv_in < h->rows) return fail(h, LZ_ERR_ARG, "lz_run_resume_partial: ldv_in < rows_local");
+  if (!(h->flags & LZ_FLAG_REORTH_PARTIAL) || (h->flags & LZ_FLAG_ONE_REDUCE))
+    return fail(h, LZ_ERR_STATE, "lz_run_resume_partial: needs LZ_FLAG_REORTH_PARTIAL without LZ_FLAG_ONE_REDUCE (the device-decided loop, engine 7)");
+  LZ_TRY(basis_alloc(h, n, j0));  // (all j0 uploaded rows cleared first: see lz_run_resume)
+  if (choose_loop(h, n) != LOOP_PARTIAL_DEVICE)
+    return fail(h, LZ_ERR_STATE, "lz_run_resume_partial: these options / knobs do not select the device-decided partial loop");
+  h->halo_inflight_j = -1;
+  h->y_n = 0;
+  LZ_TRY(upload2d(h, h->d_V, (size_t)h->ldv * sizeof(double), V_rows, (size_t)ldv_in * sizeof(double), (size_t)h->rows * sizeof(double), (size_t)j0));
+  LZ_TRY(upload(h, h->d_r, r_local, (size_t)h->rows * sizeof(double)));
+  LZ_HIP(h, hipMemcpyAsync(h->d_alpha, alpha_in, (size_t)j0 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(h->d_beta, beta_in, (size_t)(j0 - 1) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  LZ_HIP(h, hipEventRecord(h->run_a, h->stream));
+  h->host_syncs = 0;
+  h->last_engine = LOOP_PARTIAL_DEVICE;
+  LZ_TRY(run_loop_partial_device(h, n, j0, omega_state));
+  h->r_state = 1;
+  h->prof_iter = true;
+  LZ_HIP(h, hipEventRecord(h->run_b, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(alpha_out, h->d_alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipMemcpyAsync(beta_out, h->d_beta, (size_t)(n - 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  std::vector<int> sweep_log(omega_state_ints(n));
+  LZ_HIP(h, hipMemcpyAsync(sweep_log.data(), h->d_omi, sweep_log.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  LZ_HIP(h, hipStreamSynchronize(h->stream));
+  h->last_misses = 0;
+  h->sweep_log.assign((size_t)n, 0);  // (the steps of the first leg are not on this record)
+  account_partial_device(h, n, sweep_log, &h->last_sweeps);
+  for (int j = j0; j < n; ++j) h->sweep_log[(size_t)j] = sweep_log[(size_t)2 + j] != 0;
+  float ms = 0.f;
+  LZ_HIP(h, hipEventElapsedTime(&ms, h->run_a, h->run_b));
+  h->acc.total_ms += ms;
+  return breakdown_status(h, n, alpha_out, beta_out);
+}
+
 int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_in, const double* r_local, const double* alpha_in,
                   const double* beta_in, double* alpha_out, double* beta_out) {
   if (!h) return LZ_ERR_ARG;
@@ -1004,8 +1082,10 @@ int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_
   if (n > h->Mg) return fail(h, LZ_ERR_ARG, "lz_run_resume: n cannot be larger than M");
   if (ldv_in < h->rows) return fail(h, LZ_ERR_ARG, "lz_run_resume: ldv_in < rows_local");
   if (h->flags & (LZ_FLAG_REORTH_PARTIAL | LZ_FLAG_ONE_REDUCE))
-    return fail(h, LZ_ERR_STATE, "lz_run_resume: not with partial re-orthogonalisation (its omega-recurrence state is not part of a checkpoint) or the one-reduce loop");
-  LZ_TRY(basis_alloc(h, n, 1));
+    return fail(h, LZ_ERR_STATE, "lz_run_resume: not with partial re-orthogonalisation (lz_run_resume_partial continues the device-decided loop from its omega state) or the one-reduce loop");
+  // The j0 rows about to be uploaded are cleared whole: the upload writes `rows` columns of each, the kernels stream rows_pad of them,
+  // and a recycled allocation's padding would enter ||r||^2 (a run's own kernels write the padding of every row they produce: zeros).
+  LZ_TRY(basis_alloc(h, n, j0));
   h->halo_inflight_j = -1;
   h->y_n = 0;
   LZ_TRY(upload2d(h, h->d_V, (size_t)h->ldv * sizeof(double), V_rows, (size_t)ldv_in * sizeof(double), (size_t)h->rows * sizeof(double), (size_t)j0));
@@ -1017,6 +1097,8 @@ int lz_run_resume(lz_handle h, int n, int j0, const double* V_rows, int64_t ldv_
   h->last_engine = LOOP_SIX;  // every loop structure gives the same bits (tests/test_gpu_small.py): the plain one takes a start step
   LZ_TRY(run_loop_six(h, n, &sweeps, j0));
   h->last_sweeps = sweeps;
+  h->last_misses = 0;
+  h->sweep_log.assign((size_t)n, 1);
   h->r_state = 1;
   h->prof_iter = true;
   LZ_HIP(h, hipEventRecord(h->run_b, h->stream));

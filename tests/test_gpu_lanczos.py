@@ -861,6 +861,7 @@ def test_partial_one_reduce_cancellation_guard(hip):
 @pytest.mark.parametrize("build,n1,n2", [(lambda: synthetic.laplacian_2d_5pt(64, 48).to_scipy(), 10, 31),             # three-launch loop
                                          (lambda: synthetic.laplacian_3d_7pt(40, 30, 20).to_scipy(), 17, 40),         # five-launch loop
                                          (lambda: synthetic.random_graph_laplacian(50000, 175000, seed=3).to_scipy(), 2, 12),
+                                         (lambda: load_golden("box1d_N500_n50")[1], 5, 20),                           # M = 500: padded rows
                                          (lambda: synthetic.dense_symmetric(700, seed=2), 25, 26)])
 @pytest.mark.parametrize("fused", [True, False])
 def test_checkpoint_and_resume_is_bit_identical(tmp_path, build, n1, n2, fused):
@@ -882,6 +883,7 @@ def test_checkpoint_and_resume_is_bit_identical(tmp_path, build, n1, n2, fused):
     assert ck["V"].shape == (n1, H.shape[0]) and ck["r"].shape == (H.shape[0],) and len(ck["beta"]) == n1 - 1
     first.close()
     second = Lanczos(H)
+    second._get_handle().set_tuning(_capi.TUNE_POISON_BASIS, 1)  # (the uploaded rows' padding is cleared, not inherited: round 5)
     second.resume_Lanczos(n2, path)
     assert second._handle.last_engine() == "kernels"
     assert np.array_equal(second.H_eff, whole.H_eff)
@@ -924,6 +926,87 @@ def test_checkpoint_and_resume_is_bit_identical(tmp_path, build, n1, n2, fused):
     third.close()
     with pytest.raises(_capi.LanczosHipError, match="released"):
         third.checkpoint()
+    for s in (whole, second):
+        s.close()
+
+
+@pytest.mark.parametrize("build,n1,n2", [(lambda: synthetic.laplacian_3d_7pt(40, 30, 20).to_scipy(), 37, 120),       # ELL-fused r / beta; sweeps on both sides of the cut
+                                         (lambda: load_golden("deuteron3d_N12_27pt_n100")[1], 50, 100),              # 27-point rows: scale kernel + CSR stream
+                                         (lambda: load_golden("box1d_N500_n50")[1], 2, 50),                          # the shortest first leg
+                                         (lambda: synthetic.dense_symmetric(700, seed=2), 61, 90)])
+def test_checkpoint_and_resume_of_the_partial_loop_is_bit_identical(tmp_path, hip, build, n1, n2):
+    """a reorth='partial' run can be continued too.  Its checkpoint also carries the omega-recurrence state of the
+    device-decided loop (lz_get_omega_state); lz_run_resume_partial re-lays it for the longer run and takes the decision of the first
+    new step from the refreshed ||r||^2 exactly as the uninterrupted run did: coefficients, basis AND sweep schedule equal an
+    uninterrupted run's bit for bit, wherever the cut falls relative to a sweep pair."""
+    H = build()
+    Lanczos.verbose = False
+    whole = Lanczos(H)
+    whole.reorth = "partial"
+    whole.execute_Lanczos(n2)
+    hw = whole._get_handle()
+    assert hw.last_engine() == "partial-device"
+    log_whole = hw.last_sweep_log()
+    first = Lanczos(H)
+    first.reorth = "partial"
+    first.execute_Lanczos(n1)
+    assert list(first._get_handle().last_sweep_log()) == list(log_whole[:n1])
+    path = str(tmp_path / "ck.npz")
+    first.save_checkpoint(path)
+    ck = first.checkpoint()
+    assert ck["omega_state"].shape == (2 + (n1 + 2) + 3 * (n1 + 1),) and str(ck["reorth"]) == "partial"
+    first.close()
+    second = Lanczos(H)
+    second.reorth = "partial"
+    # (NaN-poisoned fresh basis: the padding of the uploaded rows must not be whatever the recycled allocation held - it enters
+    # ||r||^2 through the kernels that stream rows_pad columns; found with this test at M = 500)
+    second._get_handle().set_tuning(_capi.TUNE_POISON_BASIS, 1)
+    second.resume_Lanczos(n2, path)
+    hs = second._get_handle()
+    assert hs.last_engine() == "partial-device" and hs.last_host_syncs() == 0
+    assert np.array_equal(second.H_eff, whole.H_eff)
+    assert np.array_equal(second.V, whole.V)
+    assert list(hs.last_sweep_log()[n1:]) == list(log_whole[n1:])  # (the record of a resumed run covers its own steps)
+    assert second.sweeps == int(np.sum(log_whole[n1:]))
+    # ... and the resumed run can be checkpointed and continued again: same state as the uninterrupted run's
+    ck2, ckw = second.checkpoint(), whole.checkpoint()
+    assert np.array_equal(ck2["r"], ckw["r"]) and np.array_equal(ck2["omega_state"], ckw["omega_state"])
+    if n2 + 5 <= H.shape[0]:
+        longer = Lanczos(H)
+        longer.reorth = "partial"
+        longer.execute_Lanczos(n2 + 5)
+        third = Lanczos(H)
+        third.reorth = "partial"
+        third.resume_Lanczos(n2 + 5, ck2)
+        assert np.array_equal(third.H_eff, longer.H_eff) and np.array_equal(third.V, longer.V)
+        third.close()
+        longer.close()
+    # refusals: a full-sweep object, a checkpoint without the state, a state of the wrong length, the one-reduce arm
+    full = Lanczos(H)
+    with pytest.raises(ValueError, match="reorth='partial' run"):
+        full.resume_Lanczos(n2, ck)
+    full.close()
+    other = Lanczos(H)
+    other.reorth = "partial"
+    with pytest.raises(NotImplementedError, match="omega-recurrence state"):
+        other.resume_Lanczos(n2, {k: v for k, v in ck.items() if k != "omega_state"})
+    with pytest.raises(ValueError, match="does not belong"):
+        other.resume_Lanczos(n2, dict(ck, omega_state=ck["omega_state"][:-1]))
+    other.close()
+    onered = Lanczos(H)
+    onered.reorth = "partial"
+    onered.options = _capi.FLAG_ONE_REDUCE
+    with pytest.raises(ValueError, match="options"):
+        onered.resume_Lanczos(n2, ck)
+    onered.close()
+    # at the C boundary: the state is only there after the device-decided loop
+    hf = hip.Handle(0)
+    Hs = scipy.sparse.csr_matrix(H)
+    hf.set_csr(Hs.shape[0], 0, Hs.indptr, Hs.indices, Hs.data)
+    hf.run(5, np.ones(Hs.shape[0]) / np.sqrt(Hs.shape[0]))
+    with pytest.raises(_capi.LanczosHipError, match="engine 7"):
+        hf.get_omega_state()
+    hf.close()
     for s in (whole, second):
         s.close()
 
