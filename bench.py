@@ -456,6 +456,9 @@ def main():
                        "fused_norm_allreduce": bool(solver.options & _capi.FLAG_FUSED_NORM), "profile_stride": stride,
                        "halo_overlap": bool(solver.options & _capi.FLAG_OVERLAP_HALO),
                        "one_reduce": bool(solver.options & _capi.FLAG_ONE_REDUCE), "spmv_kernel": solver.h.spmv_plan(),
+                       # row-class coding of a stencil matrix (round 5): [kind, classes]; the SpMV then streams one byte per row (+ the values
+                       # for "offsets") instead of 12 bytes per entry - roofline_all.spmv counts the bytes of the format that ran
+                       "spmv_coding": list(solver.h.spmv_coding()) if hasattr(solver.h, "spmv_coding") else None,
                        "step": "one full k-iteration Lanczos solve"},
             "roofline": dict(per_class[dominant], kernel=dominant) if dominant else None,
             "roofline_all": per_class,

@@ -133,12 +133,16 @@ int lz_set_options(lz_handle h, int flags);
  *   17  fixed-K (stencil) SpMV layout: 0 auto (CSR-order kernel with products staged through LDS; the ELL-ordered second copy -
  *       a lane owns whole rows - is built and used only by the partial re-orthogonalisation loop's fused SpMV; 27 entries per
  *       row, which have no CSR-order fixed-K kernel: ELL for every SpMV, 3 % faster than CSR-stream), 1 never ELL,
- *       2 ELL for every SpMV, one row per lane and trip, 3 ELL, two adjacent rows per lane (16-byte loads)
+ *       2 ELL for every SpMV, one row per lane and trip, 3 ELL, two adjacent rows per lane (16-byte loads).
+ *       Round 5: auto first looks for ROW CLASSES (lz_spmv_coding) - a coded ELL copy is every SpMV's default; 2 / 3 keep the uncoded
+ *       copy (A/B), 4 codes the offsets only even where the values repeat as well (A/B)
  *   19  Gram matrix of the Ritz vectors: 0 auto (accumulator-stationary symmetric kernel, operands staged through LDS once per workgroup),
  *       1 the split-K TN GEMM always, 2 the symmetric kernel with per-wave register rings (round 4; also what an odd n runs)
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
  *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta),
  *       3 device-resident with pass 1's second-stage sums as a kernel of their own (default: pass 1's last block adds them)
+ *   23  fully row-class coded SpMV (lz_spmv_coding == 2): 0 auto (two 512-row units per workgroup, four rows in flight per lane),
+ *       1 one unit per workgroup (A/B; same bits - the alpha partials are per unit)
  *   22  irregular (two-phase) SpMV: interleave its two phases over this many groups of row blocks (A/B arm of round 5: the product
  *       stream of a group could stay in the Infinity Cache between the phases; measured 8-110 % slower - DESIGN.md section 4; kernel-bench
  *       build only; 0 / 1 = off)
@@ -228,6 +232,11 @@ int lz_csr_info(lz_handle h, int64_t* rows, int64_t* nnz);
 /* which SpMV kernel the current matrix + options select: 0 scalar CSR (LZ_FLAG_SPMV_SCALAR), 1 CSR-stream, 2 fixed-K
  * (stencils), 3 column-blocked two-phase (matrices without column locality, lz_spmv_pb.hip), 4 dense GEMV */
 int lz_spmv_plan(lz_handle h, int* plan);
+/* Row-class coding of a fixed-K (stencil) matrix (round 5): where the rows of the matrix fall into <= 256 classes up to translation -
+ * the K offsets col - row, and for constant coefficients the K values too - the SpMV streams ONE BYTE per row (the class; + 8 bytes per
+ * entry when only the offsets repeat) instead of 12 bytes per entry; found and verified on the device at lz_set_csr, same products in the
+ * same order (same bits).  coding: 0 none, 1 offsets by class (values streamed), 2 offsets and values by class; classes: how many. */
+int lz_spmv_coding(lz_handle h, int* coding, int* classes);
 /* download the handle's CSR matrix (sizes from lz_csr_info) */
 int lz_get_csr(lz_handle h, int32_t* rowptr, int32_t* colidx, double* vals);
 /* halo plan: for peer p (npeers of them) send x[send_idx[..]] (local row

@@ -48,8 +48,10 @@ TUNE_POISON_BASIS = 13      # 1 = NaN-poison a fresh basis allocation (test knob
 TUNE_SPMV_PLAN = 14         # irregular SpMV plan (0 auto, 1 never two-phase, 2 always)
 TUNE_LOOP = 15              # loop structure (0 auto, 1 six launches per step always)
 TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 forces it)
-TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto: CSR order, ELL only in the partial loop; 1 never ELL; 2 / 3 ELL always, one / two rows per lane)
+TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto: row-class coded ELL where the rows fall into classes, else CSR order and ELL only in the partial loop;
+                            # 1 never ELL; 2 / 3 uncoded ELL always, one / two rows per lane; 4 offsets-only coding)
 TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel with LDS-staged operands, 1 split-K TN GEMM, 2 the register-ring form)
+TUNE_CLS_GROUP = 23         # fully coded SpMV: 1 = one 512-row unit per workgroup (A/B; default two)
 TUNE_PB_GROUPS = 22         # two-phase SpMV: phases interleaved over this many row-block groups (A/B arm; 0 = off)
 TUNE_GRAM_SLICES = 21       # Gram matrix: K slices of the symmetric kernel (0 auto)
 TUNE_PARTIAL_LOOKAHEAD = 20 # one-reduce partial loop: safety factor of the look-ahead sweep decision (0 = default 4)
@@ -109,6 +111,7 @@ SIGNATURES = {
                                            C.c_int, _I64, _I64]),
     "lz_csr_info": (C.c_int, [_P, _I64, _I64]),
     "lz_spmv_plan": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "lz_spmv_coding": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lz_get_csr": (C.c_int, [_P, _I32, _I32, _D]),
     "lz_set_halo": (C.c_int, [_P, C.c_int, _I32, _I64, _I32, _I64]),
     "lz_set_allgather": (C.c_int, [_P, C.c_int64]),
@@ -459,6 +462,14 @@ class Handle:
         k = C.c_int()
         self.check(self.lib.lz_spmv_plan(self._h, C.byref(k)))
         return self.SPMV_PLANS[k.value]
+
+    SPMV_CODINGS = ("none", "offsets", "offsets+values")
+
+    def spmv_coding(self):
+        """row-class coding of a stencil matrix: ("none" | "offsets" | "offsets+values", number of classes)"""
+        c, k = C.c_int(), C.c_int()
+        self.check(self.lib.lz_spmv_coding(self._h, C.byref(c), C.byref(k)))
+        return self.SPMV_CODINGS[c.value], k.value
 
     def get_csr(self):
         rows, nnz = C.c_int64(), C.c_int64()

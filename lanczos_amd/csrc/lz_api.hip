@@ -3,6 +3,7 @@
 // in lz_loops.hip, matrix setup in lz_matrix.hip, Ritz vectors / Gram / quality in lz_ritz.hip, the two-sided variant in
 // lz_twosided_api.hip.  See include/lanczos_hip.h for the contract and the reference call sites each entry point replaces.
 #include <atomic>
+#include <deque>
 #include <unordered_map>
 
 #include "lz_context.h"
@@ -184,6 +185,15 @@ std::atomic<bool> g_vmm_off{false};  // set by lz_comm_init_rccl(world > 1), see
 constexpr size_t kBigChunk = (size_t)2 << 30;
 constexpr size_t kBigAlign = (size_t)2 << 20;
 
+// Freed address ranges in quarantine: reserved again (unmapped, no memory behind them) so that no new buffer lands on them.
+struct Quarantined {
+  void* va;
+  size_t bytes;
+};
+std::deque<Quarantined> g_quarantine;  // (under g_big_mu)
+size_t g_quarantine_bytes = 0;
+constexpr size_t kQuarantineBytes = (size_t)16 << 40;  // 16 TB of addresses (nothing behind them) are held back before the oldest are let go
+
 void big_release(void* va, BigBuf& b) {
   size_t off = 0;
   for (size_t k = 0; k < b.chunks.size(); ++k) {
@@ -191,7 +201,37 @@ void big_release(void* va, BigBuf& b) {
     (void)hipMemRelease(b.chunks[k]);
     off += b.sizes[k];
   }
+  // On this stack (ROCm 7.2, gfx950) the physical memory only comes back with hipMemAddressFree, and a fresh mapping that lands on
+  // just-freed addresses intermittently has holes - kernels fault on pages that belong to the NEW buffer (tools/spmv_coding_probe.py:
+  // 3 of 4 runs, the faulting page inside both the freed and the new buffer; never with LZ_NO_VMM=1; profiles/r05/
+  // vmm_address_reuse_fault.txt).  So the range is freed - the memory returns - and at once reserved again at the same address, with
+  // nothing mapped: later buffers cannot land on it.  Up to 16 TB of such addresses are held back (a thousand 16 GB bases); the oldest are let go beyond that.
   (void)hipMemAddressFree(va, b.bytes);
+  static const bool reuse_ok = getenv("LZ_VMM_ADDRESS_REUSE") != nullptr;  // (the first form of this round, to reproduce the fault)
+  if (reuse_ok) return;
+  void* q = nullptr;
+  if (hipMemAddressReserve(&q, b.bytes, kBigAlign, va, 0) == hipSuccess && q) {
+    if (q != va) {  // the hint was not honoured: this reservation protects nothing
+      (void)hipMemAddressFree(q, b.bytes);
+      if (getenv("LZ_DEBUG_VMM")) fprintf(stderr, "[vmm] quarantine of %p (%zu bytes) not honoured: got %p\n", va, b.bytes, q);
+      return;
+    }
+    std::vector<Quarantined> old;
+    {
+      std::lock_guard<std::mutex> lk(g_big_mu);
+      g_quarantine.push_back({q, b.bytes});
+      g_quarantine_bytes += b.bytes;
+      while (g_quarantine_bytes > kQuarantineBytes && g_quarantine.size() > 1) {
+        old.push_back(g_quarantine.front());
+        g_quarantine_bytes -= g_quarantine.front().bytes;
+        g_quarantine.pop_front();
+      }
+    }
+    for (const Quarantined& o : old) (void)hipMemAddressFree(o.va, o.bytes);
+  } else {
+    (void)hipGetLastError();
+    if (getenv("LZ_DEBUG_VMM")) fprintf(stderr, "[vmm] quarantine of %p (%zu bytes): reservation failed\n", va, b.bytes);
+  }
 }
 }  // namespace
 

@@ -236,7 +236,7 @@ int comm_exchange_x(lz_handle h, int j, const double** x_out);
 
 // the individual steps of the recurrence (lz_loops.hip)
 int ensure_part(lz_handle h, size_t need);
-double spmv_bytes(lz_handle h);
+double spmv_bytes(lz_handle h, bool ell = false);  // ell: the launch takes the ELL copy whatever the plain SpMV does (the partial loop's fused SpMV)
 double spmv_flops(lz_handle h);
 int step_spmv(lz_handle h, int j, double* alpha_dst = nullptr, bool reduce = true, int* np_out = nullptr);
 int step_reorth(lz_handle h, int j, int nrows, bool scale, int beta_idx, bool in_run_loop = false);

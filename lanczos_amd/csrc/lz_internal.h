@@ -67,7 +67,15 @@ struct CsrDev {
   double* ell_v = nullptr;
   int ell_rb = 0;             // rows per block of the ELL copy (0: none)
   int ell_variant = 0;        // 0: one row per lane and trip (rows t, t + 256, ...); 1: two adjacent rows per lane (16-byte loads)
-  bool ell_default = false;   // true: every SpMV takes the ELL copy (knob 17 >= 2); false: only the partial loop's fused SpMV does
+  bool ell_default = false;   // true: every SpMV takes the ELL copy (knob 17 >= 2, or a row-class coded one); false: only the partial loop's fused SpMV does
+  // row-class coding of the ELL copy (round 5; k_spmv_ell, CODED): one byte per row names its class; a class is the row's K offsets
+  // col - row (ell_coded >= 1: ell_c is not kept) and, for constant coefficients, its K values (ell_coded == 2: ell_v is not kept either)
+  uint8_t* ell_cls = nullptr;
+  int32_t* cls_off = nullptr; // [256][K]
+  double* cls_val = nullptr;  // [256][K]
+  int ell_coded = 0;
+  int ell_ncls = 0;
+  int cls_group = 2;          // k_spmv_cls: partial units (ELL blocks) per workgroup (knob 23: 1 = one, A/B)
   const int32_t* host_colidx = nullptr;  // the caller's arrays, valid ONLY inside lz_set_csr / lz_set_csr_transpose (pb_build reads them)
   const double* host_vals = nullptr;
 };
@@ -84,13 +92,19 @@ int launch_spmv_pb(const CsrDev& A, const PbDev* pb, const double* x, double* y,
 int launch_spmv_csr(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, int flags,
                     hipStream_t s);
 // ELL copy of a fixed-K matrix (K in {5, 7, 27}); variant as CsrDev::ell_variant.  ell_free releases it.
-hipError_t ell_build(CsrDev& A, int variant, hipStream_t s);
+hipError_t ell_build(CsrDev& A, int variant, hipStream_t s, int coding = 0, bool plain_fallback = true);
 void ell_free(CsrDev& A);
 bool ell_usable(const CsrDev& A, int flags);
 // The device-resident partial re-orthogonalisation loop's SpMV: when gate[0] == 0 (no sweep ran on this vector) the kernel
 // forms v_j = r / sqrt(nrm2[0]) ITSELF wherever it reads an entry of x (IEEE division: the same bits wherever it is formed),
 // stores the rows it owns to vj and beta to beta_slot; when gate[0] != 0 the sweep kernels have written vj and it is a plain
 // y = A vj.  y must not alias r.  Returns the number of alpha partials.
+struct EllCode {
+  const uint8_t* cls = nullptr;
+  const int32_t* off = nullptr;
+  const double* val = nullptr;
+  int ncls = 0;
+};
 struct SpmvScale {
   const double* r = nullptr;
   const double* nrm2 = nullptr;

@@ -16,7 +16,10 @@ int ensure_part(lz_handle h, size_t need) {
   return LZ_OK;
 }
 
-double spmv_bytes(lz_handle h) {
+double spmv_bytes(lz_handle h, bool ell) {
+  // (a row-class coded ELL copy: one class byte per row, the values only when they are not part of the class, x once, y)
+  if (h->kind == 1 && h->csr.ell_coded && (ell || (h->csr.ell_default && ell_usable(h->csr, h->flags))))
+    return 17.0 * h->rows + (h->csr.ell_coded == 1 ? 8.0 * h->csr.nnz : 0.0);
   if (h->kind == 1) return 12.0 * h->csr.nnz + 4.0 * (h->rows + 1) + 16.0 * h->rows;
   return 8.0 * (double)h->rows * (double)h->Mg + 8.0 * (double)h->Mg + 8.0 * h->rows;  // A block, x once, y
 }
@@ -331,7 +334,10 @@ bool small_args(lz_handle h, int n, SmallArgs& sa) {
     const CsrDev& A = h->csr;
     const bool fixed = !(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7);
     // (one lane walks one row in the engine: rows of more than 32 entries would turn into a chain of dependent loads)
-    if (A.pb || A.ell_default || A.max_row_nnz > 32 || (fixed && A.fixed_rb != 512)) return false;  // (the engine replays the CSR kernels' alpha grouping)
+    // (the engine replays the CSR kernels' alpha grouping; a row-class coded copy of 5- / 7-entry rows groups alpha per 512-row unit
+    // exactly like k_spmv_fixed<K, 512>, so it may stand in for the default SpMV)
+    const bool ell_other_grouping = A.ell_default && !(A.ell_coded && fixed);
+    if (A.pb || ell_other_grouping || A.max_row_nnz > 32 || (fixed && A.fixed_rb != 512)) return false;
     sa.rowptr = A.rowptr;
     sa.colidx = A.colidx;
     sa.vals = A.vals;
@@ -655,7 +661,10 @@ int run_loop_partial_device(lz_handle h, int n, int j0 = 0, const double* state_
       ss.gate = gate;
       int npa = 0;
       {
-        Scope sc(h, LZ_K_SPMV, spmv_bytes(h) + 16.0 * M, spmv_flops(h) + M);  // (the scale pass's 16M bytes ride here: BASELINE.md's accounting of the step is unchanged)
+        // (the scale pass's 16M bytes ride here: BASELINE.md's accounting of the step is unchanged.  With a row-class coded matrix the
+        // launch moves 25 bytes per row - r once, y, V[j], the class byte - so only V[j]'s 8 are added: counting r twice would be a
+        // third of the total there)
+        Scope sc(h, LZ_K_SPMV, spmv_bytes(h, true) + (h->csr.ell_coded ? 8.0 : 16.0) * M, spmv_flops(h) + M);
         npa = launch_spmv_ell(h->csr, vj, rnext, vj, h->d_part, h->stream, &ss);
         LZ_TRY(check_launch(h, "spmv(ell, scale fused)"));
       }

@@ -81,8 +81,21 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   // rows have no CSR-order fixed-K kernel - they ran the generic CSR-stream kernel - and there ELL wins: 247.9 vs 256.3 us on the
   // reference's largest run (deuteron N = 160: 0.710 vs 0.687; the partial loop 223 vs 232 ms with the fused r / beta), so it is
   // their default (gpurun r4q; +12 bytes per entry of device memory).
+  // Round 5, row-class coding (k_spmv_ell, CODED): where the rows of a fixed-K matrix fall into <= 256 classes up to translation - any
+  // stencil on a regular grid - the matrix stream of the ELL-order kernel is one byte per row (+ the values unless the coefficients are
+  // constant too), found and verified on the device right here (~1 ms at 1e7 rows).  Such a copy costs (almost) no memory and moves
+  // 0.21 (0.76 with streamed values) of the CSR bytes: it is every SpMV's default.  tune[17]: 2 / 3 keep the uncoded copy (A/B), 4 codes
+  // the offsets only.
   A.ell_default = h->tune[17] >= 2 || (h->tune[17] == 0 && fixed_k == 27);
-  if (A.ell_default && (fixed_k == 5 || fixed_k == 7 || fixed_k == 27)) LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
+  if (fixed_k == 5 || fixed_k == 7 || fixed_k == 27) {
+    if (h->tune[17] == 0 || h->tune[17] == 4) {
+      LZ_HIP(h, ell_build(A, 0, h->stream, h->tune[17] == 4 ? 2 : 1, A.ell_default));
+      if (A.ell_coded) A.ell_default = true;
+      A.cls_group = h->tune[23] == 1 ? 1 : 2;
+    } else if (A.ell_default) {
+      LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
+    }
+  }
   const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
     const hipError_t pe = pb_build(A, rowptr_host, &A.pb, h->stream, h->tune[10], h->tune[22]);
@@ -300,6 +313,16 @@ int lz_spmv_plan(lz_handle h, int* plan) {
   else if (A.pb && !(h->flags & LZ_FLAG_SPMV_STREAM)) *plan = 3;
   else if (!(h->flags & LZ_FLAG_SPMV_STREAM) && (A.fixed_k == 5 || A.fixed_k == 7 || (A.ell_default && ell_usable(A, h->flags)))) *plan = 2;
   else *plan = 1;
+  return LZ_OK;
+}
+
+int lz_spmv_coding(lz_handle h, int* coding, int* classes) {
+  if (!h || !coding || !classes) return LZ_ERR_ARG;
+  if (h->kind == 0) return fail(h, LZ_ERR_STATE, "lz_spmv_coding: no matrix set");
+  const CsrDev& A = h->csr;
+  const bool used = h->kind == 1 && A.ell_coded && ell_usable(A, h->flags);
+  *coding = used ? A.ell_coded : 0;
+  *classes = used ? A.ell_ncls : 0;
   return LZ_OK;
 }
 

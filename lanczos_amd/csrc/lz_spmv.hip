@@ -222,37 +222,77 @@ __device__ __forceinline__ T ld_nt(const T* p) {
   return __builtin_nontemporal_load(p);
 }
 
-template <int K, int RPT, int VEC, bool SC>
+//   CODED (round 5; "row-class coding"): a stencil matrix has a handful of distinct rows up to translation - the K offsets col - row
+//   take at most 256 different tuples ("classes": interior, faces, edges, corners of a periodic grid; ell_build finds them on the device
+//   from the CSR arrays and verifies every row against its class).  CODED == 1: the columns are one BYTE per row (the class; its offsets
+//   sit in LDS) instead of 4 bytes per entry, the values stream as before.  Where the values repeat with the offsets (constant
+//   coefficients) the whole matrix is that byte per row: k_spmv_cls below.  Products, their order and the alpha partials are exactly
+//   those of the uncoded kernel: same bits.
+template <int K, int RPT, int VEC, bool SC, int CODED>
 __global__ __launch_bounds__(kTPB) void k_spmv_ell(const int32_t* __restrict__ ec, const double* __restrict__ ev,
                                                   const double* __restrict__ x, const double* __restrict__ xown,
                                                   double* __restrict__ y, int rows, int rows_pad, double* __restrict__ part,
-                                                  SpmvScale sc) {
+                                                  SpmvScale sc, EllCode code) {
   constexpr int RB = kTPB * RPT * VEC;
   constexpr int NR = RPT * VEC;  // rows per lane
   __shared__ double sm[kTPB / 64];
+  extern __shared__ double s_tab[];  // CODED == 1: [ncls * K] offsets (ints)
   const int blk = xcd_remap(blockIdx.x, gridDim.x);
   const int r0 = blk * RB;
   const int64_t e0 = (int64_t)blk * K * RB;
+  int lrow[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    lrow[q] = VEC == 1 ? r0 + q * kTPB + (int)threadIdx.x : r0 + (q >> 1) * (2 * kTPB) + 2 * (int)threadIdx.x + (q & 1);
   double a[NR][K];
   int c[NR][K];
+  if constexpr (CODED != 0) {
+    int cl[NR];
 #pragma unroll
-  for (int q = 0; q < RPT; ++q)
+    for (int q = 0; q < NR; ++q) cl[q] = lrow[q] < rows ? (int)code.cls[lrow[q]] : -1;
+    {  // the values stream as in the uncoded kernel (issued before the table is staged)
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if constexpr (VEC == 1) {
-        const int64_t idx = e0 + (int64_t)k * RB + q * kTPB + threadIdx.x;
-        a[q][k] = ld_nt(ev + idx);
-        c[q][k] = ld_nt(ec + idx);
-      } else {
-        const int64_t idx = e0 + (int64_t)k * RB + q * (2 * kTPB) + 2 * threadIdx.x;
-        const double2 av = ld_stream<1>(reinterpret_cast<const double2*>(ev + idx));
-        const int2 cv = ld_stream<1>(reinterpret_cast<const int2*>(ec + idx));
-        a[2 * q][k] = av.x;
-        a[2 * q + 1][k] = av.y;
-        c[2 * q][k] = cv.x;
-        c[2 * q + 1][k] = cv.y;
-      }
+      for (int q = 0; q < RPT; ++q)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if constexpr (VEC == 1) {
+            a[q][k] = ld_nt(ev + e0 + (int64_t)k * RB + q * kTPB + threadIdx.x);
+          } else {
+            const double2 av = ld_stream<1>(reinterpret_cast<const double2*>(ev + e0 + (int64_t)k * RB + q * (2 * kTPB) + 2 * threadIdx.x));
+            a[2 * q][k] = av.x;
+            a[2 * q + 1][k] = av.y;
+          }
+        }
     }
+    const int nt = code.ncls * K;
+    int* s_off = reinterpret_cast<int*>(s_tab);
+    for (int i = threadIdx.x; i < nt; i += kTPB) s_off[i] = code.off[i];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+      for (int k = 0; k < K; ++k)  // (rows past the end of the last block: column 0; their values are the pad slots' zeros)
+        c[q][k] = cl[q] >= 0 ? lrow[q] + s_off[cl[q] * K + k] : 0;
+  } else {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if constexpr (VEC == 1) {
+          const int64_t idx = e0 + (int64_t)k * RB + q * kTPB + threadIdx.x;
+          a[q][k] = ld_nt(ev + idx);
+          c[q][k] = ld_nt(ec + idx);
+        } else {
+          const int64_t idx = e0 + (int64_t)k * RB + q * (2 * kTPB) + 2 * threadIdx.x;
+          const double2 av = ld_stream<1>(reinterpret_cast<const double2*>(ev + idx));
+          const int2 cv = ld_stream<1>(reinterpret_cast<const int2*>(ec + idx));
+          a[2 * q][k] = av.x;
+          a[2 * q + 1][k] = av.y;
+          c[2 * q][k] = cv.x;
+          c[2 * q + 1][k] = cv.y;
+        }
+      }
+  }
   bool scale = false;
   double beta = 1.0;
   const double* xs = x;
@@ -271,13 +311,9 @@ __global__ __launch_bounds__(kTPB) void k_spmv_ell(const int32_t* __restrict__ e
   for (int q = 0; q < NR; ++q)
 #pragma unroll
     for (int k = 0; k < K; ++k) xv[q][k] = xs[c[q][k]];
-  int lrow[NR];
   double own[NR];
 #pragma unroll
-  for (int q = 0; q < NR; ++q) {
-    lrow[q] = VEC == 1 ? r0 + q * kTPB + (int)threadIdx.x : r0 + (q >> 1) * (2 * kTPB) + 2 * (int)threadIdx.x + (q & 1);
-    own[q] = lrow[q] < rows_pad ? xo[lrow[q]] : 0.0;
-  }
+  for (int q = 0; q < NR; ++q) own[q] = lrow[q] < rows_pad ? xo[lrow[q]] : 0.0;
   if constexpr (SC) {
     if (scale) {
 #pragma unroll
@@ -304,6 +340,201 @@ __global__ __launch_bounds__(kTPB) void k_spmv_ell(const int32_t* __restrict__ e
   if (threadIdx.x == 0) part[blk] = d;
 }
 
+// Offsets AND values by class: the matrix is one byte per row.  A block covers G partial units of RBU = 256 RPT rows - the alpha partial of
+// a unit is formed exactly as k_spmv_ell forms a block's (lane t: rows t, t + 256, ... of the unit in order; wave sums; the waves added in
+// order), so the bits do not depend on G - and a lane keeps G RPT rows in flight: the values are read from LDS only when the gathers
+// have landed, which leaves registers for twice the rows of the uncoded kernel (the kernel is bound by two dependent memory round
+// trips - class byte, then x - not by bytes: 17 per row).
+template <int K, int RPT, int G, bool SC>
+__global__ __launch_bounds__(kTPB) void k_spmv_cls(EllCode code, const double* __restrict__ x, const double* __restrict__ xown, double* __restrict__ y,
+                                                  int rows, int rows_pad, int nunits, double* __restrict__ part, SpmvScale sc) {
+  constexpr int RBU = kTPB * RPT;
+  constexpr int NR = RPT * G;
+  __shared__ double sm[G][kTPB / 64];
+  extern __shared__ double s_tab[];  // [ncls * K] values, then [ncls * K] offsets
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int r0 = blk * (RBU * G);
+  int lrow[NR], cl[NR];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) lrow[g * RPT + q] = r0 + g * RBU + q * kTPB + (int)threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) cl[i] = lrow[i] < rows ? (int)code.cls[lrow[i]] : -1;
+  bool scale = false;
+  double beta = 1.0;
+  const double* xs = x;
+  const double* xo = xown;
+  if constexpr (SC) {
+    scale = sc.gate[0] == 0;
+    if (scale) {
+      beta = sqrt(sc.nrm2[0]);
+      xs = sc.r;
+      xo = sc.r;
+      if (blockIdx.x == 0 && threadIdx.x == 0) sc.beta_slot[0] = beta;
+    }
+  }
+  double own[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) own[i] = lrow[i] < rows_pad ? xo[lrow[i]] : 0.0;  // (does not wait for the class)
+  const int nt = code.ncls * K;
+  int* s_off = reinterpret_cast<int*>(s_tab + nt);
+  for (int i = threadIdx.x; i < nt; i += kTPB) {
+    s_off[i] = code.off[i];
+    s_tab[i] = code.val[i];
+  }
+  __syncthreads();
+  double xv[NR][K];
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int k = 0; k < K; ++k) xv[i][k] = xs[cl[i] >= 0 ? lrow[i] + s_off[cl[i] * K + k] : 0];
+  if constexpr (SC) {
+    if (scale) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) xv[i][k] = xv[i][k] / beta;
+        own[i] = own[i] / beta;
+        if (lrow[i] < rows_pad) sc.vj[lrow[i]] = own[i];  // (the pad of r is zero: 0 / beta keeps the pad of V[j] zero)
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    double d = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int i = g * RPT + q;
+      if (lrow[i] < rows) {
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) sum += s_tab[cl[i] * K + k] * xv[i][k];
+        y[lrow[i]] = sum;
+        d += own[i] * sum;
+      }
+    }
+    d = wave_sum(d);
+    if (lane == 0) sm[g][w] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int unit = blk * G + (int)threadIdx.x;
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < kTPB / 64; ++i) t += sm[threadIdx.x][i];
+    if (unit < nunits) part[unit] = t;
+  }
+}
+
+// ---- row classes of a fixed-K matrix, found on the device ------------------------------------------------------------------
+// Two open-addressing tables of 1024 slots (keys: a 64-bit hash of the row's K offsets / of its offsets and value bits; 0 = empty).
+// ctl: [0] classes by offsets, [1] classes by offsets + values, [2] / [3] "more than 256" of either, [4] a row that does not equal
+// its class's representative (a hash collision: the coding is then abandoned).
+constexpr int kClsSlots = 1024, kClsMax = 256;
+
+__device__ __forceinline__ unsigned long long cls_mix(unsigned long long h, unsigned long long v) {
+  h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+  h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 31;
+  return h;
+}
+__device__ __forceinline__ void cls_hash(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int row, unsigned long long* h_off,
+                                         unsigned long long* h_all) {
+  unsigned long long h1 = 0x243F6A8885A308D3ull, h2 = 0x13198A2E03707344ull;
+  const int64_t e = (int64_t)row * K;
+  for (int k = 0; k < K; ++k) {
+    const unsigned long long o = (unsigned long long)(long long)(colidx[e + k] - row);
+    h1 = cls_mix(h1, o);
+    h2 = cls_mix(cls_mix(h2, o), (unsigned long long)__double_as_longlong(vals[e + k]));
+  }
+  *h_off = h1 ? h1 : 1;
+  *h_all = h2 ? h2 : 1;
+}
+__device__ __forceinline__ void cls_insert(unsigned long long* keys, int* rep, int* count, int* overflow, unsigned long long h, int row) {
+  if (*reinterpret_cast<volatile int*>(overflow)) return;
+  unsigned slot = (unsigned)(h >> 20) & (kClsSlots - 1);
+  for (int p = 0; p < kClsSlots; ++p, slot = (slot + 1) & (kClsSlots - 1)) {
+    unsigned long long prev = *reinterpret_cast<volatile unsigned long long*>(keys + slot);  // (a stale 0 only costs the atomic below)
+    if (prev == 0) prev = atomicCAS(keys + slot, 0ull, h);
+    if (prev == 0) {
+      if (atomicAdd(count, 1) + 1 > kClsMax) atomicExch(overflow, 1);
+      atomicMin(rep + slot, row);
+      return;
+    }
+    if (prev == h) {
+      if (row < *reinterpret_cast<volatile int*>(rep + slot)) atomicMin(rep + slot, row);  // (the representative: the class's first row)
+      return;
+    }
+  }
+  atomicExch(overflow, 1);
+}
+__global__ __launch_bounds__(kTPB) void k_cls_insert(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int rows,
+                                                    unsigned long long* keys_off, int* rep_off, unsigned long long* keys_all, int* rep_all, int* ctl) {
+  const int row = blockIdx.x * kTPB + threadIdx.x;
+  if (row >= rows) return;
+  unsigned long long h1, h2;
+  cls_hash(colidx, vals, K, row, &h1, &h2);
+  cls_insert(keys_off, rep_off, ctl + 0, ctl + 2, h1, row);
+  cls_insert(keys_all, rep_all, ctl + 1, ctl + 3, h2, row);
+}
+// one block of kClsSlots threads: number the occupied slots in slot order and write the class table from the representatives
+__global__ __launch_bounds__(kClsSlots) void k_cls_number(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K,
+                                                         const unsigned long long* __restrict__ keys, const int* __restrict__ rep, int* __restrict__ ids,
+                                                         int32_t* __restrict__ toff, double* __restrict__ tval) {
+  __shared__ int scan[kClsSlots];
+  const int t = threadIdx.x;
+  const int occ = keys[t] != 0 ? 1 : 0;
+  scan[t] = occ;
+  __syncthreads();
+  for (int d = 1; d < kClsSlots; d <<= 1) {
+    const int v = t >= d ? scan[t - d] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  const int id = scan[t] - occ;
+  ids[t] = occ ? id : -1;
+  if (occ && id < kClsMax) {
+    const int r = rep[t];
+    for (int k = 0; k < K; ++k) {
+      toff[id * K + k] = colidx[(int64_t)r * K + k] - r;
+      tval[id * K + k] = vals[(int64_t)r * K + k];
+    }
+  }
+}
+__global__ __launch_bounds__(kTPB) void k_cls_assign(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int rows, int with_vals,
+                                                    const unsigned long long* __restrict__ keys, const int* __restrict__ ids,
+                                                    const int32_t* __restrict__ toff, const double* __restrict__ tval, uint8_t* __restrict__ cls,
+                                                    int* ctl) {
+  const int row = blockIdx.x * kTPB + threadIdx.x;
+  if (row >= rows) return;
+  unsigned long long h1, h2;
+  cls_hash(colidx, vals, K, row, &h1, &h2);
+  const unsigned long long h = with_vals ? h2 : h1;
+  unsigned slot = (unsigned)(h >> 20) & (kClsSlots - 1);
+  int id = -1;
+  for (int p = 0; p < kClsSlots; ++p, slot = (slot + 1) & (kClsSlots - 1))
+    if (keys[slot] == h) {
+      id = ids[slot];
+      break;
+    }
+  bool same = id >= 0 && id < kClsMax;
+  if (same) {
+    const int64_t e = (int64_t)row * K;
+    for (int k = 0; k < K; ++k) {
+      same = same && toff[id * K + k] == colidx[e + k] - row;
+      if (with_vals) same = same && __double_as_longlong(tval[id * K + k]) == __double_as_longlong(vals[e + k]);
+    }
+  }
+  if (!same) {
+    atomicExch(ctl + 4, 1);
+    return;
+  }
+  cls[row] = (uint8_t)id;
+}
+
 __global__ __launch_bounds__(kTPB) void k_ell_build(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int RB,
                                                    int64_t nnz, int32_t* __restrict__ ec, double* __restrict__ ev) {
   const int64_t e = (int64_t)blockIdx.x * kTPB + threadIdx.x;
@@ -313,7 +544,7 @@ __global__ __launch_bounds__(kTPB) void k_ell_build(const int32_t* __restrict__ 
   const int64_t b = row / RB;
   const int lr = (int)(row - b * RB);
   const int64_t dst = (b * K + k) * RB + lr;
-  ec[dst] = colidx[e];
+  if (ec) ec[dst] = colidx[e];  // (offsets-only row-class coding keeps the values, not the columns)
   ev[dst] = vals[e];
 }
 
@@ -322,12 +553,80 @@ static int ell_rows_per_block(int K, int variant) { return K > 7 ? kTPB : 2 * kT
 void ell_free(CsrDev& A) {
   if (A.ell_c) hipFree(A.ell_c);
   if (A.ell_v) hipFree(A.ell_v);
+  if (A.ell_cls) hipFree(A.ell_cls);
+  if (A.cls_off) hipFree(A.cls_off);
+  if (A.cls_val) hipFree(A.cls_val);
   A.ell_c = nullptr;
   A.ell_v = nullptr;
+  A.ell_cls = nullptr;
+  A.cls_off = nullptr;
+  A.cls_val = nullptr;
   A.ell_rb = 0;
+  A.ell_coded = 0;
+  A.ell_ncls = 0;
 }
 
-hipError_t ell_build(CsrDev& A, int variant, hipStream_t s) {
+// Row classes of the fixed-K matrix A (see k_spmv_ell, CODED): returns the coding found - 2 offsets and values, 1 offsets only, 0 none
+// (more than 256 classes of either kind) - with A.ell_cls / cls_off / cls_val / ell_ncls filled in.  `want`: 1 try both, 2 offsets
+// only (A/B arm).  Two short synchronisations of `s` (this is matrix set-up).
+static hipError_t ell_classes(CsrDev& A, int want, hipStream_t s, int* coded_out) {
+  *coded_out = 0;
+  const int K = A.fixed_k;
+  const int rows = (int)A.rows;
+  struct Scratch {
+    void* p = nullptr;
+    ~Scratch() {
+      if (p) hipFree(p);
+    }
+  } scr;
+  // [keys_off 1024 u64 | keys_all 1024 u64 | rep_off 1024 | rep_all 1024 | ids 1024 | ctl 8]
+  const size_t bytes = 2 * kClsSlots * sizeof(unsigned long long) + (3 * kClsSlots + 8) * sizeof(int);
+  hipError_t e = hipMalloc(&scr.p, bytes);
+  if (e != hipSuccess) return e;
+  unsigned long long* keys_off = static_cast<unsigned long long*>(scr.p);
+  unsigned long long* keys_all = keys_off + kClsSlots;
+  int* rep_off = reinterpret_cast<int*>(keys_all + kClsSlots);
+  int* rep_all = rep_off + kClsSlots;
+  int* ids = rep_all + kClsSlots;
+  int* ctl = ids + kClsSlots;
+  if ((e = hipMemsetAsync(scr.p, 0, bytes, s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(rep_off, 0x7F, 2 * kClsSlots * sizeof(int), s)) != hipSuccess) return e;
+  const unsigned grid = (unsigned)((rows + kTPB - 1) / kTPB);
+  hipLaunchKernelGGL(k_cls_insert, dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, K, rows, keys_off, rep_off, keys_all, rep_all, ctl);
+  int h_ctl[8] = {0};
+  if ((e = hipMemcpyAsync(h_ctl, ctl, sizeof h_ctl, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+  int coded = 0;
+  if (want == 1 && !h_ctl[3] && h_ctl[1] <= kClsMax) coded = 2;
+  else if (!h_ctl[2] && h_ctl[0] <= kClsMax) coded = 1;
+  if (!coded) return hipSuccess;
+  const int ncls = coded == 2 ? h_ctl[1] : h_ctl[0];
+  void* p = nullptr;
+  const int RB = A.ell_rb;
+  const int64_t nblk = (A.rows + RB - 1) / RB;
+  if ((e = hipMalloc(&p, (size_t)nblk * RB)) != hipSuccess) return e;
+  A.ell_cls = static_cast<uint8_t*>(p);
+  if ((e = hipMalloc(&p, (size_t)kClsMax * K * sizeof(int32_t))) != hipSuccess) return e;
+  A.cls_off = static_cast<int32_t*>(p);
+  if ((e = hipMalloc(&p, (size_t)kClsMax * K * sizeof(double))) != hipSuccess) return e;
+  A.cls_val = static_cast<double*>(p);
+  if ((e = hipMemsetAsync(A.ell_cls, 0, (size_t)nblk * RB, s)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_cls_number, dim3(1), dim3(kClsSlots), 0, s, A.colidx, A.vals, K, coded == 2 ? keys_all : keys_off, coded == 2 ? rep_all : rep_off, ids,
+                     A.cls_off, A.cls_val);
+  hipLaunchKernelGGL(k_cls_assign, dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, K, rows, coded == 2 ? 1 : 0, coded == 2 ? keys_all : keys_off, ids, A.cls_off,
+                     A.cls_val, A.ell_cls, ctl);
+  if ((e = hipMemcpyAsync(h_ctl, ctl, sizeof h_ctl, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (h_ctl[4]) return hipSuccess;  // a hash collision (two different rows, one key): no coding
+  A.ell_ncls = ncls;
+  *coded_out = coded;
+  return hipSuccess;
+}
+
+// coding: 0 the plain ELL copy, 1 row-class coding where the matrix allows it (offsets and values, else offsets only, else plain),
+// 2 at most the offsets-only coding (A/B arm); plain_fallback == false: no copy at all when the rows do not fall into classes
+hipError_t ell_build(CsrDev& A, int variant, hipStream_t s, int coding, bool plain_fallback) {
   ell_free(A);
   const int K = A.fixed_k;
   if (!(K == 5 || K == 7 || K == 27) || A.rows <= 0) return hipSuccess;
@@ -335,30 +634,59 @@ hipError_t ell_build(CsrDev& A, int variant, hipStream_t s) {
   const int RB = ell_rows_per_block(K, variant);
   const int64_t nblk = (A.rows + RB - 1) / RB;
   const size_t cap = (size_t)nblk * K * RB;
+  A.ell_rb = RB;  // (ell_classes sizes the class bytes by it)
+  hipError_t e = hipSuccess;
+  int coded = 0;
+  if (coding && A.rows < ((int64_t)1 << 31) - 2 * RB) {
+    e = ell_classes(A, coding, s, &coded);
+    if (e != hipSuccess || !coded) {
+      const int rb = A.ell_rb;
+      ell_free(A);
+      A.ell_rb = rb;
+      if (e != hipSuccess) {
+        A.ell_rb = 0;
+        return e;
+      }
+    }
+  }
+  if (coded == 0 && coding && !plain_fallback) {
+    ell_free(A);
+    return hipSuccess;
+  }
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, cap * sizeof(int32_t));
-  if (e != hipSuccess) return e;
-  A.ell_c = static_cast<int32_t*>(p);
-  e = hipMalloc(&p, cap * sizeof(double));
+  if (coded == 0) {
+    e = hipMalloc(&p, cap * sizeof(int32_t));
+    if (e != hipSuccess) {
+      ell_free(A);
+      return e;
+    }
+    A.ell_c = static_cast<int32_t*>(p);
+    e = hipMemsetAsync(A.ell_c, 0, cap * sizeof(int32_t), s);
+  }
+  if (e == hipSuccess && coded != 2) {
+    e = hipMalloc(&p, cap * sizeof(double));
+    if (e == hipSuccess) {
+      A.ell_v = static_cast<double*>(p);
+      // only the last block has pad slots, but a memset of the whole copy is cheaper than finding them
+      e = hipMemsetAsync(A.ell_v, 0, cap * sizeof(double), s);
+    }
+  }
   if (e != hipSuccess) {
     ell_free(A);
     return e;
   }
-  A.ell_v = static_cast<double*>(p);
-  // only the last block has pad slots, but a memset of the whole copy is cheaper than finding them
-  if ((e = hipMemsetAsync(A.ell_c, 0, cap * sizeof(int32_t), s)) != hipSuccess || (e = hipMemsetAsync(A.ell_v, 0, cap * sizeof(double), s)) != hipSuccess) {
-    ell_free(A);
-    return e;
-  }
-  const int64_t nnz = A.rows * K;
-  hipLaunchKernelGGL(k_ell_build, dim3((unsigned)((nnz + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, A.colidx, A.vals, K, RB, nnz, A.ell_c, A.ell_v);
-  e = hipGetLastError();
-  if (e != hipSuccess) {
-    ell_free(A);
-    return e;
+  if (coded != 2) {
+    const int64_t nnz = A.rows * K;
+    hipLaunchKernelGGL(k_ell_build, dim3((unsigned)((nnz + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, A.colidx, A.vals, K, RB, nnz, A.ell_c, A.ell_v);
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+      ell_free(A);
+      return e;
+    }
   }
   A.ell_rb = RB;
   A.ell_variant = variant;
+  A.ell_coded = coded;
   return hipSuccess;
 }
 
@@ -366,20 +694,58 @@ bool ell_usable(const CsrDev& A, int flags) {
   return A.ell_rb > 0 && !(flags & (LZ_FLAG_SPMV_SCALAR | LZ_FLAG_SPMV_STREAM)) && !A.pb;
 }
 
-template <int K, int RPT, int VEC>
-static int launch_spmv_ell_t(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
+template <int K, int RPT, int VEC, int CODED>
+static int launch_spmv_ell_c(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
   constexpr int RB = kTPB * RPT * VEC;
   const int grid = (int)((A.rows + RB - 1) / RB);
   const int rows_pad = (int)round_up(A.rows, kPadDoubles);
+  EllCode code;
+  code.cls = A.ell_cls;
+  code.off = A.cls_off;
+  code.val = A.cls_val;
+  code.ncls = A.ell_ncls;
+  const size_t lds = CODED == 0 ? 0 : (size_t)A.ell_ncls * K * 4 + 8;
   if (sc)
-    hipLaunchKernelGGL((k_spmv_ell<K, RPT, VEC, true>), dim3(grid), dim3(kTPB), 0, s, A.ell_c, A.ell_v, x, x_own, y, (int)A.rows, rows_pad, part, *sc);
+    hipLaunchKernelGGL((k_spmv_ell<K, RPT, VEC, true, CODED>), dim3(grid), dim3(kTPB), lds, s, A.ell_c, A.ell_v, x, x_own, y, (int)A.rows, rows_pad, part, *sc,
+                       code);
   else
-    hipLaunchKernelGGL((k_spmv_ell<K, RPT, VEC, false>), dim3(grid), dim3(kTPB), 0, s, A.ell_c, A.ell_v, x, x_own, y, (int)A.rows, rows_pad, part,
-                       SpmvScale());
+    hipLaunchKernelGGL((k_spmv_ell<K, RPT, VEC, false, CODED>), dim3(grid), dim3(kTPB), lds, s, A.ell_c, A.ell_v, x, x_own, y, (int)A.rows, rows_pad, part,
+                       SpmvScale(), code);
   return grid;
+}
+template <int K, int RPT, int G>
+static int launch_spmv_cls(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
+  constexpr int RBU = kTPB * RPT;
+  const int nunits = (int)((A.rows + RBU - 1) / RBU);  // one alpha partial per unit: the ELL copy's blocks
+  const int grid = (nunits + G - 1) / G;
+  const int rows_pad = (int)round_up(A.rows, kPadDoubles);
+  EllCode code;
+  code.cls = A.ell_cls;
+  code.off = A.cls_off;
+  code.val = A.cls_val;
+  code.ncls = A.ell_ncls;
+  const size_t lds = (size_t)A.ell_ncls * K * 12 + 8;
+  if (sc)
+    hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, true>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, *sc);
+  else
+    hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, false>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, SpmvScale());
+  return nunits;
+}
+template <int K, int RPT, int VEC>
+static int launch_spmv_ell_t(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
+  if (A.ell_coded == 1) return launch_spmv_ell_c<K, RPT, VEC, 1>(A, x, y, x_own, part, s, sc);
+  return launch_spmv_ell_c<K, RPT, VEC, 0>(A, x, y, x_own, part, s, sc);
 }
 
 int launch_spmv_ell(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
+  if (A.ell_coded == 2) {  // (always built with one row per lane and trip: ell_variant 0)
+    // (the fused r / beta form holds 62 registers with one unit per workgroup, 112 with two: measured no faster in 2-D, 7 % slower on a
+    // 300^3 grid - it keeps one; the plain SpMV takes two: 185 vs 191 us there, equal in 2-D.  tools/partial_step_probe.py, spmv_coding_probe.py)
+    const int G = sc ? 1 : A.cls_group;
+    if (A.fixed_k == 27) return launch_spmv_cls<27, 1, 1>(A, x, y, x_own, part, s, sc);
+    if (A.fixed_k == 5) return G == 1 ? launch_spmv_cls<5, 2, 1>(A, x, y, x_own, part, s, sc) : launch_spmv_cls<5, 2, 2>(A, x, y, x_own, part, s, sc);
+    return G == 1 ? launch_spmv_cls<7, 2, 1>(A, x, y, x_own, part, s, sc) : launch_spmv_cls<7, 2, 2>(A, x, y, x_own, part, s, sc);
+  }
   if (A.fixed_k == 27) return launch_spmv_ell_t<27, 1, 1>(A, x, y, x_own, part, s, sc);
   if (A.ell_variant == 1) {
     if (A.fixed_k == 5) return launch_spmv_ell_t<5, 1, 2>(A, x, y, x_own, part, s, sc);

@@ -102,6 +102,91 @@ def test_spmv_fixed_k_layouts_bit_exact(hip, K, M):
         assert alphas[1] == alphas[2]  # 512-row blocks, rows t and t + 256 per lane in both
 
 
+def _stencil_cases():
+    lap2 = synthetic.laplacian_2d_5pt(37, 29).to_scipy()       # 9 classes (periodic: interior, 4 edges, 4 corners), ragged last block
+    lap2b = synthetic.laplacian_2d_5pt(400, 300).to_scipy()
+    lap3 = synthetic.laplacian_3d_7pt(21, 17, 13).to_scipy()   # 27 classes
+    rng = np.random.default_rng(5)
+
+    def with_values(H, what):
+        G = H.copy()
+        if what == "random":
+            G.data = rng.standard_normal(G.nnz)
+        else:  # a potential on the diagonal: the reference's own operators (Hamiltonian.py) - offsets repeat, values do not
+            G = (G + scipy.sparse.diags(rng.uniform(-1, 1, G.shape[0]))).tocsr()
+        G.sort_indices()
+        return G
+
+    return {"lap2d_37x29": (lap2, "offsets+values", 9), "lap2d_400x300": (lap2b, "offsets+values", 9), "lap3d_21x17x13": (lap3, "offsets+values", 27),
+            "lap2d_37x29_random_values": (with_values(lap2, "random"), "offsets", 9),
+            "lap3d_21x17x13_potential": (with_values(lap3, "potential"), "offsets", 27),
+            "lap2d_400x300_potential": (with_values(lap2b, "potential"), "offsets", 9)}
+
+
+@pytest.mark.parametrize("name", ["lap2d_37x29", "lap2d_400x300", "lap3d_21x17x13", "lap2d_37x29_random_values", "lap3d_21x17x13_potential",
+                                  "lap2d_400x300_potential"])
+def test_spmv_row_class_coding_bit_exact(hip, name):
+    """Round 5: a stencil matrix's rows fall into a handful of classes up to translation (offsets col - row; with constant coefficients
+    the values too).  lz_set_csr finds and verifies them on the device and the ELL-order kernel then streams ONE BYTE per row (+ the
+    values when only the offsets repeat) instead of 12 bytes per entry.  y and the alpha partials are bit-identical to the CSR-order
+    kernel (knob 17 = 1), the uncoded ELL copy (2) and SciPy; knob 4 keeps the values streamed (A/B)."""
+    H, coding, classes = _stencil_cases()[name]
+    M = H.shape[0]
+    x = np.random.default_rng(1).uniform(-1, 1, M)
+    ref = H * x
+    alphas = {}
+    for knob in (0, 1, 2, 4):
+        h = hip.Handle(0)
+        h.set_tuning(hip.TUNE_FIXED_LAYOUT, knob)
+        h.set_csr(M, 0, H.indptr, H.indices, H.data)
+        want = {0: (coding, classes), 1: ("none", 0), 2: ("none", 0), 4: ("offsets", classes)}[knob]
+        assert h.spmv_coding() == want, (knob, h.spmv_coding())
+        assert h.spmv_plan() == "fixed-k"
+        for _ in range(2):
+            y = h.spmv_host(x)
+            assert np.array_equal(y, ref), (knob, np.abs(y - ref).max())
+        h.basis_alloc(3)
+        h.basis_set_row(1, x)
+        alphas[knob] = h.step_spmv(1)
+        assert np.array_equal(h.r_get(), ref)
+        h.close()
+    assert alphas[0] == alphas[1] == alphas[2] == alphas[4]
+
+
+def test_spmv_row_class_coding_gives_way(hip):
+    """More than 256 classes (fixed-K rows without stencil structure; a stencil whose every row has its own coefficients still codes its
+    OFFSETS), a value class count just over the limit, and options that bypass the ELL copy: the uncoded kernels run, same bits."""
+    H = _fixed_k_random(3000, 5, seed=3)
+    h = hip.Handle(0)
+    h.set_csr(3000, 0, H.indptr, H.indices, H.data)
+    assert h.spmv_coding() == ("none", 0)
+    x = np.random.default_rng(2).uniform(-1, 1, 3000)
+    assert np.array_equal(h.spmv_host(x), H * x)
+    h.close()
+    # 300 different diagonal values on a 5-point stencil: 9 offset classes, but 9 x 300 > 256 value classes -> offsets only
+    L = synthetic.laplacian_2d_5pt(60, 50).to_scipy()
+    D = scipy.sparse.diags((np.arange(3000) % 300).astype(float))
+    G = (L + D).tocsr()
+    G.sort_indices()
+    h = hip.Handle(0)
+    h.set_csr(3000, 0, G.indptr, G.indices, G.data)
+    assert h.spmv_coding() == ("offsets", 9)
+    assert np.array_equal(h.spmv_host(x), G * x)
+    h.set_options(_capi.FLAG_SPMV_STREAM)  # the CSR-stream kernel on request: the coding is not in play
+    assert h.spmv_coding() == ("none", 0) and h.spmv_plan() == "csr-stream"
+    assert np.array_equal(h.spmv_host(x), G * x)
+    h.close()
+    # 25 diagonal values: 9 x 25 = 225 classes of offsets + values (a table of 225 x 5 entries in LDS)
+    G = (L + scipy.sparse.diags((np.arange(3000) % 25).astype(float))).tocsr()
+    G.sort_indices()
+    h = hip.Handle(0)
+    h.set_csr(3000, 0, G.indptr, G.indices, G.data)
+    kind, ncls = h.spmv_coding()
+    assert kind == "offsets+values" and 25 <= ncls <= 225
+    assert np.array_equal(h.spmv_host(x), G * x)
+    h.close()
+
+
 def _two_phase_matrices():
     rng = np.random.default_rng(11)
     big = synthetic.random_graph_laplacian(60000, 210000, seed=8).to_scipy()  # several row blocks x 118 column blocks
