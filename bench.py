@@ -98,6 +98,34 @@ def gram_record(tg, k):
     return rec
 
 
+def spmv_format_arm(_capi, local, device, coding):
+    """A/B beside a row-class coded SpMV (round 5): the SAME matrix through the uncoded kernel (knob 17 = 1: the CSR-order fixed-K kernel /
+    CSR-stream, 12 bytes per entry) - the bandwidth-bound SpMV BASELINE.json's roofline target speaks of - on a handle of its own;
+    12 launches, the library's hipEvents.  The coded kernel moves a fifth of those bytes, so ITS fraction of the HBM peak is lower while
+    it is 2.5x faster: both are reported, each on the bytes it actually moves."""
+    h = _capi.Handle(device)
+    try:
+        h.set_options(_capi.FLAG_FUSED_NORM | _capi.FLAG_PROFILE)
+        h.set_tuning(_capi.TUNE_FIXED_LAYOUT, 1)
+        h.set_tuning(_capi.TUNE_PROFILE_STRIDE, 1)
+        M = local.shape[0]
+        h.set_csr(M, 0, local.rowptr, local.colidx, local.vals)
+        h.basis_alloc(2)
+        h.basis_set_row(0, np.random.default_rng(0).uniform(-1, 1, M))
+        h.step_spmv(0)
+        h.timings()
+        for _ in range(12):
+            h.step_spmv(0)
+        t = h.timings()["spmv"]
+        us = 1e3 * t["ms"] / max(t["timed_launches"], 1)
+        gbs = t["timed_bytes"] / max(t["ms"], 1e-9) / 1e6
+        return {"kernel": h.spmv_plan() + " (uncoded, knob 17 = 1)", "avg_us": round(us, 2), "bytes_per_launch": t["timed_bytes"] / max(t["timed_launches"], 1),
+                "achieved_GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "launches": int(t["timed_launches"]),
+                "coded_kernel_of_this_run": {"coding": coding[0], "classes": coding[1]}}
+    finally:
+        h.close()
+
+
 def class_surface(lanczos_amd, local, k):
     """Wall time of the reference's call sequence through lanczos_amd.Lanczos (see the call site)."""
     H = local.to_scipy()
@@ -629,6 +657,10 @@ def main():
         # Lanczos(H).execute_Lanczos(k) and reads .H_eigvals / .V / .H_eigvecs (Lanczos.py:75-163).  Wall seconds of each through
         # the class surface, on a fresh object: first call (start vector + content hash + pack + validate + H2D + layout + solve),
         # second call on the unchanged H (hash only + solve), then the lazily fetched results.
+        if (world == 1 and rank == 0 and not args.no_class_surface and hasattr(local, "rowptr") and hasattr(solver.h, "spmv_coding")
+                and solver.h.spmv_coding()[0] != "none"):  # (not in the PMC / rocprofv3 passes, which run with --no-class-surface)
+            arm_state["arm"] = "spmv_uncoded_arm"
+            line["spmv_uncoded_arm"] = spmv_format_arm(_capi, local, local_rank, solver.h.spmv_coding())
         if world == 1 and not args.no_class_surface and hasattr(local, "to_scipy"):
             arm_state["arm"] = "class_surface"
             if 16.0 * M * k > 120e9:

@@ -141,8 +141,9 @@ int lz_set_options(lz_handle h, int flags);
  *   18  partial re-orthogonalisation loop: 0 auto (device-resident decisions, lz_last_engine 7), 1 the host-decided loop
  *       (two scalars read back per step; same bits), 2 device-resident but with the separate scale pass (no fused r / beta),
  *       3 device-resident with pass 1's second-stage sums as a kernel of their own (default: pass 1's last block adds them)
- *   23  fully row-class coded SpMV (lz_spmv_coding == 2): 0 auto (two 512-row units per workgroup, four rows in flight per lane),
- *       1 one unit per workgroup (A/B; same bits - the alpha partials are per unit)
+ *   23  fully row-class coded SpMV (lz_spmv_coding == 2): 0 auto (two ADJACENT rows per lane: 16-byte gathers, half the vector-memory
+ *       instructions), 1 / 3 one row per lane and trip with one / two 512-row units per workgroup (A/B; same bits in every form - the
+ *       alpha partials are per unit and per the one-row-per-lane lane mapping)
  *   22  irregular (two-phase) SpMV: interleave its two phases over this many groups of row blocks (A/B arm of round 5: the product
  *       stream of a group could stay in the Infinity Cache between the phases; measured 8-110 % slower - DESIGN.md section 4; kernel-bench
  *       build only; 0 / 1 = off)

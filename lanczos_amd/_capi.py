@@ -51,7 +51,7 @@ TUNE_RITZ_CHUNK_ROWS = 16   # rows per chunk of the chunked Ritz mode (> 0 force
 TUNE_FIXED_LAYOUT = 17      # fixed-K SpMV layout (0 auto: row-class coded ELL where the rows fall into classes, else CSR order and ELL only in the partial loop;
                             # 1 never ELL; 2 / 3 uncoded ELL always, one / two rows per lane; 4 offsets-only coding)
 TUNE_GRAM_KERNEL = 19       # Gram matrix of the Ritz vectors (0 auto: symmetric accumulator-stationary kernel with LDS-staged operands, 1 split-K TN GEMM, 2 the register-ring form)
-TUNE_CLS_GROUP = 23         # fully coded SpMV: 1 = one 512-row unit per workgroup (A/B; default two)
+TUNE_CLS_GROUP = 23         # fully coded SpMV: 0 two adjacent rows per lane; 1 / 3 one row per lane, one / two units per workgroup (A/B)
 TUNE_PB_GROUPS = 22         # two-phase SpMV: phases interleaved over this many row-block groups (A/B arm; 0 = off)
 TUNE_GRAM_SLICES = 21       # Gram matrix: K slices of the symmetric kernel (0 auto)
 TUNE_PARTIAL_LOOKAHEAD = 20 # one-reduce partial loop: safety factor of the look-ahead sweep decision (0 = default 4)

@@ -75,7 +75,7 @@ struct CsrDev {
   double* cls_val = nullptr;  // [256][K]
   int ell_coded = 0;
   int ell_ncls = 0;
-  int cls_group = 2;          // k_spmv_cls: partial units (ELL blocks) per workgroup (knob 23: 1 = one, A/B)
+  int cls_group = 0;          // knob 23: 0 k_spmv_cls2 (two adjacent rows per lane); 1 / 3: k_spmv_cls with one / two units per workgroup (A/B)
   const int32_t* host_colidx = nullptr;  // the caller's arrays, valid ONLY inside lz_set_csr / lz_set_csr_transpose (pb_build reads them)
   const double* host_vals = nullptr;
 };

@@ -91,7 +91,7 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
     if (h->tune[17] == 0 || h->tune[17] == 4) {
       LZ_HIP(h, ell_build(A, 0, h->stream, h->tune[17] == 4 ? 2 : 1, A.ell_default));
       if (A.ell_coded) A.ell_default = true;
-      A.cls_group = h->tune[23] == 1 ? 1 : 2;
+      A.cls_group = h->tune[23];  // 0: two adjacent rows per lane; 1 / 3: one row per lane and trip, one / two units per workgroup (A/B)
     } else if (A.ell_default) {
       LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
     }

@@ -428,6 +428,97 @@ __global__ __launch_bounds__(kTPB) void k_spmv_cls(EllCode code, const double* _
   }
 }
 
+// The same with TWO ADJACENT ROWS PER LANE (the default for 5 and 7 entries per row).  rocprofv3 counters of k_spmv_cls on the headline
+// matrix (profiles/r05/pmc_spmv_summary.json): waves 43 % parked on memory, 43 % stalled at ISSUE, 14 % active; 5000 vector-memory
+// instructions per CU x ~16 clocks each = the kernel's 43 us - the texture-address unit takes a 64-lane 8-byte gather at 4 lanes per
+// clock, and a row costs eight such instructions (K gathers, class byte, own x, y).  Rows 2t and 2t + 1 of one class gather
+// x[2t + off], x[2t + 1 + off] as ONE 16-byte load per lane (8-byte aligned: fine for global loads), own x and y are 16-byte accesses,
+// the two class bytes one 2-byte load: four instructions per row.  Lanes whose two rows differ in class (a grid line's end) take two
+// 8-byte gathers.  The alpha partial must still be the one k_spmv_ell forms (lane L: rows L and L + 256 of the unit, in order): the
+// products own * sum go through LDS to that lane mapping, then the same wave sums.  Same bits.
+template <int K, bool SC>
+__global__ __launch_bounds__(kTPB) void k_spmv_cls2(EllCode code, const double* __restrict__ x, const double* __restrict__ xown, double* __restrict__ y,
+                                                   int rows, int rows_pad, double* __restrict__ part, SpmvScale sc) {
+  constexpr int RBU = 2 * kTPB;  // one alpha partial unit per workgroup
+  __shared__ double sm[kTPB / 64];
+  __shared__ __attribute__((aligned(16))) double sp[RBU];
+  extern __shared__ double s_tab[];  // [ncls * K] values, then [ncls * K] offsets
+  struct __attribute__((aligned(8))) Pair {  // two adjacent doubles at an 8-byte aligned address: one 16-byte load
+    double x, y;
+  };
+  const int blk = xcd_remap(blockIdx.x, gridDim.x);
+  const int ra = blk * RBU + 2 * (int)threadIdx.x;  // rows ra, ra + 1 (the class array is padded to whole units)
+  const unsigned short cpair = *reinterpret_cast<const unsigned short*>(code.cls + ra);
+  const bool live_a = ra < rows, live_b = ra + 1 < rows;
+  const int ca = cpair & 0xFF, cb = cpair >> 8;
+  bool scale = false;
+  double beta = 1.0;
+  const double* xs = x;
+  const double* xo = xown;
+  if constexpr (SC) {
+    scale = sc.gate[0] == 0;
+    if (scale) {
+      beta = sqrt(sc.nrm2[0]);
+      xs = sc.r;
+      xo = sc.r;
+      if (blockIdx.x == 0 && threadIdx.x == 0) sc.beta_slot[0] = beta;
+    }
+  }
+  double2 own = make_double2(0.0, 0.0);
+  if (ra + 1 < rows_pad) own = *reinterpret_cast<const double2*>(xo + ra);  // (rows_pad is even: both or neither)
+  const int nt = code.ncls * K;
+  int* s_off = reinterpret_cast<int*>(s_tab + nt);
+  for (int i = threadIdx.x; i < nt; i += kTPB) {
+    s_off[i] = code.off[i];
+    s_tab[i] = code.val[i];
+  }
+  __syncthreads();
+  double xa[K], xb[K];
+  if (live_b && ca == cb) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const Pair v = *reinterpret_cast<const Pair*>(xs + (ra + s_off[ca * K + k]));
+      xa[k] = v.x;
+      xb[k] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      xa[k] = xs[live_a ? ra + s_off[ca * K + k] : 0];
+      xb[k] = xs[live_b ? ra + 1 + s_off[cb * K + k] : 0];
+    }
+  }
+  if constexpr (SC) {
+    if (scale) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        xa[k] = xa[k] / beta;
+        xb[k] = xb[k] / beta;
+      }
+      own.x = own.x / beta;
+      own.y = own.y / beta;
+      if (ra + 1 < rows_pad) *reinterpret_cast<double2*>(sc.vj + ra) = own;  // (the pad of r is zero: 0 / beta keeps the pad of V[j] zero)
+    }
+  }
+  double suma = 0.0, sumb = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) suma += s_tab[ca * K + k] * xa[k];
+#pragma unroll
+  for (int k = 0; k < K; ++k) sumb += s_tab[cb * K + k] * xb[k];
+  if (live_b)
+    *reinterpret_cast<double2*>(y + ra) = make_double2(suma, sumb);
+  else if (live_a)
+    y[ra] = suma;
+  // own * sum of every row, to the lane mapping of the one-row-per-lane kernels (lane L adds rows L, then L + 256, of the unit)
+  *reinterpret_cast<double2*>(sp + 2 * threadIdx.x) = make_double2(live_a ? own.x * suma : 0.0, live_b ? own.y * sumb : 0.0);
+  __syncthreads();
+  double d = 0.0;
+  d += sp[threadIdx.x];
+  d += sp[threadIdx.x + kTPB];
+  d = block_sum(d, sm);
+  if (threadIdx.x == 0) part[blk] = d;
+}
+
 // ---- row classes of a fixed-K matrix, found on the device ------------------------------------------------------------------
 // Two open-addressing tables of 1024 slots (keys: a 64-bit hash of the row's K offsets / of its offsets and value bits; 0 = empty).
 // ctl: [0] classes by offsets, [1] classes by offsets + values, [2] / [3] "more than 256" of either, [4] a row that does not equal
@@ -731,6 +822,22 @@ static int launch_spmv_cls(const CsrDev& A, const double* x, double* y, const do
     hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, false>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, SpmvScale());
   return nunits;
 }
+template <int K>
+static int launch_spmv_cls2(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
+  const int nunits = (int)((A.rows + 2 * kTPB - 1) / (2 * kTPB));
+  const int rows_pad = (int)round_up(A.rows, kPadDoubles);
+  EllCode code;
+  code.cls = A.ell_cls;
+  code.off = A.cls_off;
+  code.val = A.cls_val;
+  code.ncls = A.ell_ncls;
+  const size_t lds = (size_t)A.ell_ncls * K * 12 + 8;
+  if (sc)
+    hipLaunchKernelGGL((k_spmv_cls2<K, true>), dim3(nunits), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, part, *sc);
+  else
+    hipLaunchKernelGGL((k_spmv_cls2<K, false>), dim3(nunits), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, part, SpmvScale());
+  return nunits;
+}
 template <int K, int RPT, int VEC>
 static int launch_spmv_ell_t(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
   if (A.ell_coded == 1) return launch_spmv_ell_c<K, RPT, VEC, 1>(A, x, y, x_own, part, s, sc);
@@ -741,8 +848,14 @@ int launch_spmv_ell(const CsrDev& A, const double* x, double* y, const double* x
   if (A.ell_coded == 2) {  // (always built with one row per lane and trip: ell_variant 0)
     // (the fused r / beta form holds 62 registers with one unit per workgroup, 112 with two: measured no faster in 2-D, 7 % slower on a
     // 300^3 grid - it keeps one; the plain SpMV takes two: 185 vs 191 us there, equal in 2-D.  tools/partial_step_probe.py, spmv_coding_probe.py)
-    const int G = sc ? 1 : A.cls_group;
+    const int G = (!sc && A.cls_group == 3) ? 2 : 1;
     if (A.fixed_k == 27) return launch_spmv_cls<27, 1, 1>(A, x, y, x_own, part, s, sc);
+    if (A.cls_group != 1 && A.cls_group != 3) {  // (knob 23: 1 / 3 = the one-row-per-lane forms, A/B)
+      // two adjacent rows per lane: headline 43.5 -> 35.1 us, C2 9.7 -> 8.7, 300^3 7-point 187 -> 178, 464^3 674 -> 624; the fused r / beta
+      // form 54.5 -> 51.0 us (5-point) but 235 -> 254 (7-point: 82 registers, five waves) - that one keeps one row per lane
+      if (A.fixed_k == 5) return launch_spmv_cls2<5>(A, x, y, x_own, part, s, sc);
+      if (!sc) return launch_spmv_cls2<7>(A, x, y, x_own, part, s, sc);
+    }
     if (A.fixed_k == 5) return G == 1 ? launch_spmv_cls<5, 2, 1>(A, x, y, x_own, part, s, sc) : launch_spmv_cls<5, 2, 2>(A, x, y, x_own, part, s, sc);
     return G == 1 ? launch_spmv_cls<7, 2, 1>(A, x, y, x_own, part, s, sc) : launch_spmv_cls<7, 2, 2>(A, x, y, x_own, part, s, sc);
   }

@@ -135,11 +135,12 @@ def test_spmv_row_class_coding_bit_exact(hip, name):
     x = np.random.default_rng(1).uniform(-1, 1, M)
     ref = H * x
     alphas = {}
-    for knob in (0, 1, 2, 4):
+    for knob in (0, 1, 2, 4, 10, 30):  # 10 / 30: auto with knob 23 = 1 / 3 (the one-row-per-lane forms of the fully coded kernel, A/B)
         h = hip.Handle(0)
-        h.set_tuning(hip.TUNE_FIXED_LAYOUT, knob)
+        h.set_tuning(hip.TUNE_FIXED_LAYOUT, knob if knob < 10 else 0)
+        h.set_tuning(hip.TUNE_CLS_GROUP, knob // 10)
         h.set_csr(M, 0, H.indptr, H.indices, H.data)
-        want = {0: (coding, classes), 1: ("none", 0), 2: ("none", 0), 4: ("offsets", classes)}[knob]
+        want = {0: (coding, classes), 1: ("none", 0), 2: ("none", 0), 4: ("offsets", classes), 10: (coding, classes), 30: (coding, classes)}[knob]
         assert h.spmv_coding() == want, (knob, h.spmv_coding())
         assert h.spmv_plan() == "fixed-k"
         for _ in range(2):
@@ -150,7 +151,7 @@ def test_spmv_row_class_coding_bit_exact(hip, name):
         alphas[knob] = h.step_spmv(1)
         assert np.array_equal(h.r_get(), ref)
         h.close()
-    assert alphas[0] == alphas[1] == alphas[2] == alphas[4]
+    assert alphas[0] == alphas[1] == alphas[2] == alphas[4] == alphas[10] == alphas[30]
 
 
 def test_spmv_row_class_coding_gives_way(hip):

@@ -18,7 +18,7 @@ for name, build, n in CASES:
     v0 = np.random.RandomState(99).uniform(-1, 1, M)
     v0 /= np.linalg.norm(v0)
     base = None
-    for layout, group in ((2, 0), (0, 1), (0, 0)):
+    for layout, group in ((2, 0), (0, 1), (0, 0)):  # knob 23: 1 = one row per lane (A/B), 0 = two adjacent rows per lane
         h = _capi.Handle(0)
         h.set_options(_capi.FLAG_REORTH_PARTIAL | _capi.FLAG_PROFILE)
         h.set_tuning(_capi.TUNE_FIXED_LAYOUT, layout)

@@ -1,5 +1,5 @@
 """Row-class coded SpMV (round 5) against the uncoded kernels, one MI355X: device time per SpMV (the library's hipEvents) for knob 17 =
-0 (auto: coded where the rows fall into classes; knob 23 = 1: one unit per workgroup), 1 (CSR-order fixed-K kernel / CSR-stream), 2 (uncoded
+0 (auto: coded where the rows fall into classes; knob 23 = 0 two adjacent rows per lane, 1 / 3 one row per lane with one / two units per workgroup), 1 (CSR-order fixed-K kernel / CSR-stream), 2 (uncoded
 ELL), 4 (offsets-only coding);
 y checked bit for bit against knob 1.   python tools/spmv_coding_probe.py > gpurun_out/spmv_coding_probe.jsonl"""
 import json
@@ -20,7 +20,7 @@ for name, dims, pts, pot in CASES:
     M = int(np.prod(dims))
     xs = np.random.default_rng(0).uniform(-1, 1, M)
     ref = None
-    for knob, group in ((1, 0), (2, 0), (4, 0), (0, 1), (0, 0)):
+    for knob, group in ((1, 0), (2, 0), (4, 0), (0, 1), (0, 3), (0, 0)):
         h = _capi.Handle(0)
         h.set_options(_capi.FLAG_FUSED_NORM | _capi.FLAG_PROFILE)
         h.set_tuning(_capi.TUNE_FIXED_LAYOUT, knob)
