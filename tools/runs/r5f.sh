@@ -22,6 +22,9 @@ for w in "$@"; do
 done
 cp $O/hbm_traffic.json $ROOT/profiles/hbm_traffic.json   # (on the box: the bench lines below read it; merged back by hand from gpurun_out/r5f)
 timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench default rc=$?"
+timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err; echo "bench driver-style rc=$?"
+timeout -k 10 600 python bench.py --workload deuteron3d_N160_27pt_k400 --steps 3 --warmup 1 > $O/bench_deuteron3d_N160_27pt_k400.json 2> $O/bench_deuteron.err; echo "bench deuteron rc=$?"
+timeout -k 10 300 python tools/partial_step_probe.py > $O/partial_step_probe.jsonl 2> $O/partial_step_probe.err; echo "partial step probe rc=$?"
 for w in "$@"; do
   [ "$w" = lap2d_5pt_M1e7_k200 ] && continue
   timeout -k 10 900 python bench.py --workload $w --steps 3 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w rc=$?"
