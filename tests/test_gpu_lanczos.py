@@ -1064,6 +1064,45 @@ def test_large_results_come_back_through_the_staged_copy_unchanged():
     h.close()
 
 
+def test_big_buffers_survive_allocation_churn(hip):
+    """Round 5 (profiles/r05/vmm_address_reuse_fault.txt): on this stack a fresh VMM mapping that lands on just-freed addresses
+    intermittently had holes - kernels faulted inside their own buffers.  `big_free` now frees a range and at once reserves the same
+    addresses again, unmapped, so that no later buffer lands on them.  Handles with VMM-sized buffers of changing sizes (a 330 - 650 MB
+    basis, Ritz vectors) are created, run and destroyed in turn while another one stays alive; every run of one size must give the
+    bits of the first run of that size, and the memory must be back at the end."""
+    probe = hip.Handle(0)
+    free0, _ = probe.device_memory()
+    A = synthetic.laplacian_2d_5pt(1300, 800)  # M = 1.04e6: 8.3 MB per basis row
+    M = A.shape[0]
+    v0 = synthetic.reference_start_vector(M)
+    v0 /= np.linalg.norm(v0)
+    keeper = hip.Handle(0)
+    keeper.set_options(hip.FLAG_FUSED_NORM)
+    keeper.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+    first = {}
+    for cyc, n in enumerate((40, 78, 52, 64, 40, 78, 45, 52, 64, 70, 40, 78)):
+        h = hip.Handle(0)
+        h.set_options(hip.FLAG_FUSED_NORM)
+        h.set_csr(M, 0, A.rowptr, A.colidx, A.vals)
+        a, b = h.run(n, v0)
+        S = np.linalg.eigh(np.diag(a) + np.diag(b, 1) + np.diag(b, -1))[1]
+        h.ritz_vectors(S, fetch=False)
+        G = h.ritz_gram()
+        assert np.abs(G - np.eye(n)).max() < 1e-10
+        if n in first:
+            assert np.array_equal(a, first[n][0]) and np.array_equal(b, first[n][1]), (cyc, n)
+        else:
+            first[n] = (a, b)
+        if cyc % 3 == 0:  # the long-lived handle allocates and drops big buffers in between
+            ka, kb = keeper.run(48 + cyc, v0)
+            assert np.array_equal(ka[:39], first[40][0][:39])  # (a longer run's leading coefficients are the shorter run's)
+        h.close()
+    keeper.close()
+    free1, _ = probe.device_memory()
+    probe.close()
+    assert abs(free1 - free0) < 96 << 20, (free0, free1)
+
+
 def test_closing_a_handle_gives_the_device_memory_back(hip):
     """Round 5: buffers of 256 MB and more are VMM ranges (reserve + create + map), everything else hipMalloc; `lz_destroy` must
     release both kinds - a plain hipFree of a mapped range fails silently and would leak it.  Several handles with a 400 MB basis,
