@@ -236,7 +236,9 @@ int lz_spmv_plan(lz_handle h, int* plan);
 /* Row-class coding of a fixed-K (stencil) matrix (round 5): where the rows of the matrix fall into <= 256 classes up to translation -
  * the K offsets col - row, and for constant coefficients the K values too - the SpMV streams ONE BYTE per row (the class; + 8 bytes per
  * entry when only the offsets repeat) instead of 12 bytes per entry; found and verified on the device at lz_set_csr, same products in the
- * same order (same bits).  coding: 0 none, 1 offsets by class (values streamed), 2 offsets and values by class; classes: how many. */
+ * same order (same bits).  coding: 0 none, 1 offsets by class (values streamed), 2 offsets and values by class, 3 offsets and the
+ * values OFF the diagonal by class with the diagonal's values streamed (8 more bytes per row: a constant-coefficient stencil plus a
+ * potential - the reference's Hamiltonians); classes: how many. */
 int lz_spmv_coding(lz_handle h, int* coding, int* classes);
 /* download the handle's CSR matrix (sizes from lz_csr_info) */
 int lz_get_csr(lz_handle h, int32_t* rowptr, int32_t* colidx, double* vals);

@@ -463,7 +463,7 @@ class Handle:
         self.check(self.lib.lz_spmv_plan(self._h, C.byref(k)))
         return self.SPMV_PLANS[k.value]
 
-    SPMV_CODINGS = ("none", "offsets", "offsets+values")
+    SPMV_CODINGS = ("none", "offsets", "offsets+values", "offsets+values, diagonal streamed")
 
     def spmv_coding(self):
         """row-class coding of a stencil matrix: ("none" | "offsets" | "offsets+values", number of classes)"""

@@ -73,6 +73,7 @@ struct CsrDev {
   uint8_t* ell_cls = nullptr;
   int32_t* cls_off = nullptr; // [256][K]
   double* cls_val = nullptr;  // [256][K]
+  double* cls_diag = nullptr; // ell_coded == 3: the diagonal's values, one per row (the class holds the offsets and the OTHER values)
   int ell_coded = 0;
   int ell_ncls = 0;
   int cls_group = 0;          // knob 23: 0 k_spmv_cls2 (two adjacent rows per lane); 1 / 3: k_spmv_cls with one / two units per workgroup (A/B)
@@ -100,6 +101,7 @@ bool ell_usable(const CsrDev& A, int flags);
 // stores the rows it owns to vj and beta to beta_slot; when gate[0] != 0 the sweep kernels have written vj and it is a plain
 // y = A vj.  y must not alias r.  Returns the number of alpha partials.
 struct EllCode {
+  const double* diag = nullptr;  // coded 3: the value of the entry at offset 0 comes from here
   const uint8_t* cls = nullptr;
   const int32_t* off = nullptr;
   const double* val = nullptr;

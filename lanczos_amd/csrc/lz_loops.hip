@@ -19,7 +19,7 @@ int ensure_part(lz_handle h, size_t need) {
 double spmv_bytes(lz_handle h, bool ell) {
   // (a row-class coded ELL copy: one class byte per row, the values only when they are not part of the class, x once, y)
   if (h->kind == 1 && h->csr.ell_coded && (ell || (h->csr.ell_default && ell_usable(h->csr, h->flags))))
-    return 17.0 * h->rows + (h->csr.ell_coded == 1 ? 8.0 * h->csr.nnz : 0.0);
+    return 17.0 * h->rows + (h->csr.ell_coded == 1 ? 8.0 * h->csr.nnz : 0.0) + (h->csr.ell_coded == 3 ? 8.0 * h->rows : 0.0);  // (3: + the diagonal)
   if (h->kind == 1) return 12.0 * h->csr.nnz + 4.0 * (h->rows + 1) + 16.0 * h->rows;
   return 8.0 * (double)h->rows * (double)h->Mg + 8.0 * (double)h->Mg + 8.0 * h->rows;  // A block, x once, y
 }

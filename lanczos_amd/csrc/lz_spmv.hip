@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kTPB) void k_spmv_ell(const int32_t* __restrict__ e
 // order), so the bits do not depend on G - and a lane keeps G RPT rows in flight: the values are read from LDS only when the gathers
 // have landed, which leaves registers for twice the rows of the uncoded kernel (the kernel is bound by two dependent memory round
 // trips - class byte, then x - not by bytes: 17 per row).
-template <int K, int RPT, int G, bool SC>
+template <int K, int RPT, int G, bool SC, bool DIAG>
 __global__ __launch_bounds__(kTPB) void k_spmv_cls(EllCode code, const double* __restrict__ x, const double* __restrict__ xown, double* __restrict__ y,
                                                   int rows, int rows_pad, int nunits, double* __restrict__ part, SpmvScale sc) {
   constexpr int RBU = kTPB * RPT;
@@ -361,6 +361,11 @@ __global__ __launch_bounds__(kTPB) void k_spmv_cls(EllCode code, const double* _
     for (int q = 0; q < RPT; ++q) lrow[g * RPT + q] = r0 + g * RBU + q * kTPB + (int)threadIdx.x;
 #pragma unroll
   for (int i = 0; i < NR; ++i) cl[i] = lrow[i] < rows ? (int)code.cls[lrow[i]] : -1;
+  double dg[NR];  // DIAG (coding 3): the diagonal's value streams, the class holds the rest
+  if constexpr (DIAG) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) dg[i] = lrow[i] < rows ? code.diag[lrow[i]] : 0.0;
+  }
   bool scale = false;
   double beta = 1.0;
   const double* xs = x;
@@ -410,7 +415,11 @@ __global__ __launch_bounds__(kTPB) void k_spmv_cls(EllCode code, const double* _
       if (lrow[i] < rows) {
         double sum = 0.0;
 #pragma unroll
-        for (int k = 0; k < K; ++k) sum += s_tab[cl[i] * K + k] * xv[i][k];
+        for (int k = 0; k < K; ++k) {
+          double a = s_tab[cl[i] * K + k];
+          if constexpr (DIAG) a = s_off[cl[i] * K + k] == 0 ? dg[i] : a;
+          sum += a * xv[i][k];
+        }
         y[lrow[i]] = sum;
         d += own[i] * sum;
       }
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(kTPB) void k_spmv_cls(EllCode code, const double* _
 // the two class bytes one 2-byte load: four instructions per row.  Lanes whose two rows differ in class (a grid line's end) take two
 // 8-byte gathers.  The alpha partial must still be the one k_spmv_ell forms (lane L: rows L and L + 256 of the unit, in order): the
 // products own * sum go through LDS to that lane mapping, then the same wave sums.  Same bits.
-template <int K, bool SC>
+template <int K, bool SC, bool DIAG>
 __global__ __launch_bounds__(kTPB) void k_spmv_cls2(EllCode code, const double* __restrict__ x, const double* __restrict__ xown, double* __restrict__ y,
                                                    int rows, int rows_pad, double* __restrict__ part, SpmvScale sc) {
   constexpr int RBU = 2 * kTPB;  // one alpha partial unit per workgroup
@@ -451,6 +460,8 @@ __global__ __launch_bounds__(kTPB) void k_spmv_cls2(EllCode code, const double* 
   const unsigned short cpair = *reinterpret_cast<const unsigned short*>(code.cls + ra);
   const bool live_a = ra < rows, live_b = ra + 1 < rows;
   const int ca = cpair & 0xFF, cb = cpair >> 8;
+  double2 dg = make_double2(0.0, 0.0);  // DIAG (coding 3): the diagonal's values stream (the array is padded to whole units)
+  if constexpr (DIAG) dg = *reinterpret_cast<const double2*>(code.diag + ra);
   bool scale = false;
   double beta = 1.0;
   const double* xs = x;
@@ -502,9 +513,17 @@ __global__ __launch_bounds__(kTPB) void k_spmv_cls2(EllCode code, const double* 
   }
   double suma = 0.0, sumb = 0.0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) suma += s_tab[ca * K + k] * xa[k];
+  for (int k = 0; k < K; ++k) {
+    double a = s_tab[ca * K + k];
+    if constexpr (DIAG) a = s_off[ca * K + k] == 0 ? dg.x : a;
+    suma += a * xa[k];
+  }
 #pragma unroll
-  for (int k = 0; k < K; ++k) sumb += s_tab[cb * K + k] * xb[k];
+  for (int k = 0; k < K; ++k) {
+    double a = s_tab[cb * K + k];
+    if constexpr (DIAG) a = s_off[cb * K + k] == 0 ? dg.y : a;
+    sumb += a * xb[k];
+  }
   if (live_b)
     *reinterpret_cast<double2*>(y + ra) = make_double2(suma, sumb);
   else if (live_a)
@@ -532,16 +551,20 @@ __device__ __forceinline__ unsigned long long cls_mix(unsigned long long h, unsi
   return h;
 }
 __device__ __forceinline__ void cls_hash(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int row, unsigned long long* h_off,
-                                         unsigned long long* h_all) {
-  unsigned long long h1 = 0x243F6A8885A308D3ull, h2 = 0x13198A2E03707344ull;
+                                         unsigned long long* h_all, unsigned long long* h_nd) {
+  unsigned long long h1 = 0x243F6A8885A308D3ull, h2 = 0x13198A2E03707344ull, h3 = 0xA4093822299F31D0ull;
   const int64_t e = (int64_t)row * K;
   for (int k = 0; k < K; ++k) {
-    const unsigned long long o = (unsigned long long)(long long)(colidx[e + k] - row);
+    const int off = colidx[e + k] - row;
+    const unsigned long long o = (unsigned long long)(long long)off;
+    const unsigned long long v = (unsigned long long)__double_as_longlong(vals[e + k]);
     h1 = cls_mix(h1, o);
-    h2 = cls_mix(cls_mix(h2, o), (unsigned long long)__double_as_longlong(vals[e + k]));
+    h2 = cls_mix(cls_mix(h2, o), v);
+    h3 = cls_mix(cls_mix(h3, o), off == 0 ? 0x5851F42D4C957F2Dull : v);  // (the diagonal's value is not part of this key)
   }
   *h_off = h1 ? h1 : 1;
   *h_all = h2 ? h2 : 1;
+  *h_nd = h3 ? h3 : 1;
 }
 __device__ __forceinline__ void cls_insert(unsigned long long* keys, int* rep, int* count, int* overflow, unsigned long long h, int row) {
   if (*reinterpret_cast<volatile int*>(overflow)) return;
@@ -562,13 +585,15 @@ __device__ __forceinline__ void cls_insert(unsigned long long* keys, int* rep, i
   atomicExch(overflow, 1);
 }
 __global__ __launch_bounds__(kTPB) void k_cls_insert(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int rows,
-                                                    unsigned long long* keys_off, int* rep_off, unsigned long long* keys_all, int* rep_all, int* ctl) {
+                                                    unsigned long long* keys_off, int* rep_off, unsigned long long* keys_all, int* rep_all,
+                                                    unsigned long long* keys_nd, int* rep_nd, int* ctl) {
   const int row = blockIdx.x * kTPB + threadIdx.x;
   if (row >= rows) return;
-  unsigned long long h1, h2;
-  cls_hash(colidx, vals, K, row, &h1, &h2);
+  unsigned long long h1, h2, h3;
+  cls_hash(colidx, vals, K, row, &h1, &h2, &h3);
   cls_insert(keys_off, rep_off, ctl + 0, ctl + 2, h1, row);
   cls_insert(keys_all, rep_all, ctl + 1, ctl + 3, h2, row);
+  cls_insert(keys_nd, rep_nd, ctl + 5, ctl + 6, h3, row);
 }
 // one block of kClsSlots threads: number the occupied slots in slot order and write the class table from the representatives
 __global__ __launch_bounds__(kClsSlots) void k_cls_number(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K,
@@ -595,15 +620,16 @@ __global__ __launch_bounds__(kClsSlots) void k_cls_number(const int32_t* __restr
     }
   }
 }
+// with_vals: 0 the class is the offsets; 1 offsets and values; 2 offsets and the values off the diagonal (the diagonal's value goes to diag[row])
 __global__ __launch_bounds__(kTPB) void k_cls_assign(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int rows, int with_vals,
                                                     const unsigned long long* __restrict__ keys, const int* __restrict__ ids,
                                                     const int32_t* __restrict__ toff, const double* __restrict__ tval, uint8_t* __restrict__ cls,
-                                                    int* ctl) {
+                                                    double* __restrict__ diag, int* ctl) {
   const int row = blockIdx.x * kTPB + threadIdx.x;
   if (row >= rows) return;
-  unsigned long long h1, h2;
-  cls_hash(colidx, vals, K, row, &h1, &h2);
-  const unsigned long long h = with_vals ? h2 : h1;
+  unsigned long long h1, h2, h3;
+  cls_hash(colidx, vals, K, row, &h1, &h2, &h3);
+  const unsigned long long h = with_vals == 1 ? h2 : (with_vals == 2 ? h3 : h1);
   unsigned slot = (unsigned)(h >> 20) & (kClsSlots - 1);
   int id = -1;
   for (int p = 0; p < kClsSlots; ++p, slot = (slot + 1) & (kClsSlots - 1))
@@ -612,11 +638,21 @@ __global__ __launch_bounds__(kTPB) void k_cls_assign(const int32_t* __restrict__
       break;
     }
   bool same = id >= 0 && id < kClsMax;
+  double dg = 0.0;
   if (same) {
     const int64_t e = (int64_t)row * K;
     for (int k = 0; k < K; ++k) {
-      same = same && toff[id * K + k] == colidx[e + k] - row;
-      if (with_vals) same = same && __double_as_longlong(tval[id * K + k]) == __double_as_longlong(vals[e + k]);
+      const int off = colidx[e + k] - row;
+      same = same && toff[id * K + k] == off;
+      if (with_vals == 2 && off == 0)
+        dg = vals[e + k];  // (a row with two entries on the diagonal keeps the last here and would sum both below: such a matrix hashes them
+                           // into the class key as "diagonal" twice and the kernel would use one value for both - refused:)
+      else if (with_vals) same = same && __double_as_longlong(tval[id * K + k]) == __double_as_longlong(vals[e + k]);
+    }
+    if (with_vals == 2) {
+      int ndiag = 0;
+      for (int k = 0; k < K; ++k) ndiag += colidx[e + k] == row;
+      same = same && ndiag <= 1;
     }
   }
   if (!same) {
@@ -624,6 +660,7 @@ __global__ __launch_bounds__(kTPB) void k_cls_assign(const int32_t* __restrict__
     return;
   }
   cls[row] = (uint8_t)id;
+  if (with_vals == 2) diag[row] = dg;
 }
 
 __global__ __launch_bounds__(kTPB) void k_ell_build(const int32_t* __restrict__ colidx, const double* __restrict__ vals, int K, int RB,
@@ -647,6 +684,8 @@ void ell_free(CsrDev& A) {
   if (A.ell_cls) hipFree(A.ell_cls);
   if (A.cls_off) hipFree(A.cls_off);
   if (A.cls_val) hipFree(A.cls_val);
+  if (A.cls_diag) hipFree(A.cls_diag);
+  A.cls_diag = nullptr;
   A.ell_c = nullptr;
   A.ell_v = nullptr;
   A.ell_cls = nullptr;
@@ -657,9 +696,10 @@ void ell_free(CsrDev& A) {
   A.ell_ncls = 0;
 }
 
-// Row classes of the fixed-K matrix A (see k_spmv_ell, CODED): returns the coding found - 2 offsets and values, 1 offsets only, 0 none
-// (more than 256 classes of either kind) - with A.ell_cls / cls_off / cls_val / ell_ncls filled in.  `want`: 1 try both, 2 offsets
-// only (A/B arm).  Two short synchronisations of `s` (this is matrix set-up).
+// Row classes of the fixed-K matrix A (see k_spmv_ell, CODED): returns the coding found - 2 offsets and values, 3 offsets and the values
+// off the diagonal (the diagonal streams: a constant-coefficient stencil plus a potential - the reference's own operators), 1 offsets
+// only, 0 none (more than 256 classes of every kind) - with A.ell_cls / cls_off / cls_val / cls_diag / ell_ncls filled in.  `want`: 1 try
+// all, 2 offsets only (A/B arm).  Two short synchronisations of `s` (this is matrix set-up).
 static hipError_t ell_classes(CsrDev& A, int want, hipStream_t s, int* coded_out) {
   *coded_out = 0;
   const int K = A.fixed_k;
@@ -670,28 +710,33 @@ static hipError_t ell_classes(CsrDev& A, int want, hipStream_t s, int* coded_out
       if (p) hipFree(p);
     }
   } scr;
-  // [keys_off 1024 u64 | keys_all 1024 u64 | rep_off 1024 | rep_all 1024 | ids 1024 | ctl 8]
-  const size_t bytes = 2 * kClsSlots * sizeof(unsigned long long) + (3 * kClsSlots + 8) * sizeof(int);
+  // [keys_off | keys_all | keys_nd: 1024 u64 each | rep_off | rep_all | rep_nd | ids: 1024 ints each | ctl 8]
+  const size_t bytes = 3 * kClsSlots * sizeof(unsigned long long) + (4 * kClsSlots + 8) * sizeof(int);
   hipError_t e = hipMalloc(&scr.p, bytes);
   if (e != hipSuccess) return e;
   unsigned long long* keys_off = static_cast<unsigned long long*>(scr.p);
   unsigned long long* keys_all = keys_off + kClsSlots;
-  int* rep_off = reinterpret_cast<int*>(keys_all + kClsSlots);
+  unsigned long long* keys_nd = keys_all + kClsSlots;
+  int* rep_off = reinterpret_cast<int*>(keys_nd + kClsSlots);
   int* rep_all = rep_off + kClsSlots;
-  int* ids = rep_all + kClsSlots;
-  int* ctl = ids + kClsSlots;
+  int* rep_nd = rep_all + kClsSlots;
+  int* ids = rep_nd + kClsSlots;
+  int* ctl = ids + kClsSlots;  // [0] / [1] / [5] classes by offsets / all values / off-diagonal values; [2] / [3] / [6] their overflows; [4] mismatch
   if ((e = hipMemsetAsync(scr.p, 0, bytes, s)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(rep_off, 0x7F, 2 * kClsSlots * sizeof(int), s)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(rep_off, 0x7F, 3 * kClsSlots * sizeof(int), s)) != hipSuccess) return e;
   const unsigned grid = (unsigned)((rows + kTPB - 1) / kTPB);
-  hipLaunchKernelGGL(k_cls_insert, dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, K, rows, keys_off, rep_off, keys_all, rep_all, ctl);
+  hipLaunchKernelGGL(k_cls_insert, dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, K, rows, keys_off, rep_off, keys_all, rep_all, keys_nd, rep_nd, ctl);
   int h_ctl[8] = {0};
   if ((e = hipMemcpyAsync(h_ctl, ctl, sizeof h_ctl, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
   int coded = 0;
   if (want == 1 && !h_ctl[3] && h_ctl[1] <= kClsMax) coded = 2;
+  else if (want == 1 && !h_ctl[6] && h_ctl[5] <= kClsMax) coded = 3;
   else if (!h_ctl[2] && h_ctl[0] <= kClsMax) coded = 1;
   if (!coded) return hipSuccess;
-  const int ncls = coded == 2 ? h_ctl[1] : h_ctl[0];
+  const int ncls = coded == 2 ? h_ctl[1] : (coded == 3 ? h_ctl[5] : h_ctl[0]);
+  const unsigned long long* keys = coded == 2 ? keys_all : (coded == 3 ? keys_nd : keys_off);
+  const int* rep = coded == 2 ? rep_all : (coded == 3 ? rep_nd : rep_off);
   void* p = nullptr;
   const int RB = A.ell_rb;
   const int64_t nblk = (A.rows + RB - 1) / RB;
@@ -702,14 +747,18 @@ static hipError_t ell_classes(CsrDev& A, int want, hipStream_t s, int* coded_out
   if ((e = hipMalloc(&p, (size_t)kClsMax * K * sizeof(double))) != hipSuccess) return e;
   A.cls_val = static_cast<double*>(p);
   if ((e = hipMemsetAsync(A.ell_cls, 0, (size_t)nblk * RB, s)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_cls_number, dim3(1), dim3(kClsSlots), 0, s, A.colidx, A.vals, K, coded == 2 ? keys_all : keys_off, coded == 2 ? rep_all : rep_off, ids,
-                     A.cls_off, A.cls_val);
-  hipLaunchKernelGGL(k_cls_assign, dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, K, rows, coded == 2 ? 1 : 0, coded == 2 ? keys_all : keys_off, ids, A.cls_off,
-                     A.cls_val, A.ell_cls, ctl);
+  if (coded == 3) {
+    if ((e = hipMalloc(&p, (size_t)nblk * RB * sizeof(double))) != hipSuccess) return e;
+    A.cls_diag = static_cast<double*>(p);
+    if ((e = hipMemsetAsync(A.cls_diag, 0, (size_t)nblk * RB * sizeof(double), s)) != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_cls_number, dim3(1), dim3(kClsSlots), 0, s, A.colidx, A.vals, K, keys, rep, ids, A.cls_off, A.cls_val);
+  hipLaunchKernelGGL(k_cls_assign, dim3(grid), dim3(kTPB), 0, s, A.colidx, A.vals, K, rows, coded == 2 ? 1 : (coded == 3 ? 2 : 0), keys, ids, A.cls_off,
+                     A.cls_val, A.ell_cls, A.cls_diag, ctl);
   if ((e = hipMemcpyAsync(h_ctl, ctl, sizeof h_ctl, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
   if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  if (h_ctl[4]) return hipSuccess;  // a hash collision (two different rows, one key): no coding
+  if (h_ctl[4]) return hipSuccess;  // a hash collision (two different rows, one key), or two entries on one diagonal: no coding
   A.ell_ncls = ncls;
   *coded_out = coded;
   return hipSuccess;
@@ -754,7 +803,7 @@ hipError_t ell_build(CsrDev& A, int variant, hipStream_t s, int coding, bool pla
     A.ell_c = static_cast<int32_t*>(p);
     e = hipMemsetAsync(A.ell_c, 0, cap * sizeof(int32_t), s);
   }
-  if (e == hipSuccess && coded != 2) {
+  if (e == hipSuccess && coded != 2 && coded != 3) {
     e = hipMalloc(&p, cap * sizeof(double));
     if (e == hipSuccess) {
       A.ell_v = static_cast<double*>(p);
@@ -766,7 +815,7 @@ hipError_t ell_build(CsrDev& A, int variant, hipStream_t s, int coding, bool pla
     ell_free(A);
     return e;
   }
-  if (coded != 2) {
+  if (coded != 2 && coded != 3) {
     const int64_t nnz = A.rows * K;
     hipLaunchKernelGGL(k_ell_build, dim3((unsigned)((nnz + kTPB - 1) / kTPB)), dim3(kTPB), 0, s, A.colidx, A.vals, K, RB, nnz, A.ell_c, A.ell_v);
     e = hipGetLastError();
@@ -816,10 +865,18 @@ static int launch_spmv_cls(const CsrDev& A, const double* x, double* y, const do
   code.val = A.cls_val;
   code.ncls = A.ell_ncls;
   const size_t lds = (size_t)A.ell_ncls * K * 12 + 8;
-  if (sc)
-    hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, true>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, *sc);
-  else
-    hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, false>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, SpmvScale());
+  code.diag = A.cls_diag;
+  const SpmvScale none;
+  if (A.ell_coded == 3) {
+    if (sc)
+      hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, true, true>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, *sc);
+    else
+      hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, false, true>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, none);
+  } else if (sc) {
+    hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, true, false>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, *sc);
+  } else {
+    hipLaunchKernelGGL((k_spmv_cls<K, RPT, G, false, false>), dim3(grid), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, nunits, part, none);
+  }
   return nunits;
 }
 template <int K>
@@ -832,10 +889,18 @@ static int launch_spmv_cls2(const CsrDev& A, const double* x, double* y, const d
   code.val = A.cls_val;
   code.ncls = A.ell_ncls;
   const size_t lds = (size_t)A.ell_ncls * K * 12 + 8;
-  if (sc)
-    hipLaunchKernelGGL((k_spmv_cls2<K, true>), dim3(nunits), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, part, *sc);
-  else
-    hipLaunchKernelGGL((k_spmv_cls2<K, false>), dim3(nunits), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, part, SpmvScale());
+  code.diag = A.cls_diag;
+  const SpmvScale none;
+  if (A.ell_coded == 3) {
+    if (sc)
+      hipLaunchKernelGGL((k_spmv_cls2<K, true, true>), dim3(nunits), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, part, *sc);
+    else
+      hipLaunchKernelGGL((k_spmv_cls2<K, false, true>), dim3(nunits), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, part, none);
+  } else if (sc) {
+    hipLaunchKernelGGL((k_spmv_cls2<K, true, false>), dim3(nunits), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, part, *sc);
+  } else {
+    hipLaunchKernelGGL((k_spmv_cls2<K, false, false>), dim3(nunits), dim3(kTPB), lds, s, code, x, x_own, y, (int)A.rows, rows_pad, part, none);
+  }
   return nunits;
 }
 template <int K, int RPT, int VEC>
@@ -845,7 +910,7 @@ static int launch_spmv_ell_t(const CsrDev& A, const double* x, double* y, const 
 }
 
 int launch_spmv_ell(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
-  if (A.ell_coded == 2) {  // (always built with one row per lane and trip: ell_variant 0)
+  if (A.ell_coded == 2 || A.ell_coded == 3) {  // (always built with one row per lane and trip: ell_variant 0)
     // (the fused r / beta form holds 62 registers with one unit per workgroup, 112 with two: measured no faster in 2-D, 7 % slower on a
     // 300^3 grid - it keeps one; the plain SpMV takes two: 185 vs 191 us there, equal in 2-D.  tools/partial_step_probe.py, spmv_coding_probe.py)
     const int G = (!sc && A.cls_group == 3) ? 2 : 1;

@@ -112,15 +112,15 @@ def _stencil_cases():
         G = H.copy()
         if what == "random":
             G.data = rng.standard_normal(G.nnz)
-        else:  # a potential on the diagonal: the reference's own operators (Hamiltonian.py) - offsets repeat, values do not
+        else:  # a potential on the diagonal: the reference's own operators (Hamiltonian.py) - offsets and off-diagonal values repeat, the diagonal streams
             G = (G + scipy.sparse.diags(rng.uniform(-1, 1, G.shape[0]))).tocsr()
         G.sort_indices()
         return G
 
     return {"lap2d_37x29": (lap2, "offsets+values", 9), "lap2d_400x300": (lap2b, "offsets+values", 9), "lap3d_21x17x13": (lap3, "offsets+values", 27),
             "lap2d_37x29_random_values": (with_values(lap2, "random"), "offsets", 9),
-            "lap3d_21x17x13_potential": (with_values(lap3, "potential"), "offsets", 27),
-            "lap2d_400x300_potential": (with_values(lap2b, "potential"), "offsets", 9)}
+            "lap3d_21x17x13_potential": (with_values(lap3, "potential"), "offsets+values, diagonal streamed", 27),
+            "lap2d_400x300_potential": (with_values(lap2b, "potential"), "offsets+values, diagonal streamed", 9)}
 
 
 @pytest.mark.parametrize("name", ["lap2d_37x29", "lap2d_400x300", "lap3d_21x17x13", "lap2d_37x29_random_values", "lap3d_21x17x13_potential",
@@ -164,14 +164,14 @@ def test_spmv_row_class_coding_gives_way(hip):
     x = np.random.default_rng(2).uniform(-1, 1, 3000)
     assert np.array_equal(h.spmv_host(x), H * x)
     h.close()
-    # 300 different diagonal values on a 5-point stencil: 9 offset classes, but 9 x 300 > 256 value classes -> offsets only
+    # 300 different diagonal values on a 5-point stencil: 9 x 300 > 256 classes of offsets + values -> the diagonal streams (9 classes)
     L = synthetic.laplacian_2d_5pt(60, 50).to_scipy()
     D = scipy.sparse.diags((np.arange(3000) % 300).astype(float))
     G = (L + D).tocsr()
     G.sort_indices()
     h = hip.Handle(0)
     h.set_csr(3000, 0, G.indptr, G.indices, G.data)
-    assert h.spmv_coding() == ("offsets", 9)
+    assert h.spmv_coding() == ("offsets+values, diagonal streamed", 9)
     assert np.array_equal(h.spmv_host(x), G * x)
     h.set_options(_capi.FLAG_SPMV_STREAM)  # the CSR-stream kernel on request: the coding is not in play
     assert h.spmv_coding() == ("none", 0) and h.spmv_plan() == "csr-stream"
@@ -185,6 +185,25 @@ def test_spmv_row_class_coding_gives_way(hip):
     kind, ncls = h.spmv_coding()
     assert kind == "offsets+values" and 25 <= ncls <= 225
     assert np.array_equal(h.spmv_host(x), G * x)
+    h.close()
+    # random OFF-diagonal values as well: only the offsets repeat
+    R = L.copy().tocsr()
+    R.data = np.random.default_rng(7).standard_normal(R.nnz)
+    h = hip.Handle(0)
+    h.set_csr(3000, 0, R.indptr, R.indices, R.data)
+    assert h.spmv_coding() == ("offsets", 9)
+    assert np.array_equal(h.spmv_host(x), R * x)
+    h.close()
+    # an explicit second entry on the diagonal (duplicate column) in a fixed-K matrix: the diagonal-streamed coding is refused
+    rows = np.repeat(np.arange(3000), 5)
+    cols = np.stack([np.arange(3000), np.arange(3000), (np.arange(3000) + 1) % 3000, (np.arange(3000) + 2) % 3000, (np.arange(3000) + 3) % 3000], axis=1).ravel()
+    vals = np.tile([1.0, 1.0, -1.0, -1.0, -1.0], 3000) + np.repeat(np.arange(3000) * 1e-3, 5) * (np.tile([1, 0, 0, 0, 0], 3000))
+    h = hip.Handle(0)
+    h.set_csr(3000, 0, np.arange(0, 15001, 5, dtype=np.int32), cols.astype(np.int32), vals)
+    assert h.spmv_coding()[0] in ("offsets", "none")
+    ref = np.zeros(3000)
+    np.add.at(ref, rows, vals * x[cols])  # (unordered accumulation: compare to rounding)
+    assert np.abs(h.spmv_host(x) - ref).max() <= 1e-12
     h.close()
 
 
