@@ -911,8 +911,10 @@ static int launch_spmv_ell_t(const CsrDev& A, const double* x, double* y, const 
 
 int launch_spmv_ell(const CsrDev& A, const double* x, double* y, const double* x_own, double* part, hipStream_t s, const SpmvScale* sc) {
   if (A.ell_coded == 2 || A.ell_coded == 3) {  // (always built with one row per lane and trip: ell_variant 0)
-    // (the fused r / beta form holds 62 registers with one unit per workgroup, 112 with two: measured no faster in 2-D, 7 % slower on a
-    // 300^3 grid - it keeps one; the plain SpMV takes two: 185 vs 191 us there, equal in 2-D.  tools/partial_step_probe.py, spmv_coding_probe.py)
+    // Which form runs (tools/spmv_coding_probe.py, partial_step_probe.py): 27 entries per row - one row per lane; 5 entries - two adjacent
+    // rows per lane, also with the fused r / beta; 7 entries - two adjacent rows per lane for the plain SpMV, one row per lane for the
+    // fused form.  Knob 23 = 1 / 3: the one-row-per-lane kernel with one / two 512-row units per workgroup (A/B: two units measured equal
+    // in 2-D, 185 vs 191 us on a 300^3 grid, and 7 % slower for the fused form - 112 registers - which therefore always takes one).
     const int G = (!sc && A.cls_group == 3) ? 2 : 1;
     if (A.fixed_k == 27) return launch_spmv_cls<27, 1, 1>(A, x, y, x_own, part, s, sc);
     if (A.cls_group != 1 && A.cls_group != 3) {  // (knob 23: 1 / 3 = the one-row-per-lane forms, A/B)
