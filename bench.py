@@ -661,6 +661,15 @@ def main():
                 and solver.h.spmv_coding()[0] != "none"):  # (not in the PMC / rocprofv3 passes, which run with --no-class-surface)
             arm_state["arm"] = "spmv_uncoded_arm"
             line["spmv_uncoded_arm"] = spmv_format_arm(_capi, local, local_rank, solver.h.spmv_coding())
+            coded_us = line["roofline_all"].get("spmv", {}).get("avg_us")
+            if coded_us:
+                # the headline metric's "SpMV GB/s vs HBM roofline": the coded kernel moves a fraction of the CSR bytes, so its GB/s and
+                # fraction (spmv_gbps, spmv_frac_hbm_peak: on the bytes it moves) are LOWER than the uncoded kernel's while it is faster
+                line["spmv_note"] = ("row-class coded SpMV (%s, %d classes): %.1f us per launch on %.0f MB; the uncoded CSR kernel of the same matrix in "
+                                     "this run: %.1f us on %.0f MB = %.3f of the HBM peak (spmv_uncoded_arm) - %.2fx slower"
+                                     % (solver.h.spmv_coding()[0], solver.h.spmv_coding()[1], coded_us, line["roofline_all"]["spmv"]["bytes_per_launch"] / 1e6,
+                                        line["spmv_uncoded_arm"]["avg_us"], line["spmv_uncoded_arm"]["bytes_per_launch"] / 1e6,
+                                        line["spmv_uncoded_arm"]["frac_hbm_peak"], line["spmv_uncoded_arm"]["avg_us"] / coded_us))
         if world == 1 and not args.no_class_surface and hasattr(local, "to_scipy"):
             arm_state["arm"] = "class_surface"
             if 16.0 * M * k > 120e9:
