@@ -359,13 +359,22 @@ class LanczosBase:
 
             hres = self._get_handle()
             basis_ready = threading.Event()
+            matrix_on_device = threading.Event()  # set when the upload thread is through (or was never started)
+            run_started = threading.Event()       # set when this thread enters lz_run (or gives up)
 
             def _reserve():
+                # Order matters where the device has to CLEAR the memory it hands out (a box whose free memory is "dirty": 16 GB take
+                # ~0.7 s there, and the small allocations of the matrix upload queue up behind the big one - measured 1.4 s of
+                # `device alloc` in lz_set_csr, tools/first_call_probe.py): first the matrix (0.6 GB, on the upload thread), then the
+                # basis, and the Ritz vectors only once the solve is running - nothing waits for them before `get_H_eigs`.
+                matrix_on_device.wait(60.0)
                 try:
                     hres.reserve(M, n, with_ritz=False)  # the basis: lz_run needs it
                 except Exception:  # never fatal: lz_run allocates (and reports) itself
                     pass
                 basis_ready.set()
+                run_started.wait(60.0)
+                time.sleep(0.03)  # (lz_run enqueues its whole loop in the first 3 - 10 ms: keep the allocator out of the launches' way)
                 try:
                     hres.reserve(M, n, with_ritz=2)  # the Ritz vectors ONLY: while the solve runs (lz_reserve touches only its own fields)
                 except Exception:
@@ -392,6 +401,9 @@ class LanczosBase:
                     self._upload_matrix(h, pending_key)
                 except BaseException as e:  # re-raised in the calling thread
                     upload_err.append(e)
+                finally:
+                    if reserve is not None:
+                        matrix_on_device.set()
 
             upload = threading.Thread(target=_upload, name="lz-upload", daemon=True)
             upload.start()
@@ -420,11 +432,14 @@ class LanczosBase:
             if self.reorth not in ("full", "partial"):
                 raise ValueError("reorth must be 'full' or 'partial'")
         finally:
+            if reserve is not None and upload is None:
+                matrix_on_device.set()  # (no upload thread: nothing to wait for)
             if upload is not None:
                 upload.join()
             if reserve is not None:  # the basis must be reserved (or given up on) before lz_run looks for it
                 basis_ready.wait()
                 self._reserved = (M, n)
+                run_started.set()  # (also on the error paths: the helper thread must not sit out its timeout)
         if upload_err:
             raise upload_err[0]
         t_2 = time.perf_counter()

@@ -87,6 +87,7 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
   // 0.21 (0.76 with streamed values) of the CSR bytes: it is every SpMV's default.  tune[17]: 2 / 3 keep the uncoded copy (A/B), 4 codes
   // the offsets only.
   A.ell_default = h->tune[17] >= 2 || (h->tune[17] == 0 && fixed_k == 27);
+  const double t_ell = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   if (fixed_k == 5 || fixed_k == 7 || fixed_k == 27) {
     if (h->tune[17] == 0 || h->tune[17] == 4) {
       LZ_HIP(h, ell_build(A, 0, h->stream, h->tune[17] == 4 ? 2 : 1, A.ell_default));
@@ -95,6 +96,9 @@ int fill_csr_meta(lz_handle h, CsrDev& A, const int32_t* rowptr_host, int64_t ro
     } else if (A.ell_default) {
       LZ_HIP(h, ell_build(A, h->tune[17] == 3 ? 1 : 0, h->stream));
     }
+    if (getenv("LZ_DEBUG_TIMING"))
+      fprintf(stderr, "[lz_set_csr] row classes / ELL copy: %.3f ms (coding %d, %d classes)\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_ell, A.ell_coded, A.ell_ncls);
   }
   const bool want = h->tune[14] == 2 || (h->tune[14] == 0 && fixed_k == 0 && ncols_ext >= ((int64_t)1 << 20) && A.far_frac > 0.25);
   if (want) {
